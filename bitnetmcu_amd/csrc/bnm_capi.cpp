@@ -1,0 +1,669 @@
+// C ABI of libbitnetmcu_hip.so / Bitnet_inf.dll (declared in include/bitnetmcu_hip.h).
+// Host side only: model handling, device residency, kernel selection, the reference's own symbols on top
+// of the device kernels.  There is NO CPU compute path in this file: if HIP is unusable, the reference-ABI
+// functions abort() and the bnm_* functions return BNM_EHIP.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "bnm_kernels.h"
+#include "bnm_model.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(BNM_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+    } while (0)
+
+uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1u) / m * m; }
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return BNM_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        HIP_TRY(hipMalloc(&p, need));
+        bytes = need;
+        return BNM_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct FcDev {
+    bnm_layer_info info{};
+    uint32_t n_real = 0;      // activations actually consumed
+    uint32_t act_stride = 0;  // bytes between consecutive input vectors of this layer
+    void *packed = nullptr;
+    int8_t *rows_lo = nullptr, *rows_hi = nullptr;
+    uint32_t row_stride = 0;
+};
+
+}  // namespace
+
+struct bnm_ctx {
+    int device = 0;
+    bnm_model model;
+    std::vector<FcDev> fc;
+    // CNN front end
+    uint32_t channels = 0;
+    int8_t *w_conv[3] = {nullptr, nullptr, nullptr};
+    // fused MFMA path
+    bool fused_ok = false;
+    BnmFusedShape shape{};
+    void *frags = nullptr;
+    int variant = -1, grid_blocks = 0;
+    // ternary ALU path
+    bool tern_ok = false;
+    int requested_path = BNM_PATH_AUTO, path = BNM_PATH_LAYERWISE_ALU;
+    // scratch
+    DevBuf act_a, act_b, out32, argmax, cnn_feat, stage_img, stage_cls, stage_logits;
+    std::vector<void *> owned;
+    std::mutex mu;
+};
+
+namespace {
+
+constexpr uint64_t kChunk = 1ull << 20;   // images per internal chunk of the staged / layer-wise paths
+
+int resolve_path(bnm_ctx *c) {
+    int want = c->requested_path;
+    bool all_tern = !c->fc.empty();
+    for (auto &l : c->fc) all_tern = all_tern && l.info.bits_per_weight == 64;
+    if (want == BNM_PATH_AUTO) {
+        if (c->model.kind == BNM_KIND_FC && all_tern && c->tern_ok) want = BNM_PATH_TERNARY_ALU;
+        else if (c->fused_ok) want = BNM_PATH_FUSED_MFMA;
+        else want = BNM_PATH_LAYERWISE_ALU;
+    }
+    if (want == BNM_PATH_FUSED_MFMA && !c->fused_ok)
+        return fail(BNM_EUNSUPPORTED, "model shape/codec is outside the fused MFMA kernel table");
+    if (want == BNM_PATH_TERNARY_ALU && !(c->tern_ok && c->model.kind == BNM_KIND_FC))
+        return fail(BNM_EUNSUPPORTED, "ternary ALU kernel needs a ternary FC 256-96-96-96-N model");
+    c->path = want;
+    return BNM_OK;
+}
+
+int dev_alloc(bnm_ctx *c, void **p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    c->owned.push_back(*p);
+    return BNM_OK;
+}
+
+int ctx_build(bnm_ctx *c) {
+    const bnm_model &m = c->model;
+    hipStream_t s = nullptr;
+    uint32_t width = 256;
+    size_t li = 0;
+    if (m.kind == BNM_KIND_CNN) {
+        c->channels = m.layers[0].info.out_channels;
+        const int conv_idx[3] = {0, 1, 3};
+        for (int k = 0; k < 3; k++) {
+            const BnmLayer &L = m.layers[conv_idx[k]];
+            void *p = nullptr;
+            if (int e = dev_alloc(c, &p, L.weights.size())) return e;
+            HIP_TRY(hipMemcpy(p, L.weights.data(), L.weights.size(), hipMemcpyHostToDevice));
+            c->w_conv[k] = (int8_t *)p;
+        }
+        width = c->channels * 4u;
+        li = 5;
+    }
+    const uint32_t in_width = width;
+    bool all_known = true, any_fp130 = false, all_tern = true;
+    for (; li < m.layers.size(); li++) {
+        const BnmLayer &L = m.layers[li];
+        FcDev d;
+        d.info = L.info;
+        d.n_real = bnm_fc_real_inputs(L.info, width);
+        d.act_stride = width;
+        if (int e = dev_alloc(c, &d.packed, L.weights.size())) return e;
+        HIP_TRY(hipMemcpy(d.packed, L.weights.data(), L.weights.size(), hipMemcpyHostToDevice));
+        d.row_stride = round_up(d.n_real, 32);
+        const size_t rb = (size_t)round_up(L.info.n_output, 32) * d.row_stride;
+        void *lo = nullptr, *hi = nullptr;
+        if (int e = dev_alloc(c, &lo, rb)) return e;
+        if (int e = dev_alloc(c, &hi, rb)) return e;
+        HIP_TRY(hipMemset(lo, 0, rb));
+        HIP_TRY(hipMemset(hi, 0, rb));
+        d.rows_lo = (int8_t *)lo;
+        d.rows_hi = (int8_t *)hi;
+        // GPU unpack: packed words -> int8 rows
+        HIP_TRY(bnmk_unpack_rows(d.packed, L.info.bits_per_weight, L.info.n_input, d.n_real, L.info.n_output, d.rows_lo,
+                                 d.rows_hi, d.row_stride, s));
+        all_known = all_known && bnm_codec_known(L.info.bits_per_weight);
+        any_fp130 = any_fp130 || L.info.bits_per_weight == 20;
+        all_tern = all_tern && L.info.bits_per_weight == 64;
+        width = L.info.n_output;
+        c->fc.push_back(d);
+    }
+
+    // ---- fused MFMA path: shape + fragment buffer --------------------------------------------------
+    const size_t nfc = c->fc.size();
+    if (all_known && (nfc == 3 || nfc == 4) && in_width % 32u == 0) {
+        BnmFusedShape sh{};
+        sh.KT0 = (int)(in_width / 32u);
+        for (size_t i = 0; i < 4; i++) sh.M[i] = i < nfc ? (int)((c->fc[i].info.n_output + 31u) / 32u) : 0;
+        sh.split = any_fp130;
+        int var = bnmk_fused_default_variant(sh);
+        if (bnmk_fused_supported(sh, var)) {
+            const int sp = sh.split ? 2 : 1;
+            size_t frag_count = 0;
+            int kt = sh.KT0;
+            for (size_t i = 0; i < nfc; i++) { frag_count += (size_t)sh.M[i] * kt * sp; kt = sh.M[i]; }
+            if (int e = dev_alloc(c, &c->frags, frag_count * 1024)) return e;
+            char *dst = (char *)c->frags;
+            kt = sh.KT0;
+            for (size_t i = 0; i < nfc; i++) {
+                const FcDev &d = c->fc[i];
+                // per M-tile the kernel expects [KT lo fragments][KT hi fragments]; the builder emits
+                // [m][s], so lo and hi are built per m into the interleaved place
+                for (int mt = 0; mt < sh.M[i]; mt++) {
+                    for (int part = 0; part < sp; part++) {
+                        const int8_t *rows = (part == 0 ? d.rows_lo : d.rows_hi) + (size_t)mt * 32u * d.row_stride;
+                        uint32_t rows_left = d.info.n_output > (uint32_t)mt * 32u ? d.info.n_output - (uint32_t)mt * 32u : 0u;
+                        HIP_TRY(bnmk_build_fragments(rows, d.row_stride, rows_left, d.n_real, 1, (uint32_t)kt, i == 0 ? 0 : 1,
+                                                     dst + ((size_t)mt * kt * sp + (size_t)part * kt) * 1024, s));
+                    }
+                }
+                dst += (size_t)sh.M[i] * kt * sp * 1024;
+                kt = sh.M[i];
+            }
+            c->shape = sh;
+            c->variant = var;
+            c->fused_ok = true;
+        }
+    }
+    // ---- ternary ALU path ------------------------------------------------------------------------------
+    if (m.kind == BNM_KIND_FC && all_tern && nfc == 4 && c->fc[0].n_real == 256 && c->fc[0].info.n_output == 96 &&
+        c->fc[1].info.n_output == 96 && c->fc[2].info.n_output == 96 && c->fc[3].info.n_output <= 64)
+        c->tern_ok = true;
+    HIP_TRY(hipDeviceSynchronize());
+    return resolve_path(c);
+}
+
+// ---- whole-model launches on device data -----------------------------------------------------------
+int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32_t *d_logits, hipStream_t s) {
+    BnmFusedArgs a{};
+    a.images = d_in;
+    a.n = n;
+    a.frags = c->frags;
+    a.n_classes = c->model.num_classes();
+    a.cls = d_cls;
+    a.logits = d_logits;
+    HIP_TRY(bnmk_fused_fc(c->shape, c->variant, c->grid_blocks, a, s));
+    return BNM_OK;
+}
+
+// FC chain layer by layer on [n][in_stride] int8 inputs; n <= kChunk
+int run_layerwise(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32_t *d_logits, int8_t *d_acts_tap,
+                  uint32_t tap_stride, uint32_t tap_off, hipStream_t s) {
+    uint32_t maxw = 0;
+    for (auto &l : c->fc) maxw = l.info.n_output > maxw ? l.info.n_output : maxw;
+    if (int e = c->act_a.ensure((size_t)n * maxw)) return e;
+    if (int e = c->act_b.ensure((size_t)n * maxw)) return e;
+    if (int e = c->out32.ensure((size_t)n * maxw * 4)) return e;
+    const int8_t *act = d_in;
+    int8_t *bufs[2] = {(int8_t *)c->act_a.p, (int8_t *)c->act_b.p};
+    for (size_t i = 0; i < c->fc.size(); i++) {
+        const FcDev &d = c->fc[i];
+        const bool last = i + 1 == c->fc.size();
+        int32_t *out = (last && d_logits) ? d_logits : (int32_t *)c->out32.p;
+        HIP_TRY(bnmk_fc_layer(act, d.act_stride, d.packed, d.info.bits_per_weight, d.info.n_input, d.info.n_output, out, n, s));
+        int8_t *nxt = bufs[i & 1];
+        HIP_TRY(bnmk_relunorm(out, d.info.n_output, nxt, d.info.n_output, last ? d_cls : nullptr, n, s));
+        if (d_acts_tap) {
+            HIP_TRY(hipMemcpy2DAsync(d_acts_tap + tap_off, tap_stride, nxt, d.info.n_output, d.info.n_output, n,
+                                     hipMemcpyDeviceToDevice, s));
+            tap_off += d.info.n_output;
+        }
+        act = nxt;
+    }
+    return BNM_OK;
+}
+
+int run_ternary(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32_t *d_logits, hipStream_t s) {
+    BnmTernArgs a{};
+    a.images = d_in;
+    a.n = n;
+    a.n_layers = 4;
+    for (int i = 0; i < 4; i++) {
+        a.rows[i] = c->fc[i].rows_lo;
+        a.stride[i] = c->fc[i].row_stride;
+        a.n_in[i] = c->fc[i].n_real;
+        a.n_out[i] = c->fc[i].info.n_output;
+    }
+    a.cls = d_cls;
+    a.logits = d_logits;
+    HIP_TRY(bnmk_ternary_alu(a, c->grid_blocks, s));
+    return BNM_OK;
+}
+
+int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls, int32_t *d_logits,
+                        int8_t *d_acts_tap, uint32_t tap_stride, hipStream_t s) {
+    if (!n) return BNM_OK;
+    if (!d_images || !d_cls) return fail(BNM_EINVAL, "null device pointer");
+    if (((uintptr_t)d_images & 15u) != 0) return fail(BNM_EINVAL, "d_images must be 16-byte aligned");
+    const uint32_t ncls = c->model.num_classes();
+    const int path = d_acts_tap ? BNM_PATH_LAYERWISE_ALU : c->path;
+    if (c->model.kind == BNM_KIND_FC) {
+        if (path == BNM_PATH_FUSED_MFMA) return run_fused(c, d_images, n, d_cls, d_logits, s);
+        if (path == BNM_PATH_TERNARY_ALU) return run_ternary(c, d_images, n, d_cls, d_logits, s);
+        for (uint64_t off = 0; off < n; off += kChunk) {
+            uint64_t cn = n - off < kChunk ? n - off : kChunk;
+            if (int e = run_layerwise(c, d_images + off * 256, cn, d_cls + off, d_logits ? d_logits + off * ncls : nullptr,
+                                      d_acts_tap ? d_acts_tap + off * tap_stride : nullptr, tap_stride, 0, s))
+                return e;
+        }
+        return BNM_OK;
+    }
+    // CNN: front end (conv/pool/ReLUNorm fused) -> int8 [n][4C] -> FC tail
+    const uint32_t W = c->channels * 4u;
+    for (uint64_t off = 0; off < n; off += kChunk) {
+        uint64_t cn = n - off < kChunk ? n - off : kChunk;
+        // the FC tail reads act rows with 16-byte vector loads: keep the buffer padded
+        if (int e = c->cnn_feat.ensure((size_t)cn * W * 4 + (size_t)cn * W + 64)) return e;
+        int32_t *feat = (c->channels > 64 || d_acts_tap) ? (int32_t *)c->cnn_feat.p : nullptr;
+        int8_t *acts = (int8_t *)c->cnn_feat.p + (size_t)cn * W * 4;
+        HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->channels, 4, acts, feat, s));
+        uint32_t *cls = d_cls + off;
+        int32_t *lg = d_logits ? d_logits + off * ncls : nullptr;
+        if (d_acts_tap)
+            HIP_TRY(hipMemcpy2DAsync(d_acts_tap + off * tap_stride, tap_stride, acts, W, W, cn, hipMemcpyDeviceToDevice, s));
+        if (path == BNM_PATH_FUSED_MFMA) {
+            if (int e = run_fused(c, acts, cn, cls, lg, s)) return e;
+        } else {
+            if (int e = run_layerwise(c, acts, cn, cls, lg, d_acts_tap ? d_acts_tap + off * tap_stride : nullptr, tap_stride,
+                                      d_acts_tap ? W : 0, s))
+                return e;
+        }
+    }
+    return BNM_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// (B) additive ABI
+// =================================================================================================
+extern "C" {
+
+const char *bnm_last_error(void) { return g_err.c_str(); }
+const char *bnm_version(void) { return "bitnetmcu_hip 0.1 (gfx950)"; }
+
+int bnm_model_from_header_text(const char *text, size_t len, bnm_model **out) {
+    if (!text || !out) return fail(BNM_EINVAL, "null argument");
+    bnm_model *m = new bnm_model();
+    std::string err;
+    if (!bnm_parse_header_text(text, len, *m, err)) {
+        delete m;
+        return fail(err.find("support") != std::string::npos ? BNM_EUNSUPPORTED : BNM_EPARSE, err);
+    }
+    *out = m;
+    return BNM_OK;
+}
+
+int bnm_model_from_blob(const void *blob, size_t len, bnm_model **out) {
+    if (!blob || !out) return fail(BNM_EINVAL, "null argument");
+    bnm_model *m = new bnm_model();
+    std::string err;
+    if (!bnm_deserialize(blob, len, *m, err)) {
+        delete m;
+        return fail(BNM_EPARSE, err);
+    }
+    *out = m;
+    return BNM_OK;
+}
+
+size_t bnm_model_blob_size(const bnm_model *m) { return m ? bnm_serialize(*m).size() : 0; }
+
+int bnm_model_to_blob(const bnm_model *m, void *dst, size_t cap) {
+    if (!m || !dst) return fail(BNM_EINVAL, "null argument");
+    std::vector<uint8_t> b = bnm_serialize(*m);
+    if (cap < b.size()) return fail(BNM_EINVAL, "destination too small");
+    std::memcpy(dst, b.data(), b.size());
+    return BNM_OK;
+}
+
+void bnm_model_free(bnm_model *m) { delete m; }
+uint32_t bnm_model_kind(const bnm_model *m) { return m ? m->kind : 0; }
+uint32_t bnm_model_num_layers(const bnm_model *m) { return m ? (uint32_t)m->layers.size() : 0; }
+uint32_t bnm_model_num_classes(const bnm_model *m) { return m ? m->num_classes() : 0; }
+uint32_t bnm_model_input_bytes(const bnm_model *) { return 256; }
+
+int bnm_model_layer(const bnm_model *m, uint32_t i, bnm_layer_info *info) {
+    if (!m || !info || i >= m->layers.size()) return fail(BNM_EINVAL, "layer index out of range");
+    *info = m->layers[i].info;
+    return BNM_OK;
+}
+
+const void *bnm_model_layer_weights(const bnm_model *m, uint32_t i) {
+    if (!m || i >= m->layers.size()) return nullptr;
+    return m->layers[i].weights.data();
+}
+
+int bnm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bnm_ctx_create(const bnm_model *m, int device, bnm_ctx **out) {
+    if (!m || !out) return fail(BNM_EINVAL, "null argument");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(BNM_EHIP, "no HIP device visible");
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return fail(BNM_EINVAL, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    bnm_ctx *c = new bnm_ctx();
+    c->device = device;
+    c->model = *m;
+    int e = ctx_build(c);
+    if (e != BNM_OK) {
+        std::string keep = g_err;
+        bnm_ctx_destroy(c);
+        g_err = keep;
+        return e;
+    }
+    *out = c;
+    return BNM_OK;
+}
+
+void bnm_ctx_destroy(bnm_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (void *p : c->owned) (void)hipFree(p);
+    for (DevBuf *b : {&c->act_a, &c->act_b, &c->out32, &c->argmax, &c->cnn_feat, &c->stage_img, &c->stage_cls, &c->stage_logits})
+        b->release();
+    delete c;
+}
+
+int bnm_ctx_device(const bnm_ctx *c) { return c ? c->device : -1; }
+
+int bnm_ctx_set_path(bnm_ctx *c, int path) {
+    if (!c || path < BNM_PATH_AUTO || path > BNM_PATH_TERNARY_ALU) return fail(BNM_EINVAL, "bad path");
+    int old = c->requested_path;
+    c->requested_path = path;
+    int e = resolve_path(c);
+    if (e != BNM_OK) { c->requested_path = old; (void)resolve_path(c); }
+    return e;
+}
+
+int bnm_ctx_get_path(const bnm_ctx *c) { return c ? c->path : BNM_EINVAL; }
+
+int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
+    if (!c) return fail(BNM_EINVAL, "null ctx");
+    if (variant >= 0) {
+        if (!c->fused_ok || !bnmk_fused_supported(c->shape, variant))
+            return fail(BNM_EUNSUPPORTED, "fused kernel variant not available for this model shape");
+        c->variant = variant;
+    }
+    c->grid_blocks = grid_blocks > 0 ? grid_blocks : 0;
+    return BNM_OK;
+}
+
+int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls, int32_t *d_logits, void *stream) {
+    if (!c) return fail(BNM_EINVAL, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    return infer_device_locked(c, d_images, n, d_cls, d_logits, nullptr, 0, (hipStream_t)stream);
+}
+
+static int infer_host_impl(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls, int32_t *logits, int8_t *acts,
+                           uint32_t acts_stride) {
+    if (!c) return fail(BNM_EINVAL, "null ctx");
+    if (n && (!images || (!cls && !acts))) return fail(BNM_EINVAL, "null host pointer");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t ncls = c->model.num_classes();
+    for (uint64_t off = 0; off < n; off += kChunk) {
+        uint64_t cn = n - off < kChunk ? n - off : kChunk;
+        if (int e = c->stage_img.ensure((size_t)cn * 256)) return e;
+        if (int e = c->stage_cls.ensure((size_t)cn * 4)) return e;
+        if (logits) if (int e = c->stage_logits.ensure((size_t)cn * ncls * 4)) return e;
+        DevBuf tap;
+        if (acts) if (int e = tap.ensure((size_t)cn * acts_stride)) return e;
+        HIP_TRY(hipMemcpy(c->stage_img.p, images + off * 256, (size_t)cn * 256, hipMemcpyHostToDevice));
+        int e = infer_device_locked(c, (const int8_t *)c->stage_img.p, cn, (uint32_t *)c->stage_cls.p,
+                                    logits ? (int32_t *)c->stage_logits.p : nullptr, acts ? (int8_t *)tap.p : nullptr,
+                                    acts_stride, nullptr);
+        if (e == BNM_OK) {
+            hipError_t he = hipDeviceSynchronize();
+            if (he != hipSuccess) e = fail(BNM_EHIP, std::string("kernel execution: ") + hipGetErrorString(he));
+        }
+        if (e == BNM_OK && cls) HIP_TRY(hipMemcpy(cls + off, c->stage_cls.p, (size_t)cn * 4, hipMemcpyDeviceToHost));
+        if (e == BNM_OK && logits)
+            HIP_TRY(hipMemcpy(logits + off * ncls, c->stage_logits.p, (size_t)cn * ncls * 4, hipMemcpyDeviceToHost));
+        if (e == BNM_OK && acts)
+            HIP_TRY(hipMemcpy(acts + off * acts_stride, tap.p, (size_t)cn * acts_stride, hipMemcpyDeviceToHost));
+        tap.release();
+        if (e != BNM_OK) return e;
+    }
+    return BNM_OK;
+}
+
+int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls, int32_t *logits) {
+    return infer_host_impl(c, images, n, cls, logits, nullptr, 0);
+}
+
+int bnm_infer_host_activations(bnm_ctx *c, const int8_t *images, uint64_t n, int8_t *acts, uint32_t acts_stride) {
+    if (!c || !acts) return fail(BNM_EINVAL, "null argument");
+    uint32_t need = c->model.kind == BNM_KIND_CNN ? c->channels * 4u : 0u;
+    for (auto &l : c->fc) need += l.info.n_output;
+    if (acts_stride < need) return fail(BNM_EINVAL, "acts_stride too small");
+    std::vector<uint32_t> cls(n);
+    return infer_host_impl(c, images, n, cls.data(), nullptr, acts, acts_stride);
+}
+
+int bnm_fc_layer_device(const int8_t *d_act, uint32_t act_stride, const void *d_weights, int32_t bpw, uint32_t n_input,
+                        uint32_t n_output, int32_t *d_out, uint64_t batch, void *stream) {
+    HIP_TRY(bnmk_fc_layer(d_act, act_stride, d_weights, bpw, n_input, n_output, d_out, batch, (hipStream_t)stream));
+    return BNM_OK;
+}
+
+int bnm_relunorm_device(const int32_t *d_in, uint32_t n, int8_t *d_out, uint32_t out_stride, uint32_t *d_argmax,
+                        uint64_t batch, void *stream) {
+    HIP_TRY(bnmk_relunorm(d_in, n, d_out, out_stride, d_argmax, batch, (hipStream_t)stream));
+    return BNM_OK;
+}
+
+int bnm_unpack_layer_host(const void *weights, int32_t bpw, uint32_t n_input, uint32_t n_output, int8_t *lo, int8_t *hi,
+                          uint32_t row_stride) {
+    if (!weights || !lo || row_stride % 4u) return fail(BNM_EINVAL, "bad argument");
+    uint64_t cnt = bnm_fc_weight_count(bpw, n_input, n_output);
+    size_t wbytes = (size_t)cnt * (bpw == 64 ? 2 : 4);
+    size_t rbytes = (size_t)n_output * row_stride;
+    void *dw = nullptr, *dlo = nullptr, *dhi = nullptr;
+    HIP_TRY(hipMalloc(&dw, wbytes ? wbytes : 16));
+    HIP_TRY(hipMalloc(&dlo, rbytes));
+    HIP_TRY(hipMalloc(&dhi, rbytes));
+    if (wbytes) HIP_TRY(hipMemcpy(dw, weights, wbytes, hipMemcpyHostToDevice));
+    uint32_t n_real = n_input < row_stride ? n_input : row_stride;
+    HIP_TRY(bnmk_unpack_rows(dw, bpw, n_input, n_real, n_output, (int8_t *)dlo, (int8_t *)dhi, row_stride, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(lo, dlo, rbytes, hipMemcpyDeviceToHost));
+    if (hi) HIP_TRY(hipMemcpy(hi, dhi, rbytes, hipMemcpyDeviceToHost));
+    (void)hipFree(dw);
+    (void)hipFree(dlo);
+    (void)hipFree(dhi);
+    return BNM_OK;
+}
+
+int bnm_synth_fill_device(int8_t *d_images, uint64_t first, uint64_t count, uint64_t seed, int dist, void *stream) {
+    if (count && !d_images) return fail(BNM_EINVAL, "null pointer");
+    if (dist != BNM_DIST_U && dist != BNM_DIST_M) return fail(BNM_EINVAL, "dist must be 0 or 1");
+    HIP_TRY(bnmk_synth_fill(d_images, first, count, seed, dist, (hipStream_t)stream));
+    return BNM_OK;
+}
+
+int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint64_t n, uint64_t *d_out, uint32_t n_bins, void *stream) {
+    if (n && (!d_cls || !d_out)) return fail(BNM_EINVAL, "null pointer");
+    if (n_bins > 64) return fail(BNM_EINVAL, "n_bins <= 64");
+    HIP_TRY(bnmk_class_digest(d_cls, first, n, d_out, n_bins, (hipStream_t)stream));
+    return BNM_OK;
+}
+
+int bnm_device_malloc(void **p, size_t bytes) { HIP_TRY(hipMalloc(p, bytes)); return BNM_OK; }
+int bnm_device_free(void *p) { HIP_TRY(hipFree(p)); return BNM_OK; }
+int bnm_memcpy_h2d(void *d, const void *h, size_t bytes) { HIP_TRY(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return BNM_OK; }
+int bnm_memcpy_d2h(void *h, const void *d, size_t bytes) { HIP_TRY(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return BNM_OK; }
+int bnm_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return BNM_OK; }
+
+}  // extern "C"
+
+// =================================================================================================
+// (A) the reference's own symbols
+// =================================================================================================
+// A model-bound build (Bitnet_inf.dll) links dll_stub.c, which embeds the exporter's header text between
+// these two symbols.  In the plain library they are absent (weak, null).
+extern "C" __attribute__((weak)) const char bnm_embedded_header_begin[];
+extern "C" __attribute__((weak)) const char bnm_embedded_header_end[];
+
+namespace {
+
+std::mutex g_mu;
+bnm_ctx *g_default = nullptr;
+DevBuf g_sa, g_sw, g_so, g_sb, g_sarg;   // scratch of the per-function host ABI
+
+[[noreturn]] void die(const char *what) {
+    std::fprintf(stderr, "bitnetmcu_hip: %s: %s\n(there is no CPU fallback; a HIP device is required)\n", what, g_err.c_str());
+    std::abort();
+}
+
+bnm_ctx *default_ctx() {
+    if (g_default) return g_default;
+    if (!bnm_embedded_header_begin || !bnm_embedded_header_end || +bnm_embedded_header_end <= +bnm_embedded_header_begin) {
+        g_err = "no model bound: build Bitnet_inf.dll with bitnetmcu_amd/build.py --dll <BitNetMCU_model.h> or call "
+                "bnm_bind_default_model()";
+        die("Inference");
+    }
+    bnm_model *m = nullptr;
+    if (bnm_model_from_header_text(bnm_embedded_header_begin, (size_t)(bnm_embedded_header_end - bnm_embedded_header_begin), &m) != BNM_OK)
+        die("embedded BitNetMCU_model.h");
+    bnm_ctx *c = nullptr;
+    if (bnm_ctx_create(m, -1, &c) != BNM_OK) die("GPU context");
+    bnm_model_free(m);
+    g_default = c;
+    return c;
+}
+
+// highest activation index a ternary layer can touch + 1 (pad trits are zero: exportquant.py:132-137)
+uint32_t ternary_used_inputs(const uint16_t *w, uint32_t n_input, uint32_t n_output) {
+    uint32_t per_row = n_input / 10u, used = 0;
+    for (uint32_t r = 0; r < n_output; r++)
+        for (uint32_t e = 0; e < per_row; e++) {
+            uint32_t chunk = w[r * per_row + e];
+            for (uint32_t t = 0; t < 10; t++) {
+                chunk *= 3u;
+                if ((chunk >> 16) != 2u && e * 10u + t + 1u > used) used = e * 10u + t + 1u;
+                chunk &= 0xFFFFu;
+            }
+        }
+    return used;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bnm_bind_default_model(const bnm_model *m) {
+    if (!m) return fail(BNM_EINVAL, "null model");
+    std::lock_guard<std::mutex> g(g_mu);
+    bnm_ctx *c = nullptr;
+    int e = bnm_ctx_create(m, -1, &c);
+    if (e != BNM_OK) return e;
+    if (g_default) bnm_ctx_destroy(g_default);
+    g_default = c;
+    return BNM_OK;
+}
+
+uint32_t BitMnistInference(int8_t *input) {
+    std::lock_guard<std::mutex> g(g_mu);
+    bnm_ctx *c = default_ctx();
+    uint32_t cls = 0;
+    if (bnm_infer_host(c, input, 1, &cls, nullptr) != BNM_OK) die("BitMnistInference");
+    return cls;
+}
+
+uint32_t Inference(int8_t *input) { return BitMnistInference(input); }
+
+void processfclayer(int8_t *activations, const uint32_t *weights, int32_t bpw, uint32_t n_input, uint32_t n_output,
+                    int32_t *output) {
+    std::lock_guard<std::mutex> g(g_mu);
+    if (!n_output) return;
+    uint64_t cnt = bnm_fc_weight_count(bpw, n_input, n_output);
+    if (!bnm_codec_known(bpw) || n_input > 1024) {
+        // BitNetMCU_inference.c:202: no branch taken -> sum stays 0 (too-wide layers are outside the MCU format)
+        if (bnm_codec_known(bpw)) { g_err = "processfclayer: n_input > 1024 unsupported"; die("processfclayer"); }
+        std::memset(output, 0, sizeof(int32_t) * n_output);
+        return;
+    }
+    uint32_t n_act = bpw == 64 ? ternary_used_inputs((const uint16_t *)weights, n_input, n_output) : n_input;
+    size_t wbytes = (size_t)cnt * (bpw == 64 ? 2 : 4);
+    uint32_t stride = n_act ? n_act : 1;
+    if (g_sa.ensure(stride + 16) || g_sw.ensure(wbytes + 16) || g_so.ensure((size_t)n_output * 4)) die("processfclayer");
+    bool ok = hipMemcpy(g_sw.p, weights, wbytes, hipMemcpyHostToDevice) == hipSuccess;
+    if (n_act) ok = ok && hipMemcpy(g_sa.p, activations, n_act, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && bnmk_fc_layer((const int8_t *)g_sa.p, stride, g_sw.p, bpw, n_input, n_output, (int32_t *)g_so.p, 1, nullptr) == hipSuccess;
+    ok = ok && hipMemcpy(output, g_so.p, (size_t)n_output * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) { g_err = hipGetErrorString(hipGetLastError()); die("processfclayer"); }
+}
+
+uint32_t ReLUNorm(int32_t *input, int8_t *output, uint32_t n_input) {
+    std::lock_guard<std::mutex> g(g_mu);
+    if (!n_input) return 255;
+    if (n_input > 1024) { g_err = "ReLUNorm: n_input > 1024 unsupported"; die("ReLUNorm"); }
+    if (g_so.ensure((size_t)n_input * 4) || g_sb.ensure(n_input) || g_sarg.ensure(4)) die("ReLUNorm");
+    uint32_t pos = 255;
+    bool ok = hipMemcpy(g_so.p, input, (size_t)n_input * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && bnmk_relunorm((const int32_t *)g_so.p, n_input, (int8_t *)g_sb.p, n_input, (uint32_t *)g_sarg.p, 1, nullptr) == hipSuccess;
+    ok = ok && hipMemcpy(&pos, g_sarg.p, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    // device -> host last: output may alias input (BitNetMCU_MNIST_dll.c:80)
+    ok = ok && hipMemcpy(output, g_sb.p, n_input, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) { g_err = hipGetErrorString(hipGetLastError()); die("ReLUNorm"); }
+    return pos;
+}
+
+int32_t *processconv33ReLU(int32_t *activations, const int8_t *weights, uint32_t xy, uint32_t n_shift, int32_t *output) {
+    std::lock_guard<std::mutex> g(g_mu);
+    if (xy < 3 || xy > 64) { g_err = "processconv33ReLU: xy_input outside [3,64]"; die("processconv33ReLU"); }
+    uint32_t o = xy - 2;
+    if (g_so.ensure((size_t)xy * xy * 4) || g_sw.ensure(16) || g_sa.ensure((size_t)o * o * 4)) die("processconv33ReLU");
+    bool ok = hipMemcpy(g_so.p, activations, (size_t)xy * xy * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(g_sw.p, weights, 9, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && bnmk_conv33((const int32_t *)g_so.p, (const int8_t *)g_sw.p, xy, n_shift, (int32_t *)g_sa.p, nullptr) == hipSuccess;
+    ok = ok && hipMemcpy(output, g_sa.p, (size_t)o * o * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) { g_err = hipGetErrorString(hipGetLastError()); die("processconv33ReLU"); }
+    return output + (size_t)o * o;
+}
+
+int32_t *processmaxpool22(int32_t *activations, uint32_t xy, int32_t *output) {
+    std::lock_guard<std::mutex> g(g_mu);
+    if (xy < 2 || xy > 64) { g_err = "processmaxpool22: xy_input outside [2,64]"; die("processmaxpool22"); }
+    uint32_t o = xy / 2;
+    if (g_so.ensure((size_t)xy * xy * 4) || g_sa.ensure((size_t)o * o * 4)) die("processmaxpool22");
+    bool ok = hipMemcpy(g_so.p, activations, (size_t)xy * xy * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && bnmk_maxpool22((const int32_t *)g_so.p, xy, (int32_t *)g_sa.p, nullptr) == hipSuccess;
+    ok = ok && hipMemcpy(output, g_sa.p, (size_t)o * o * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) { g_err = hipGetErrorString(hipGetLastError()); die("processmaxpool22"); }
+    return output + (size_t)o * o;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Launch wrappers for the gfx950 kernels in bnm_kernels.hip.  Everything here takes DEVICE
+// pointers and a hipStream_t and is asynchronous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+// ---- synthetic workload / digest -------------------------------------------------------------
+hipError_t bnmk_synth_fill(int8_t *d_images, uint64_t first, uint64_t count, uint64_t seed, int dist,
+                           hipStream_t s);
+hipError_t bnmk_class_digest(const uint32_t *d_cls, uint64_t first, uint64_t n, uint64_t *d_out,
+                             uint32_t n_bins, hipStream_t s);
+
+// ---- GPU unpack: packed words -> int8 rows -> MFMA A-operand fragments ------------------------
+// lo/hi: [n_output][row_stride] int8, w = lo + hi (hi != 0 only for FP1.3.0's +-128).
+hipError_t bnmk_unpack_rows(const void *d_packed, int32_t bpw, uint32_t n_input, uint32_t n_real,
+                            uint32_t n_output, int8_t *d_lo, int8_t *d_hi, uint32_t row_stride,
+                            hipStream_t s);
+// kmap 0: natural K order (layer fed by the raw image); 1: K order of the previous layer's packed
+// ReLUNorm output (see DESIGN.md §fragment layout).  dst: MT*KT fragments of 64 lanes x 16 B.
+hipError_t bnmk_build_fragments(const int8_t *d_rows, uint32_t row_stride, uint32_t n_output,
+                                uint32_t n_real, uint32_t MT, uint32_t KT, int kmap, void *d_dst,
+                                hipStream_t s);
+
+// ---- fused whole-model FC kernel (int8 MFMA) -------------------------------------------------
+struct BnmFusedShape {
+    int KT0;        // input row bytes / 32
+    int M[4];       // 32-row tiles of each FC layer's outputs; M[3] == 0 for 3-layer models
+    bool split;     // FP1.3.0: two A passes per K-step
+    bool operator==(const BnmFusedShape &o) const {
+        return KT0 == o.KT0 && M[0] == o.M[0] && M[1] == o.M[1] && M[2] == o.M[2] && M[3] == o.M[3] &&
+               split == o.split;
+    }
+};
+struct BnmFusedArgs {
+    const int8_t *images;   // [n][32*KT0]
+    uint64_t n;
+    const void *frags;      // fragment buffer built by bnmk_build_fragments, layers concatenated
+    uint32_t n_classes;
+    uint32_t *cls;          // [n]
+    int32_t *logits;        // [n][n_classes] or nullptr
+};
+// variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (KT0 == 8 only)
+bool bnmk_fused_supported(const BnmFusedShape &sh, int variant);
+hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a,
+                         hipStream_t s);
+int bnmk_fused_default_variant(const BnmFusedShape &sh);
+
+// ---- layer-wise ALU kernels (bit-serial unpack + wave-shuffle reduction) ----------------------
+hipError_t bnmk_fc_layer(const int8_t *d_act, uint32_t act_stride, const void *d_packed, int32_t bpw,
+                         uint32_t n_input, uint32_t n_output, int32_t *d_out, uint64_t batch,
+                         hipStream_t s);
+hipError_t bnmk_relunorm(const int32_t *d_in, uint32_t n, int8_t *d_out, uint32_t out_stride,
+                         uint32_t *d_argmax, uint64_t batch, hipStream_t s);
+hipError_t bnmk_conv33(const int32_t *d_in, const int8_t *d_w, uint32_t xy, uint32_t n_shift,
+                       int32_t *d_out, hipStream_t s);
+hipError_t bnmk_maxpool22(const int32_t *d_in, uint32_t xy, int32_t *d_out, hipStream_t s);
+
+// ---- CNN front end: 3 depthwise 3x3 convs + 2 pools per channel, batched ----------------------
+// images [n][256] int8 -> acts [n][4*C] int8 after the fused ReLUNorm (channel-major,
+// BitNetMCU_MNIST_dll.c:65,76,80); feat (optional) = the int32 values before ReLUNorm
+hipError_t bnmk_cnn_front(const int8_t *d_images, uint64_t n, const int8_t *d_w1, const int8_t *d_w2,
+                          const int8_t *d_w3, uint32_t C, uint32_t n_shift, int8_t *d_acts, int32_t *d_feat,
+                          hipStream_t s);
+
+// ---- ternary ALU whole-model kernel (sign-accumulate, no MFMA) -------------------------------
+struct BnmTernArgs {
+    const int8_t *images;  // [n][256]
+    uint64_t n;
+    const int8_t *rows[4];  // unpacked trits per layer [n_out][stride]
+    uint32_t stride[4];
+    uint32_t n_in[4];       // real inputs (256, 96, 96, 96)
+    uint32_t n_out[4];
+    uint32_t n_layers;
+    uint32_t *cls;
+    int32_t *logits;
+};
+hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s);

@@ -1,0 +1,155 @@
+"""Model (host, parsed header) and Context (model resident on one GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Model:
+    """A BitNetMCU model parsed from exporter-written header text or from a BNMBLOB1 blob.
+
+    Parsing is done by the native library (bitnetmcu_amd/csrc/bnm_model.cpp) so that C and Python
+    hosts share one loader; no GPU is needed for this class.
+    """
+
+    def __init__(self, handle, lib):
+        self._h, self._lib = handle, lib
+
+    @classmethod
+    def from_header_text(cls, text, lib=None):
+        lib = lib or L.load()
+        if isinstance(text, str):
+            text = text.encode()
+        h = C.c_void_p()
+        L.check(lib, lib.bnm_model_from_header_text(text, len(text), C.byref(h)), "bnm_model_from_header_text")
+        return cls(h, lib)
+
+    @classmethod
+    def from_header(cls, path, lib=None):
+        with open(path, "rb") as f:
+            return cls.from_header_text(f.read(), lib)
+
+    @classmethod
+    def from_blob(cls, blob, lib=None):
+        lib = lib or L.load()
+        blob = bytes(blob)
+        h = C.c_void_p()
+        L.check(lib, lib.bnm_model_from_blob(blob, len(blob), C.byref(h)), "bnm_model_from_blob")
+        return cls(h, lib)
+
+    def to_blob(self):
+        n = self._lib.bnm_model_blob_size(self._h)
+        buf = C.create_string_buffer(n)
+        L.check(self._lib, self._lib.bnm_model_to_blob(self._h, buf, n), "bnm_model_to_blob")
+        return buf.raw
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.bnm_model_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def kind(self):
+        return self._lib.bnm_model_kind(self._h)
+
+    @property
+    def num_classes(self):
+        return self._lib.bnm_model_num_classes(self._h)
+
+    @property
+    def num_layers(self):
+        return self._lib.bnm_model_num_layers(self._h)
+
+    def layer(self, i):
+        info = L.LayerInfo()
+        L.check(self._lib, self._lib.bnm_model_layer(self._h, i, C.byref(info)), "bnm_model_layer")
+        return info
+
+    def layer_weights(self, i):
+        """The layer's array exactly as the C compiler lays out ``Lk_weights[]`` (numpy copy)."""
+        info = self.layer(i)
+        if info.weight_count == 0:
+            return np.zeros(0, np.uint32)
+        dt = {4: np.uint32, 2: np.uint16, 1: np.int8}[info.weight_elem_bytes]
+        p = self._lib.bnm_model_layer_weights(self._h, i)
+        raw = C.string_at(p, info.weight_count * info.weight_elem_bytes)
+        return np.frombuffer(raw, dtype=dt).copy()
+
+    def layers(self):
+        return [self.layer(i) for i in range(self.num_layers)]
+
+    def fc_layers(self):
+        return [(i, li) for i, li in enumerate(self.layers()) if li.type == L.LAYER_FC]
+
+
+class Context:
+    """A model uploaded to and unpacked on one GPU (bnm_ctx)."""
+
+    def __init__(self, model, device=-1):
+        self._lib = model._lib
+        self.model = model
+        h = C.c_void_p()
+        L.check(self._lib, self._lib.bnm_ctx_create(model._h, device, C.byref(h)), "bnm_ctx_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bnm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def path(self):
+        return self._lib.bnm_ctx_get_path(self._h)
+
+    def set_path(self, path):
+        L.check(self._lib, self._lib.bnm_ctx_set_path(self._h, path), "bnm_ctx_set_path")
+
+    def set_tuning(self, variant=-1, grid_blocks=0):
+        L.check(self._lib, self._lib.bnm_ctx_set_tuning(self._h, variant, grid_blocks), "bnm_ctx_set_tuning")
+
+    # ---- host-pointer API (numpy) -------------------------------------------------------------
+    def infer(self, images, logits=False):
+        """images: int8 array [n,256] (or [n,16,16]).  Returns class ids (uint32[n]) and, if asked,
+        the last layer's int32 outputs [n,num_classes]."""
+        x = np.ascontiguousarray(images, dtype=np.int8).reshape(-1, 256)
+        n = x.shape[0]
+        cls = np.empty(n, np.uint32)
+        lg = np.empty((n, self.model.num_classes), np.int32) if logits else None
+        L.check(self._lib, self._lib.bnm_infer_host(self._h, x.ctypes.data, n, cls.ctypes.data,
+                                                    lg.ctypes.data if logits else None), "bnm_infer_host")
+        return (cls, lg) if logits else cls
+
+    def activations(self, images):
+        """int8 activations after every ReLUNorm, concatenated per image (parity tap)."""
+        x = np.ascontiguousarray(images, dtype=np.int8).reshape(-1, 256)
+        n = x.shape[0]
+        width = (self.model.layer(0).out_channels * 4 if self.model.kind == L.KIND_CNN else 0) + \
+            sum(li.n_output for _, li in self.model.fc_layers())
+        out = np.zeros((n, width), np.int8)
+        L.check(self._lib, self._lib.bnm_infer_host_activations(self._h, x.ctypes.data, n, out.ctypes.data, width),
+                "bnm_infer_host_activations")
+        return out
+
+    # ---- device-pointer API (torch tensors on the context's GPU) --------------------------------
+    def infer_device(self, images, cls, logits=None, stream=None):
+        """Asynchronous launch on torch's current stream (or `stream`).  images: torch.int8 [n,256]
+        cuda tensor; cls: torch.int32 [n]; logits: torch.int32 [n,num_classes] or None."""
+        import torch
+        n = images.shape[0]
+        assert images.is_cuda and images.is_contiguous() and images.dtype == torch.int8
+        assert cls.is_cuda and cls.is_contiguous() and cls.element_size() == 4 and cls.numel() >= n
+        s = stream if stream is not None else torch.cuda.current_stream(images.device)
+        L.check(self._lib, self._lib.bnm_infer_device(self._h, images.data_ptr(), n, cls.data_ptr(),
+                                                      logits.data_ptr() if logits is not None else None,
+                                                      s.cuda_stream), "bnm_infer_device")
+        return cls

@@ -1,0 +1,193 @@
+/*
+ * bitnetmcu_hip.h — C ABI of the MI355X-native BitNetMCU inference path.
+ *
+ * Two groups of entry points:
+ *
+ *  (A) The reference's own symbols, kept bit-for-bit compatible so that a library built from
+ *      this repository is a drop-in `Bitnet_inf.dll` for test_inference.py:134-150 and for any
+ *      code that links the reference's C functions directly.  All pointers are HOST pointers,
+ *      buffers are caller-owned, nothing is retained, there is no init/teardown call and no
+ *      error channel (the reference has none; an unsupported codec yields zeros,
+ *      BitNetMCU_inference.c:202).  GPU context and model upload happen lazily on first use.
+ *      If no HIP device is usable these functions abort() with a message on stderr — there is
+ *      deliberately NO CPU fallback.
+ *
+ *  (B) Additive entry points (prefix bnm_): run-time model loading from header text, batched
+ *      host- and device-pointer inference, synthetic workload generation, digests.  They return
+ *      0 on success or a negative BNM_E* code; bnm_last_error() gives the message.
+ */
+#ifndef BITNETMCU_HIP_H
+#define BITNETMCU_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define BNM_API __declspec(dllexport)
+#else
+#define BNM_API __attribute__((visibility("default")))
+#endif
+
+/* =============================== (A) reference ABI ========================================= */
+
+/* Replaces BitNetMCU_MNIST_dll.c:24-26 (`EXPORT uint32_t Inference(int8_t *input)`), the symbol
+ * test_inference.py:146-150 binds with argtypes=[POINTER(c_int8)], restype=c_uint32.
+ * input: 256 int8 (16x16 row-major, already quantised by the caller).  Returns the class id.
+ * Only present in a model-bound build (`Bitnet_inf.dll`) or after
+ * bnm_bind_default_model(). */
+BNM_API uint32_t Inference(int8_t *input);
+
+/* Replaces BitNetMCU_MNIST_dll.c:48 (CNN) / :95 (FC) `uint32_t BitMnistInference(int8_t*)`. */
+BNM_API uint32_t BitMnistInference(int8_t *input);
+
+/* Replaces BitNetMCU_inference.c:88 / BitNetMCU_inference.h:31.  Same argument meaning:
+ * activations int8[n_input], weights packed as in BitNetMCU_model.h (uint32 words, or uint16
+ * words reinterpreted for bits_per_weight == 64), bits_per_weight = the header's codec id
+ * (1,2,4,12,16,20,64; anything else => output zeros), output int32[n_output]. */
+BNM_API void processfclayer(int8_t *activations, const uint32_t *weights, int32_t bits_per_weight,
+                            uint32_t n_input, uint32_t n_output, int32_t *output);
+
+/* Replaces BitNetMCU_inference.c:23 / BitNetMCU_inference.h:15.  input int32[n_input] ->
+ * output int8[n_input] in [0,127]; returns the index of the first maximum.  output may alias
+ * input (the int32 -> int8 in-place use of BitNetMCU_MNIST_dll.c:80). */
+BNM_API uint32_t ReLUNorm(int32_t *input, int8_t *output, uint32_t n_input);
+
+/* Replaces BitNetMCU_inference.c:238 / BitNetMCU_inference.h:45.  Single channel valid 3x3
+ * convolution + ReLU + >> n_shift; output may alias activations; returns output + (xy-2)^2. */
+BNM_API int32_t *processconv33ReLU(int32_t *activations, const int8_t *weights, uint32_t xy_input,
+                                   uint32_t n_shift, int32_t *output);
+
+/* Replaces BitNetMCU_inference.c:300 / BitNetMCU_inference.h:60.  2x2/stride-2 max pool;
+ * output may alias activations; returns output + (xy/2)^2. */
+BNM_API int32_t *processmaxpool22(int32_t *activations, uint32_t xy_input, int32_t *output);
+
+/* =============================== (B) additive ABI ========================================== */
+
+#define BNM_OK 0
+#define BNM_EINVAL (-1)      /* bad argument */
+#define BNM_EPARSE (-2)      /* model header text / blob not understood */
+#define BNM_EUNSUPPORTED (-3) /* model topology outside what the reference wrapper can run */
+#define BNM_EHIP (-4)        /* HIP runtime error (no device, launch failure, ...) */
+#define BNM_ENOMODEL (-5)    /* Inference() called with no bound model */
+
+typedef struct bnm_model bnm_model;   /* host-side parsed model (no GPU needed) */
+typedef struct bnm_ctx bnm_ctx;       /* a model resident on one GPU */
+
+BNM_API const char *bnm_last_error(void);     /* thread-local message of the last failure */
+BNM_API const char *bnm_version(void);
+
+/* ---- model: the BitNetMCU_model.h interchange format (exportquant.py:49-263) -------------- */
+
+/* Parse exporter-written header TEXT at run time.  Layers are discovered in order of
+ * appearance, not by fixed names; all three textual variants in the reference
+ * tree are accepted. */
+BNM_API int bnm_model_from_header_text(const char *text, size_t len, bnm_model **out);
+/* Compact binary form of the same information ("BNMBLOB1"): what rank 0 broadcasts. */
+BNM_API int bnm_model_from_blob(const void *blob, size_t len, bnm_model **out);
+BNM_API size_t bnm_model_blob_size(const bnm_model *m);
+BNM_API int bnm_model_to_blob(const bnm_model *m, void *dst, size_t cap);
+BNM_API void bnm_model_free(bnm_model *m);
+
+#define BNM_KIND_FC 0
+#define BNM_KIND_CNN 1
+#define BNM_LAYER_FC 1
+#define BNM_LAYER_CONV 2
+#define BNM_LAYER_POOL 3
+
+typedef struct {
+    uint32_t type;            /* BNM_LAYER_* */
+    uint32_t order;           /* k of the header's Lk_ prefix */
+    int32_t bits_per_weight;  /* Lk_bitperweight */
+    uint32_t n_input;         /* FC: Lk_incoming_weights (padded count for ternary) */
+    uint32_t n_output;        /* FC: Lk_outgoing_weights */
+    uint32_t in_channels, out_channels, groups, kernel_size;   /* conv */
+    uint32_t incoming_x, outgoing_x;                           /* conv / pool */
+    uint32_t pool_size;                                        /* pool */
+    uint32_t weight_elem_bytes;  /* 4 (uint32), 2 (uint16 ternary), 1 (int8 conv), 0 (pool) */
+    uint32_t weight_count;       /* number of array elements */
+} bnm_layer_info;
+
+BNM_API uint32_t bnm_model_kind(const bnm_model *m);        /* BNM_KIND_* */
+BNM_API uint32_t bnm_model_num_layers(const bnm_model *m);
+BNM_API uint32_t bnm_model_num_classes(const bnm_model *m); /* n_output of the last FC layer */
+BNM_API uint32_t bnm_model_input_bytes(const bnm_model *m); /* 256 */
+BNM_API int bnm_model_layer(const bnm_model *m, uint32_t i, bnm_layer_info *info);
+BNM_API const void *bnm_model_layer_weights(const bnm_model *m, uint32_t i); /* as in the header */
+
+/* ---- context: model uploaded + unpacked on one GPU ---------------------------------------- */
+
+/* device < 0: current HIP device.  Uploads the packed weights and runs the GPU unpack kernels
+ * (packed words -> int8 rows -> MFMA operand fragments). */
+BNM_API int bnm_ctx_create(const bnm_model *m, int device, bnm_ctx **out);
+BNM_API void bnm_ctx_destroy(bnm_ctx *c);
+BNM_API int bnm_ctx_device(const bnm_ctx *c);
+
+/* Kernel selection for the whole-model path. */
+#define BNM_PATH_AUTO 0      /* fused MFMA kernel where the codec decodes to int8, else ALU */
+#define BNM_PATH_FUSED_MFMA 1
+#define BNM_PATH_LAYERWISE_ALU 2   /* one bit-serial kernel per layer (the reference's structure) */
+#define BNM_PATH_TERNARY_ALU 3     /* fused sign-accumulate kernel, no MFMA (ternary models) */
+BNM_API int bnm_ctx_set_path(bnm_ctx *c, int path);
+BNM_API int bnm_ctx_get_path(const bnm_ctx *c);   /* the path AUTO resolved to */
+/* Tuning knobs of the fused kernel: variant id and grid size
+ * (workgroups; 0 = default). */
+BNM_API int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks);
+
+/* Whole-model batched inference, DEVICE pointers, asynchronous on `stream` (a hipStream_t;
+ * NULL = default stream).  images: int8 [n][256]; cls: uint32 [n]; logits: int32
+ * [n][num_classes] or NULL.  No host synchronisation is performed. */
+BNM_API int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls,
+                             int32_t *d_logits, void *stream);
+/* Same with HOST pointers: stages through device memory in chunks, synchronises. */
+BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls,
+                           int32_t *logits);
+/* Debug/parity tap: int8 activations after every ReLUNorm of the FC chain, concatenated per
+ * image (host pointers, layer-wise path). */
+BNM_API int bnm_infer_host_activations(bnm_ctx *c, const int8_t *images, uint64_t n,
+                                       int8_t *acts, uint32_t acts_stride);
+
+/* Batched single-layer entry points, DEVICE pointers (the building blocks behind group A). */
+BNM_API int bnm_fc_layer_device(const int8_t *d_act, uint32_t act_stride, const void *d_weights,
+                                int32_t bits_per_weight, uint32_t n_input, uint32_t n_output,
+                                int32_t *d_out, uint64_t batch, void *stream);
+BNM_API int bnm_relunorm_device(const int32_t *d_in, uint32_t n, int8_t *d_out,
+                                uint32_t out_stride, uint32_t *d_argmax, uint64_t batch,
+                                void *stream);
+/* GPU unpack of one packed layer to int8 rows [n_output][row_stride] (+128 for FP130 is split
+ * into lo/hi parts: w = lo + hi).  Used by tests to pin the unpack kernels. */
+BNM_API int bnm_unpack_layer_host(const void *weights, int32_t bits_per_weight, uint32_t n_input,
+                                  uint32_t n_output, int8_t *lo, int8_t *hi, uint32_t row_stride);
+
+/* ---- synthetic workload + digests ---------------------------------------- */
+#define BNM_DIST_U 0
+#define BNM_DIST_M 1
+#define BNM_SEED_DIST_U 0xB17E7001ull
+#define BNM_SEED_DIST_M 0xB17E7002ull
+/* Fill count images (256 B each) for global image indices [first, first+count). */
+BNM_API int bnm_synth_fill_device(int8_t *d_images, uint64_t first, uint64_t count, uint64_t seed,
+                                  int dist, void *stream);
+/* d_out[0] += sum_i splitmix64((first+i)*64 + cls[i]);  d_out[1+c] += #(cls == c), c < n_bins
+ * (uint64 accumulators, caller zeroes them). */
+BNM_API int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint64_t n,
+                                    uint64_t *d_out, uint32_t n_bins, void *stream);
+
+/* ---- model binding for group A ------------------------------------------------------------ */
+/* Bind the model that Inference()/BitMnistInference() run.  A `Bitnet_inf.dll` built by
+ * bitnetmcu_amd/build.py --dll <header> does this itself from the embedded header text. */
+BNM_API int bnm_bind_default_model(const bnm_model *m);
+
+/* ---- device helpers (so a C host needs no other HIP code) -------------------------------- */
+BNM_API int bnm_device_count(void);
+BNM_API int bnm_device_malloc(void **p, size_t bytes);
+BNM_API int bnm_device_free(void *p);
+BNM_API int bnm_memcpy_h2d(void *d, const void *h, size_t bytes);
+BNM_API int bnm_memcpy_d2h(void *h, const void *d, size_t bytes);
+BNM_API int bnm_device_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,210 @@
+"""Shared helpers for the test-suite: library loaders and a Python statement of the reference's
+model schedule that can drive ANY implementation exposing the reference's four C signatures
+(the compiled reference in oracle/_ref, the oracle port, or the product's own reference-ABI symbols).
+"""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+REF_DIR = "/root/reference"
+ORACLE_SO = os.path.join(REPO, "oracle", "libbnm_oracle.so")
+REF_OUT = os.path.join(REPO, "oracle", "_ref")
+
+MODEL_NAMES = ["fc_4bitsym_64", "cnn_64", "mcu_12k", "mcu_12k_fp130", "mcu_1k", "mcu_cnn_16", "mcu_cnn_16small",
+               "mcu_cnn_32", "mcu_cnn_48", "mcu_cnn_64", "mcu_cnn_letters", "tern_96", "tern_96_sparse"]
+
+_i8p, _u32p, _i32p = C.POINTER(C.c_int8), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+
+
+def have_reference():
+    return os.path.isfile(os.path.join(REF_DIR, "BitNetMCU_inference.c"))
+
+
+def ref_dll_path(name, o3=False):
+    return os.path.join(REF_OUT, name, "Bitnet_inf_O3.dll" if o3 else "Bitnet_inf.dll")
+
+
+def have_ref_dll(name):
+    return os.path.isfile(ref_dll_path(name))
+
+
+class Funcs:
+    """The reference's four kernels behind one interface (numpy in / numpy out)."""
+
+    def __init__(self, lib, prefix=""):
+        self.lib = lib
+        g = lambda n: getattr(lib, prefix + n)
+        self.fc, self.rn = g("processfclayer"), g("ReLUNorm")
+        self.fc.restype = None
+        self.fc.argtypes = [_i8p, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, _i32p]
+        self.rn.restype = C.c_uint32
+        self.rn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        try:    # FC builds of the reference compile conv/pool out (BitNetMCU_inference.c:210 #ifndef MODEL_FCMNIST)
+            self.conv, self.pool = g("processconv33ReLU"), g("processmaxpool22")
+        except AttributeError:
+            self.conv = self.pool = None
+            return
+        self.fc.argtypes = [_i8p, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, _i32p]
+        self.rn.restype = C.c_uint32
+        self.rn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        self.conv.restype = C.c_void_p
+        self.conv.argtypes = [C.c_void_p, _i8p, C.c_uint32, C.c_uint32, C.c_void_p]
+        self.pool.restype = C.c_void_p
+        self.pool.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+
+    def processfclayer(self, act, weights, bpw, n_in, n_out):
+        act = np.ascontiguousarray(act, dtype=np.int8)
+        weights = np.ascontiguousarray(weights)
+        out = np.zeros(n_out, np.int32)
+        self.fc(act.ctypes.data_as(_i8p), weights.ctypes.data, bpw, n_in, n_out, out.ctypes.data_as(_i32p))
+        return out
+
+    def relunorm(self, x):
+        x = np.ascontiguousarray(x, dtype=np.int32).copy()
+        out = np.zeros(len(x), np.int8)
+        pos = self.rn(x.ctypes.data, out.ctypes.data, len(x))
+        return out, int(pos)
+
+    def relunorm_inplace(self, x):
+        """int32 -> int8 over the SAME buffer (BitNetMCU_MNIST_dll.c:80)."""
+        buf = np.ascontiguousarray(x, dtype=np.int32).copy()
+        pos = self.rn(buf.ctypes.data, buf.ctypes.data, len(buf))
+        return buf.view(np.int8)[:len(buf)].copy(), int(pos)
+
+    def conv33(self, plane, w, xy, shift, inplace=True):
+        buf = np.ascontiguousarray(plane, dtype=np.int32).copy()
+        w = np.ascontiguousarray(w, dtype=np.int8)
+        o = xy - 2
+        dst = buf if inplace else np.zeros(o * o, np.int32)
+        end = self.conv(buf.ctypes.data, w.ctypes.data_as(_i8p), xy, shift, dst.ctypes.data)
+        assert end == dst.ctypes.data + 4 * o * o
+        return dst[:o * o].copy()
+
+    def maxpool22(self, plane, xy, inplace=True):
+        buf = np.ascontiguousarray(plane, dtype=np.int32).copy()
+        o = xy // 2
+        dst = buf if inplace else np.zeros(o * o, np.int32)
+        end = self.pool(buf.ctypes.data, xy, dst.ctypes.data)
+        assert end == dst.ctypes.data + 4 * o * o
+        return dst[:o * o].copy()
+
+
+def run_schedule(f, model, image):
+    """The reference's BitMnistInference schedule (BitNetMCU_MNIST_dll.c:48-121) in terms of `f`.
+    Returns (class id, logits int32[n_classes], acts int8 concatenated after every ReLUNorm)."""
+    from bitnetmcu_amd import _lib as L
+    layers = model.layers()
+    acts = []
+    if model.kind == L.KIND_CNN:
+        C_ = layers[0].out_channels
+        w1, w2, w3 = model.layer_weights(0), model.layer_weights(1), model.layer_weights(3)
+        feat = []
+        for c in range(C_):
+            p = image.astype(np.int32)
+            p = f.conv33(p, w1[9 * c:9 * c + 9], 16, 4)
+            p = f.conv33(p, w2[9 * c:9 * c + 9], 14, 4)
+            p = f.maxpool22(p, 12)
+            p = f.conv33(p, w3[9 * c:9 * c + 9], 6, 4)
+            feat.append(f.maxpool22(p, 4))
+        act, _ = f.relunorm_inplace(np.concatenate(feat))
+        acts.append(act)
+        fcs = [(i, l) for i, l in enumerate(layers) if l.type == L.LAYER_FC]
+    else:
+        act = image.astype(np.int8)
+        fcs = list(enumerate(layers))
+    cls, logits = 255, None
+    for i, li in fcs:
+        # the reference passes its fixed-size layer_in buffer; ternary layers declare a padded n_input
+        buf = np.zeros(max(li.n_input, len(act)) + 16, np.int8)
+        buf[:len(act)] = act
+        logits = f.processfclayer(buf, model.layer_weights(i), li.bits_per_weight, li.n_input, li.n_output)
+        act, cls = f.relunorm(logits)
+        acts.append(act)
+    return cls, logits, np.concatenate(acts)
+
+
+def load_oracle():
+    if not os.path.isfile(ORACLE_SO):
+        import subprocess
+        subprocess.check_call([sys.executable, os.path.join(REPO, "oracle", "build_oracle.py"), "--port"])
+    lib = C.CDLL(ORACLE_SO)
+    lib.orc_weight_at.restype = C.c_int32
+    lib.orc_weight_at.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.orc_synth.restype = None
+    lib.orc_synth.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.orc_class_digest.restype = C.c_uint64
+    lib.orc_class_digest.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32]
+    lib.orc_model_batch.restype = None
+    lib.orc_model_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    return lib
+
+
+class OrcFcLayer(C.Structure):
+    _fields_ = [("bits_per_weight", C.c_int32), ("n_input", C.c_uint32), ("n_output", C.c_uint32), ("weights", C.c_void_p)]
+
+
+class OrcCnnFront(C.Structure):
+    _fields_ = [("channels", C.c_uint32), ("w_conv1", C.c_void_p), ("w_conv2", C.c_void_p), ("w_conv3", C.c_void_p),
+                ("n_shift", C.c_uint32)]
+
+
+class OracleModel:
+    """A parsed Model bound to the oracle port's batch driver (orc_model_batch)."""
+
+    def __init__(self, model, orc=None):
+        from bitnetmcu_amd import _lib as L
+        self.orc = orc or load_oracle()
+        self.model = model
+        layers = model.layers()
+        self._keep = []
+        fcs = [(i, l) for i, l in enumerate(layers) if l.type == L.LAYER_FC]
+        self.n_layers = len(fcs)
+        self.arr = (OrcFcLayer * len(fcs))()
+        for k, (i, li) in enumerate(fcs):
+            w = model.layer_weights(i)
+            self._keep.append(w)
+            self.arr[k] = OrcFcLayer(li.bits_per_weight, li.n_input, li.n_output, w.ctypes.data)
+        self.front = None
+        if model.kind == L.KIND_CNN:
+            ws = [model.layer_weights(i) for i in (0, 1, 3)]
+            self._keep += ws
+            self.front = OrcCnnFront(layers[0].out_channels, ws[0].ctypes.data, ws[1].ctypes.data, ws[2].ctypes.data, 4)
+        self.n_classes = model.num_classes
+
+    def infer(self, images, logits=False):
+        x = np.ascontiguousarray(images, dtype=np.int8).reshape(-1, 256)
+        n = len(x)
+        cls = np.zeros(n, np.uint32)
+        lg = np.zeros((n, self.n_classes), np.int32)
+        self.orc.orc_model_batch(x.ctypes.data, n, C.byref(self.front) if self.front else None, self.arr, self.n_layers,
+                                 cls.ctypes.data, lg.ctypes.data)
+        return (cls, lg) if logits else cls
+
+
+def load_golden_model(name):
+    from bitnetmcu_amd import Model
+    with open(os.path.join(GOLDEN, "models", name + ".bnm"), "rb") as f:
+        return Model.from_blob(f.read())
+
+
+def parse_c_int8_arrays(text):
+    """`int8_t input_data_k[256] = {...}; uint8_t label_k = v;` blocks (BitNetMCU_MNIST_test_data.h,
+    mcu/BitNetMCUdemo.c:23-28; commented-out blocks are skipped).  Returns (images int8 [k,256], labels)."""
+    text = re.sub(r"//[^\n]*", "", text)
+    imgs, labels = [], []
+    for m in re.finditer(r"int8_t\s+input_data_(\d+)\s*\[256\]\s*=\s*\{([^}]*)\}", text):
+        vals = [int(float(t)) if "." in t else int(t, 0)
+                for t in (s.strip() for s in m.group(2).split(",")) if t]
+        assert len(vals) == 256
+        imgs.append(np.array(vals, dtype=np.int64).astype(np.uint8).view(np.int8) if max(vals) > 127
+                    else np.array(vals, dtype=np.int8))
+        lm = re.search(r"label_%s\s*=\s*(\d+)" % m.group(1), text)
+        labels.append(int(lm.group(1)))
+    return np.stack(imgs), np.array(labels, dtype=np.uint32)
