@@ -17,7 +17,7 @@ __asm__(
     ".global bnm_embedded_header_begin\n"
     ".type bnm_embedded_header_begin, @object\n"
     "bnm_embedded_header_begin:\n"
-    ".incbin " BNM_MODEL_HEADER_PATH "\n"
+    ".incbin \"" BNM_MODEL_HEADER_PATH "\"\n"
     ".global bnm_embedded_header_end\n"
     ".type bnm_embedded_header_end, @object\n"
     "bnm_embedded_header_end:\n"

@@ -1,0 +1,57 @@
+"""Parity at BASELINE.json's full size (100M images = 25.6 GB resident) through size-independent properties:
+ * the class histogram sums to N and the order-independent digest is identical for the two fused kernel variants
+   (two different load paths) and for a sharded run (two halves, digests added) — the multi-GPU invariant;
+ * a strided + head + tail sample is bit-exact against the oracle (class ids and logits);
+ * inference is a pure per-image function: re-running a sub-range at a different tile alignment reproduces the ids."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+import bitnetmcu_amd as b
+from bitnetmcu_amd import synth, DIST_U
+
+pytestmark = pytest.mark.gpu
+
+N_FULL = int(os.environ.get("BNM_FULL_N", "100000000"))
+
+
+def test_full_size_properties(gpu_ok, orc):
+    import torch
+    model = util.load_golden_model("fc_4bitsym_64")
+    ctx = b.Context(model)
+    n = N_FULL
+    imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+    synth.fill_device(imgs, first=0, dist=DIST_U)
+    cls = torch.empty(n, dtype=torch.int32, device="cuda")
+    digests = {}
+    for variant in (1, 0):
+        ctx.set_tuning(variant=variant)
+        cls.fill_(-1)
+        ctx.infer_device(imgs, cls)
+        d = synth.digest_device(cls, first=0, n_bins=10).cpu().numpy()
+        assert int(d[1:].sum()) == n, "histogram does not sum to N"
+        digests[variant] = d
+    assert np.array_equal(digests[0], digests[1]), "LDS-DMA and direct-load kernels disagree"
+    # sharded run: two ranks' worth of work, digests combined as the all-reduce would
+    h = n // 2 + 17
+    parts = []
+    for first, last in ((0, h), (h, n)):
+        c2 = torch.empty(last - first, dtype=torch.int32, device="cuda")
+        ctx.infer_device(imgs[first:last], c2)
+        parts.append(synth.digest_device(c2, first=first, n_bins=10).cpu().numpy())
+        assert torch.equal(c2, cls[first:last])
+    assert np.array_equal(b.dist.combine_digests(parts).view(np.int64), digests[0])
+    # oracle on a sample
+    idx = np.unique(np.concatenate([np.arange(0, 3000), np.arange(n - 3000, n), np.linspace(0, n - 1, 6000).astype(np.int64)]))
+    ti = torch.from_numpy(idx).cuda()
+    sample = imgs[ti].cpu().numpy()
+    assert np.array_equal(sample, np.concatenate([synth.images(int(i), 1, DIST_U) for i in idx[:50]] +
+                                                 [sample[50:]])), "device generator drifted at large indices"
+    want_cls, want_lg = util.OracleModel(model, orc).infer(sample, logits=True)
+    assert np.array_equal(cls[ti].cpu().numpy().astype(np.uint32), want_cls)
+    lg = torch.empty((len(idx), 10), dtype=torch.int32, device="cuda")
+    ctx.infer_device(imgs[ti].contiguous(), torch.empty(len(idx), dtype=torch.int32, device="cuda"), lg)
+    assert np.array_equal(lg.cpu().numpy(), want_lg)
+    ctx.close()

@@ -1,0 +1,202 @@
+"""GPU parity tests (-m gpu): everything goes through the C ABI of libbitnetmcu_hip.so and is compared bit-exactly
+with (i) the committed golden vectors produced by the compiled reference and (ii) the oracle port on seeded
+synthetic inputs.  Integer work: the bar is bit-exact, class ids AND all logits AND all int8 activations."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import util
+from util import GOLDEN, MODEL_NAMES
+import bitnetmcu_amd as b
+from bitnetmcu_amd import synth, DIST_U, DIST_M
+
+pytestmark = pytest.mark.gpu
+
+
+def paths_for(ctx):
+    """(label, setup) for every kernel path this model can run."""
+    out = [("auto", lambda c: c.set_path(b.PATH_AUTO))]
+    out.append(("layerwise", lambda c: c.set_path(b.PATH_LAYERWISE_ALU)))
+    for v in (0, 1):
+        def fused(c, v=v):
+            c.set_path(b.PATH_FUSED_MFMA)
+            c.set_tuning(variant=v)
+        try:
+            fused(ctx)
+            out.append((f"fused_v{v}", fused))
+        except b.BnmError:
+            pass
+    try:
+        ctx.set_path(b.PATH_TERNARY_ALU)
+        out.append(("ternary_alu", lambda c: c.set_path(b.PATH_TERNARY_ALU)))
+    except b.BnmError:
+        pass
+    ctx.set_path(b.PATH_AUTO)
+    return out
+
+
+def test_device_generator_equals_host_generator(gpu_ok):
+    import torch
+    for dist in (DIST_U, DIST_M):
+        for first, count in ((0, 1000), (10**8 - 77, 77), (2**40 + 5, 33)):
+            t = torch.empty((count, 256), dtype=torch.int8, device="cuda")
+            synth.fill_device(t, first=first, dist=dist)
+            assert np.array_equal(t.cpu().numpy(), synth.images(first, count, dist))
+
+
+def test_class_digest_kernel(gpu_ok):
+    import torch
+    cls = np.random.default_rng(5).integers(0, 10, 100003).astype(np.uint32)
+    d = synth.digest_device(torch.from_numpy(cls.view(np.int32)).cuda(), first=12345, n_bins=10).cpu().numpy()
+    assert int(d[0].astype(np.uint64)) == synth.class_digest(cls, 12345)
+    assert d[1:].tolist() == np.bincount(cls, minlength=10).tolist()
+
+
+def test_gpu_unpack_kernels_all_codecs(gpu_ok, bnm, orc):
+    """packed words -> int8 rows on the GPU == orc_weight_at for every (row, k)."""
+    k = np.load(os.path.join(GOLDEN, "kat_codecs.npz"))
+    for c in range(int(k["n_cases"])):
+        bpw, n_in, n_out = (int(v) for v in k[f"c{c}_meta"])
+        w = np.ascontiguousarray(k[f"c{c}_w"])
+        stride = (n_in + 31) // 32 * 32
+        lo = np.zeros((n_out, stride), np.int8)
+        hi = np.zeros((n_out, stride), np.int8)
+        if bpw not in (1, 2, 4, 12, 16, 20, 64):
+            continue
+        b._lib.check(bnm, bnm.bnm_unpack_layer_host(w.ctypes.data, bpw, n_in, n_out, lo.ctypes.data, hi.ctypes.data, stride), "unpack")
+        want = np.array([[orc.orc_weight_at(w.ctypes.data, bpw, n_in, r, kk) for kk in range(n_in)] for r in range(n_out)])
+        assert np.array_equal(lo[:, :n_in].astype(np.int32) + hi[:, :n_in].astype(np.int32), want), (bpw, n_in, n_out)
+        assert not lo[:, n_in:].any() and not hi[:, n_in:].any()
+
+
+def test_reference_symbols_against_golden(gpu_ok, bnm):
+    """The drop-in per-function symbols (host pointers) on the reference-generated KATs."""
+    f = util.Funcs(bnm)
+    k = np.load(os.path.join(GOLDEN, "kat_codecs.npz"))
+    for c in range(int(k["n_cases"])):
+        bpw, n_in, n_out = (int(v) for v in k[f"c{c}_meta"])
+        for tag in "sux":
+            out = f.processfclayer(k[f"c{c}{tag}_act"], k[f"c{c}_w"], bpw, n_in, n_out)
+            assert np.array_equal(out, k[f"c{c}{tag}_out"]), (bpw, n_in, n_out, tag)
+    k = np.load(os.path.join(GOLDEN, "kat_relunorm.npz"))
+    for c in range(int(k["n_cases"])):
+        out, pos = f.relunorm(k[f"in{c}"])
+        assert np.array_equal(out, k[f"out{c}"]) and pos == int(k[f"pos{c}"]), c
+        out, pos = f.relunorm_inplace(k[f"in{c}"])
+        assert np.array_equal(out, k[f"out{c}"]) and pos == int(k[f"pos{c}"]), ("inplace", c)
+    k = np.load(os.path.join(GOLDEN, "kat_convpool.npz"))
+    for c in range(int(k["n_conv"])):
+        xy, shift = (int(v) for v in k[f"conv{c}_meta"])
+        for inplace in (True, False):
+            assert np.array_equal(f.conv33(k[f"conv{c}_in"], k[f"conv{c}_w"], xy, shift, inplace), k[f"conv{c}_out"])
+    for c in range(int(k["n_pool"])):
+        xy = int(k[f"pool{c}_meta"][0])
+        for inplace in (True, False):
+            assert np.array_equal(f.maxpool22(k[f"pool{c}_in"], xy, inplace), k[f"pool{c}_out"])
+
+
+@pytest.mark.parametrize("name", ["fc_4bitsym_64", "mcu_cnn_16small"])
+def test_reference_symbols_full_schedule(name, gpu_ok, bnm):
+    """BitMnistInference's schedule executed call by call through OUR processfclayer/ReLUNorm/conv/pool symbols."""
+    model = util.load_golden_model(name)
+    k = np.load(os.path.join(GOLDEN, f"kat_{name}.npz"))
+    f = util.Funcs(bnm)
+    for i in (0, 13, 80):
+        c, lg, acts = util.run_schedule(f, model, k["images"][i])
+        assert c == k["cls"][i] and np.array_equal(lg, k["logits"][i]) and np.array_equal(acts, k["acts"][i])
+
+
+@pytest.mark.parametrize("name", MODEL_NAMES)
+def test_model_golden_all_paths(name, gpu_ok):
+    model = util.load_golden_model(name)
+    k = np.load(os.path.join(GOLDEN, f"kat_{name}.npz"))
+    x, tn = k["images"], int(k["trace_n"])
+    ctx = b.Context(model)
+    seen = []
+    for label, setup in paths_for(ctx):
+        setup(ctx)
+        cls, lg = ctx.infer(x, logits=True)
+        assert np.array_equal(cls, k["cls"]), (name, label)
+        assert np.array_equal(lg[:tn], k["logits"]), (name, label)
+        seen.append(label)
+    assert np.array_equal(ctx.activations(x[:tn]), k["acts"]), name
+    assert "layerwise" in seen and len(seen) >= 2
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", MODEL_NAMES)
+def test_model_vs_oracle_synthetic(name, gpu_ok, orc):
+    model = util.load_golden_model(name)
+    om = util.OracleModel(model, orc)
+    n = 20000 if model.kind == b.KIND_FC else 1500
+    x = np.concatenate([synth.images(7_000_000, n, DIST_U), synth.images(3_000_000, n, DIST_M)])
+    want_cls, want_lg = om.infer(x, logits=True)
+    ctx = b.Context(model)
+    for label, setup in paths_for(ctx):
+        setup(ctx)
+        cls, lg = ctx.infer(x, logits=True)
+        assert np.array_equal(cls, want_cls), (name, label)
+        assert np.array_equal(lg, want_lg), (name, label)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["fc_4bitsym_64", "tern_96", "cnn_64"])
+def test_ragged_and_empty_batches(name, gpu_ok, orc):
+    model = util.load_golden_model(name)
+    om = util.OracleModel(model, orc)
+    ctx = b.Context(model)
+    x = synth.images(42, 4200, DIST_M)
+    want_cls, want_lg = om.infer(x, logits=True)
+    for label, setup in paths_for(ctx):
+        setup(ctx)
+        for n in (0, 1, 2, 31, 32, 33, 63, 64, 65, 127, 129, 1000, 4099):
+            cls, lg = ctx.infer(x[:n], logits=True)
+            assert cls.shape == (n,) and np.array_equal(cls, want_cls[:n]), (name, label, n)
+            assert np.array_equal(lg, want_lg[:n]), (name, label, n)
+            assert np.array_equal(ctx.infer(x[:n]), want_cls[:n])          # class ids only (no logits buffer)
+    ctx.close()
+
+
+def test_device_pointer_api_does_not_touch_neighbours(gpu_ok, orc):
+    """Ragged n on device buffers: nothing is written past cls[n] / logits[n]."""
+    import torch
+    model = util.load_golden_model("fc_4bitsym_64")
+    ctx = b.Context(model)
+    for variant in (0, 1):
+        ctx.set_tuning(variant=variant)
+        for n in (1, 33, 1000):
+            imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+            synth.fill_device(imgs, first=9, dist=DIST_U)
+            cls = torch.full((n + 64,), -7, dtype=torch.int32, device="cuda")
+            lg = torch.full((n + 64, 10), -7, dtype=torch.int32, device="cuda")
+            ctx.infer_device(imgs, cls, lg)
+            torch.cuda.synchronize()
+            want_cls, want_lg = util.OracleModel(model, orc).infer(imgs.cpu().numpy(), logits=True)
+            assert np.array_equal(cls[:n].cpu().numpy().astype(np.uint32), want_cls)
+            assert np.array_equal(lg[:n].cpu().numpy(), want_lg)
+            assert (cls[n:] == -7).all() and (lg[n:] == -7).all()
+    ctx.close()
+
+
+def test_relunorm_extremes_through_model_path(gpu_ok, orc):
+    """Images engineered to hit ReLUNorm's corners inside the fused kernel: all-zero input (every layer all zero,
+    argmax tie -> index 0), saturated inputs, and single-pixel inputs."""
+    x = np.zeros((70, 256), np.int8)
+    x[1] = 127
+    x[2] = -128
+    for i in range(3, 67):
+        x[i, (i * 37) % 256] = 127 if i % 2 else -128
+    x[67, ::2], x[67, 1::2] = 127, -128
+    x[68] = np.arange(256).astype(np.int8)
+    x[69] = -1
+    for name in ("fc_4bitsym_64", "mcu_1k", "mcu_12k_fp130", "tern_96", "cnn_64"):
+        model = util.load_golden_model(name)
+        want = util.OracleModel(model, orc).infer(x, logits=True)
+        ctx = b.Context(model)
+        for label, setup in paths_for(ctx):
+            setup(ctx)
+            got = ctx.infer(x, logits=True)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (name, label)
+        ctx.close()

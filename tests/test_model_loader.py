@@ -1,0 +1,85 @@
+"""Run-time loader of the BitNetMCU_model.h interchange format (bitnetmcu_amd/csrc/bnm_model.cpp) — host logic,
+no GPU.  Where /root/reference exists, every shipped header is parsed and compared with the committed blobs."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+from util import GOLDEN, MODEL_NAMES, REPO
+from headerwriter import write_header
+from bitnetmcu_amd import Model, BnmError, KIND_CNN, KIND_FC
+
+
+def same_model(a, b, orders=None):
+    assert a.kind == b.kind and a.num_layers == b.num_layers and a.num_classes == b.num_classes
+    for i in range(a.num_layers):
+        la, lb = a.layer(i), b.layer(i)
+        for f, _ in la._fields_:
+            if f == "order" and orders is not None:
+                assert lb.order == orders[i]
+            else:
+                assert getattr(la, f) == getattr(lb, f), (i, f)
+        assert np.array_equal(a.layer_weights(i), b.layer_weights(i))
+
+
+@pytest.mark.parametrize("name", MODEL_NAMES)
+def test_blob_roundtrip_and_dialects(name):
+    m = util.load_golden_model(name)
+    same_model(m, Model.from_blob(m.to_blob()))
+    same_model(m, Model.from_header_text(write_header(m, "exporter")))
+    same_model(m, Model.from_header_text(write_header(m, "oneline")))
+
+
+def test_layer_names_are_discovered_not_assumed():
+    """Today's exporter names FC layers by module index: L3,L5,L7,L9."""
+    m = util.load_golden_model("fc_4bitsym_64")
+    same_model(m, Model.from_header_text(write_header(m, "exporter", renumber=[3, 5, 7, 9])), orders=[3, 5, 7, 9])
+
+
+def test_shipped_headers_match_committed_blobs():
+    if not util.have_reference():
+        pytest.skip("/root/reference not present")
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from build_oracle import REF_MODELS
+    for name, hdr in REF_MODELS.items():
+        same_model(util.load_golden_model(name), Model.from_header(hdr))
+
+
+def test_committed_ternary_header_parses():
+    m = Model.from_header(os.path.join(GOLDEN, "headers", "tern_96.h"))
+    assert m.kind == KIND_FC and [l.n_input for l in m.layers()] == [260, 100, 100, 100]
+    assert m.layer(0).weight_elem_bytes == 2 and m.layer(0).weight_count == 96 * 26
+    same_model(m, util.load_golden_model("tern_96"))
+
+
+def test_model_facts():
+    m = util.load_golden_model("fc_4bitsym_64")
+    assert sum(l.weight_count * 4 for l in m.layers()) == 12608          # docs/documentation.md:488 (100,864 bits)
+    c = util.load_golden_model("cnn_64")
+    assert c.kind == KIND_CNN and c.layer(0).out_channels == 64 and c.num_classes == 10
+    assert util.load_golden_model("mcu_cnn_letters").num_classes == 37
+
+
+@pytest.mark.parametrize("bad,why", [
+    ("", "no Lk_active"),
+    ("#define L1_active\n#define L1_bitperweight 4\n", "incomplete"),
+    ("#define L1_active\n#define L1_bitperweight 4\n#define L1_incoming_weights 256\n#define L1_outgoing_weights 4\n"
+     "const uint32_t L1_weights[] = {0x1,0x2};\n", "too short"),
+    ("#define L1_active\n#define L1_bitperweight 4\n#define L1_incoming_weights 100\n#define L1_outgoing_weights 4\n"
+     "const uint32_t L1_weights[] = {0x1};\n", "does not match"),
+    ("#define L1_active\n#define L1_type Dense\n", "unknown layer type"),
+])
+def test_malformed_headers_are_rejected(bad, why):
+    with pytest.raises(BnmError) as e:
+        Model.from_header_text(bad)
+    assert why in str(e.value)
+
+
+def test_bad_blob_rejected():
+    with pytest.raises(BnmError):
+        Model.from_blob(b"not a blob at all........")
+    good = util.load_golden_model("mcu_1k").to_blob()
+    with pytest.raises(BnmError):
+        Model.from_blob(good[:100])
