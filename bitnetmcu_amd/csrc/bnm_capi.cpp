@@ -161,6 +161,10 @@ int ctx_build(bnm_ctx *c) {
         sh.KT0 = (int)(in_width / 32u);
         for (size_t i = 0; i < 4; i++) sh.M[i] = i < nfc ? (int)((c->fc[i].info.n_output + 31u) / 32u) : 0;
         sh.split = any_fp130;
+        // doubling needs |2w| <= 127 in every hidden layer: all codecs but 8-bit two's complement and FP1.3.0
+        sh.dbl = true;
+        for (size_t i = 0; i + 1 < nfc; i++)
+            if (c->fc[i].info.bits_per_weight == 16 || c->fc[i].info.bits_per_weight == 20) sh.dbl = false;
         int var = bnmk_fused_default_variant(sh);
         if (bnmk_fused_supported(sh, var)) {
             const int sp = sh.split ? 2 : 1;
@@ -178,7 +182,8 @@ int ctx_build(bnm_ctx *c) {
                     for (int part = 0; part < sp; part++) {
                         const int8_t *rows = (part == 0 ? d.rows_lo : d.rows_hi) + (size_t)mt * 32u * d.row_stride;
                         uint32_t rows_left = d.info.n_output > (uint32_t)mt * 32u ? d.info.n_output - (uint32_t)mt * 32u : 0u;
-                        HIP_TRY(bnmk_build_fragments(rows, d.row_stride, rows_left, d.n_real, 1, (uint32_t)kt, i == 0 ? 0 : 1,
+                        const int scale = (sh.dbl && i + 1 < nfc) ? 2 : 1;   // hidden layers only
+                        HIP_TRY(bnmk_build_fragments(rows, d.row_stride, rows_left, d.n_real, 1, (uint32_t)kt, i == 0 ? 0 : 1, scale,
                                                      dst + ((size_t)mt * kt * sp + (size_t)part * kt) * 1024, s));
                     }
                 }

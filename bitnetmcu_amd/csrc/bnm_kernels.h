@@ -18,7 +18,7 @@ hipError_t bnmk_unpack_rows(const void *d_packed, int32_t bpw, uint32_t n_input,
 // kmap 0: natural K order (layer fed by the raw image); 1: K order of the previous layer's packed
 // ReLUNorm output (see DESIGN.md §fragment layout).  dst: MT*KT fragments of 64 lanes x 16 B.
 hipError_t bnmk_build_fragments(const int8_t *d_rows, uint32_t row_stride, uint32_t n_output,
-                                uint32_t n_real, uint32_t MT, uint32_t KT, int kmap, void *d_dst,
+                                uint32_t n_real, uint32_t MT, uint32_t KT, int kmap, int scale, void *d_dst,
                                 hipStream_t s);
 
 // ---- fused whole-model FC kernel (int8 MFMA) -------------------------------------------------
@@ -26,9 +26,10 @@ struct BnmFusedShape {
     int KT0;        // input row bytes / 32
     int M[4];       // 32-row tiles of each FC layer's outputs; M[3] == 0 for 3-layer models
     bool split;     // FP1.3.0: two A passes per K-step
+    bool dbl;       // hidden-layer weight fragments doubled (every codec except 8-bit and FP1.3.0)
     bool operator==(const BnmFusedShape &o) const {
         return KT0 == o.KT0 && M[0] == o.M[0] && M[1] == o.M[1] && M[2] == o.M[2] && M[3] == o.M[3] &&
-               split == o.split;
+               split == o.split && dbl == o.dbl;
     }
 };
 struct BnmFusedArgs {
@@ -39,7 +40,8 @@ struct BnmFusedArgs {
     uint32_t *cls;          // [n]
     int32_t *logits;        // [n][n_classes] or nullptr
 };
-// variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (KT0 == 8 only)
+// variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (KT0 == 8 only), 2 = LDS-DMA with
+// 8-wave workgroups and staggered halves
 bool bnmk_fused_supported(const BnmFusedShape &sh, int variant);
 hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a,
                          hipStream_t s);

@@ -186,9 +186,10 @@ hipError_t bnmk_unpack_rows(const void *packed, int32_t bpw, uint32_t n_input, u
 //   kmap 0 (layer fed by a raw image row):          k = 32s + 16h + t
 //   kmap 1 (layer fed by the previous layer's packed ReLUNorm output, see relunorm_pack()):
 //                                                   k = 32s + 8(t>>2) + 4h + (t&3)
+// scale: 1, or 2 for hidden layers of the "doubled" kernels (see relunorm_pack<MT, true>).
 __global__ __launch_bounds__(256) void build_fragments_kernel(const int8_t *rows, uint32_t stride, uint32_t n_output,
                                                               uint32_t n_real, uint32_t MT, uint32_t KT, int kmap,
-                                                              uint32_t *dst) {
+                                                              int scale, uint32_t *dst) {
     uint32_t total = MT * KT * 64u * 4u;   // dwords
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         uint32_t j = i & 3u, lane = (i >> 2) & 63u, frag = i >> 8;
@@ -198,19 +199,19 @@ __global__ __launch_bounds__(256) void build_fragments_kernel(const int8_t *rows
 #pragma unroll
         for (uint32_t b = 0; b < 4; b++) {
             uint32_t k = kmap == 0 ? 32u * s + 16u * h + 4u * j + b : 32u * s + 8u * j + 4u * h + b;
-            int8_t w = (row < n_output && k < n_real) ? rows[(size_t)row * stride + k] : (int8_t)0;
-            v |= (uint32_t)(uint8_t)w << (8u * b);
+            int w = (row < n_output && k < n_real) ? (int)rows[(size_t)row * stride + k] * scale : 0;
+            v |= (uint32_t)(uint8_t)(int8_t)w << (8u * b);
         }
         dst[i] = v;
     }
 }
 
 hipError_t bnmk_build_fragments(const int8_t *rows, uint32_t stride, uint32_t n_output, uint32_t n_real, uint32_t MT,
-                                uint32_t KT, int kmap, void *dst, hipStream_t s) {
+                                uint32_t KT, int kmap, int scale, void *dst, hipStream_t s) {
     uint32_t total = MT * KT * 256u;
     if (!total) return hipSuccess;
     build_fragments_kernel<<<dim3((total + 255u) / 256u), dim3(256), 0, s>>>(rows, stride, n_output, n_real, MT, KT, kmap,
-                                                                             (uint32_t *)dst);
+                                                                             scale, (uint32_t *)dst);
     return hipGetLastError();
 }
 
@@ -271,11 +272,51 @@ BNM_DEVICE int partner32(int x, int h) {
     return h ? r[0] : r[1];
 }
 
+// clamp to [0, hi] in ONE instruction.  hipcc only forms v_med3_i32 from min(max(x, lo), hi) when it can prove
+// lo <= hi (constants); with a run-time hi it emits v_max + v_min.
+BNM_DEVICE int clamp0_med3(int x, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
+    return r;
+}
+
+// 16 clamped values -> 4 dwords, byte b of dword q = c[4q+b] >> s.  One SDWA shift per value writes its result
+// byte straight into place (dst_sel:BYTE_b, dst_unused:UNUSED_PRESERVE), so no separate pack instructions.
+// Same-register writes are 4 instructions apart and a trailing s_nop covers the dst_sel forwarding hazard that
+// hipcc cannot see inside an asm statement.
+BNM_DEVICE i32x4 sdwa_shift_pack16(const int (&c)[16], int s) {
+    int d0, d1, d2, d3;
+#define SD(dst, src, sel, unused) \
+    "v_lshrrev_b32_sdwa " dst ", %4, " src " dst_sel:" sel " dst_unused:" unused " src0_sel:DWORD src1_sel:DWORD\n\t"
+    asm(SD("%0", "%5", "BYTE_0", "UNUSED_PAD") SD("%1", "%9", "BYTE_0", "UNUSED_PAD")
+        SD("%2", "%13", "BYTE_0", "UNUSED_PAD") SD("%3", "%17", "BYTE_0", "UNUSED_PAD")
+        SD("%0", "%6", "BYTE_1", "UNUSED_PRESERVE") SD("%1", "%10", "BYTE_1", "UNUSED_PRESERVE")
+        SD("%2", "%14", "BYTE_1", "UNUSED_PRESERVE") SD("%3", "%18", "BYTE_1", "UNUSED_PRESERVE")
+        SD("%0", "%7", "BYTE_2", "UNUSED_PRESERVE") SD("%1", "%11", "BYTE_2", "UNUSED_PRESERVE")
+        SD("%2", "%15", "BYTE_2", "UNUSED_PRESERVE") SD("%3", "%19", "BYTE_2", "UNUSED_PRESERVE")
+        SD("%0", "%8", "BYTE_3", "UNUSED_PRESERVE") SD("%1", "%12", "BYTE_3", "UNUSED_PRESERVE")
+        SD("%2", "%16", "BYTE_3", "UNUSED_PRESERVE") SD("%3", "%20", "BYTE_3", "UNUSED_PRESERVE")
+        "s_nop 0"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+        : "v"(s), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]),
+          "v"(c[9]), "v"(c[10]), "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
+#undef SD
+    i32x4 r = {d0, d1, d2, d3};
+    return r;
+}
+
 // ReLUNorm (BitNetMCU_inference.c:23-72) on MT x 16 accumulator values per lane (+ the partner lane's),
 // result packed as the next layer's B operand: packed[m][q] byte b = row 32m + 8q + 4h + b.
 // Rows >= n_output are zero weights => value 0: they can only raise a negative maximum to 0, in which case
 // every output is 0 either way.
-template <int MT>
+//
+// DBL = false: accumulators hold the layer sums x.   out = clamp((x + r) >> s, 0, 127), 4 VALU per value.
+// DBL = true : this layer's weight fragments were built DOUBLED, accumulators hold 2x (exact).  With
+//   s = bitlength(max(2x) >> 8) (= the reference's shift, from max(x) >> 7) and y = clamp(2x, 0, 255*2^s - 1) >> s
+//   (0..254, one v_med3 + one SDWA shift that also packs), the rounded result is
+//   (x + 2^(s-1)) >> s = (2x + 2^s) >> (s+1) = (y + 1) >> 1, which v_lerp_u8 computes for 4 bytes at once;
+//   y <= 254 makes the "clip 128 to 127" case (:62-66) fall out.  2.25 VALU per value, bit-exact.
+template <int MT, bool DBL>
 BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int h) {
     int mx = acc[0][0];
 #pragma unroll
@@ -284,41 +325,60 @@ BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int 
         for (int r = 0; r < 16; r++) mx = max(mx, acc[m][r]);
     mx = max(mx, partner32(mx, h));
     mx = max(mx, 0);
-    uint32_t t = (uint32_t)mx >> 7;
-    int sh = t ? 32 - __builtin_clz(t) : 0;
-    int rnd = (1 << sh) >> 1;
+    if constexpr (DBL) {
+        uint32_t t = (uint32_t)mx >> 8;
+        int sh = t ? 32 - __builtin_clz(t) : 0;
+        int hi = (255 << sh) - 1;
 #pragma unroll
-    for (int m = 0; m < MT; m++)
+        for (int m = 0; m < MT; m++) {
+            int c[16];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t d = 0;
+            for (int r = 0; r < 16; r++) c[r] = clamp0_med3(acc[m][r], hi);
+            i32x4 y = sdwa_shift_pack16(c, sh);
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                int v = (acc[m][4 * q + b] + rnd) >> sh;
-                v = min(max(v, 0), 127);
-                d |= (uint32_t)v << (8 * b);
-            }
-            packed[m][q] = (int)d;
+            for (int q = 0; q < 4; q++) packed[m][q] = (int)__builtin_amdgcn_lerp((uint32_t)y[q], 0u, 0x01010101u);
         }
+    } else {
+        uint32_t t = (uint32_t)mx >> 7;
+        int sh = t ? 32 - __builtin_clz(t) : 0;
+        int rnd = (1 << sh) >> 1;
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t d = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    int v = (acc[m][4 * q + b] + rnd) >> sh;
+                    v = min(max(v, 0), 127);
+                    d |= (uint32_t)v << (8 * b);
+                }
+                packed[m][q] = (int)d;
+            }
+    }
 }
 
-// first strict maximum over rows < n_classes (ReLUNorm's return value, :25-37)
+// first strict maximum over rows < n_classes (ReLUNorm's return value, :25-37).  key = value*256 + (255 - row):
+// the largest key is the largest value and, among equals, the smallest row.  |value| < 2^23 for every layer that
+// can be last (K <= 128, |act| <= 127, |w| <= 128).  Registers whose rows are all >= n_classes are skipped by
+// wave-uniform branches.
 template <int MT>
 BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h, uint32_t n_classes) {
-    int bv = -INT_MAX;
-    uint32_t bi = 255;
+    int best = INT_MIN;
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            uint32_t row = 32u * m + (r & 3) + 8u * (r >> 2) + 4u * h;
-            int v = acc[m][r];
-            if (row < n_classes && v > bv) { bv = v; bi = row; }
+            const uint32_t rowbase = 32u * m + (r & 3) + 8u * (r >> 2);   // row of the h = 0 half; h = 1: +4
+            if (rowbase < n_classes) {
+                int key = (int)(((uint32_t)acc[m][r] << 8) + (255u - rowbase));
+                if (rowbase + 4u >= n_classes) key = h ? INT_MIN : key;
+                best = max(best, key);
+            }
         }
-    int pv = partner32(bv, h);
-    uint32_t pi = (uint32_t)partner32((int)bi, h);
-    if (pv > bv || (pv == bv && pi < bi)) bi = pi;
-    return bi;
+    best = best == INT_MIN ? INT_MIN : best - 4 * h;
+    best = max(best, partner32(best, h));
+    return 255u - ((uint32_t)best & 255u);
 }
 
 template <int MT>
@@ -380,18 +440,24 @@ BNM_DEVICE void bnm_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int FUSED_WPB = 4;              // waves per workgroup
 constexpr int FUSED_TILE_BYTES = 8192;    // 32 images x 256 B
+// waves per workgroup: variants 0/1 = 4 (two workgroups per CU), variant 2 = 8 (one workgroup per CU; the second
+// half of the waves starts half a tile late so that, on every SIMD, one wave's MFMA phase runs beside its
+// partner's VALU phase instead of both contending for the same pipe)
+constexpr int fused_wpb(int variant) { return variant == 2 ? 8 : 4; }
 
-template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, int VARIANT>
-__global__ __launch_bounds__(256, 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
+template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT>
+__global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                           const i32x4 *__restrict__ frags, uint32_t n_classes,
                                                           uint32_t *__restrict__ cls_out,
                                                           int32_t *__restrict__ logits_out) {
     constexpr int SP = SPLIT ? 2 : 1;
     constexpr int ROW = 32 * KT0;
-    constexpr int MLAST = M4 > 0 ? M4 : M3;
-    __shared__ __attribute__((aligned(1024))) char smem[VARIANT == 1 ? FUSED_WPB * 2 * FUSED_TILE_BYTES : 16];
+    constexpr int FUSED_WPB = fused_wpb(VARIANT);
+    constexpr bool LDSDMA = VARIANT != 0;
+    static_assert(!LDSDMA || KT0 == 8, "the LDS-DMA tile layout is for 256-byte rows");
+    static_assert(!(SPLIT && DBL), "FP1.3.0 weights cannot be doubled in int8");
+    __shared__ __attribute__((aligned(1024))) char smem[LDSDMA ? FUSED_WPB * 2 * FUSED_TILE_BYTES : 16];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -417,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void fused_fc_kernel(const int8_t *__restri
     // DMA piece t covers rows 4t..4t+3: lane l -> row 4t + (l>>4), slot l&15.
     uint32_t voff[4];
     uint32_t lds_wave = 0, rd_base = 0;
-    if constexpr (VARIANT == 1) {
+    if constexpr (LDSDMA) {
 #pragma unroll
         for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
         lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
@@ -458,15 +524,18 @@ __global__ __launch_bounds__(256, 2) void fused_fc_kernel(const int8_t *__restri
     };
 
     if (tile < n_tiles) {
-        if constexpr (VARIANT == 1) dma_tile(tile, 0);
+        if constexpr (LDSDMA) dma_tile(tile, 0);
         else direct_load(tile, bnext);
+    }
+    if constexpr (VARIANT == 2) {
+        if (wave >= 4) __builtin_amdgcn_s_sleep(20);   // ~1300 cycles: half a tile's VALU+MFMA time
     }
 
     for (; tile < n_tiles; tile += stride) {
         const uint64_t next = tile + stride;
         i32x4 b0[KT0];
         i32x16 acc1[M1];
-        if constexpr (VARIANT == 1) {
+        if constexpr (LDSDMA) {
             if (next < n_tiles) {
                 dma_tile(next, par ^ 1);
                 bnm_wait_vmcnt<8>();
@@ -487,12 +556,12 @@ __global__ __launch_bounds__(256, 2) void fused_fc_kernel(const int8_t *__restri
 
         layer_mma<M1, KT0, SPLIT>(A1, b0, acc1);
         i32x4 p1[M1];
-        relunorm_pack<M1>(acc1, p1, h);
+        relunorm_pack<M1, DBL>(acc1, p1, h);
 
         i32x16 acc2[M2];
         layer_mma<M2, M1, SPLIT>(A2, p1, acc2);
         i32x4 p2[M2];
-        relunorm_pack<M2>(acc2, p2, h);
+        relunorm_pack<M2, DBL>(acc2, p2, h);
 
         i32x16 acc3[M3];
         layer_mma<M3, M2, SPLIT>(A3, p2, acc3);
@@ -501,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void fused_fc_kernel(const int8_t *__restri
         uint32_t cls;
         if constexpr (M4 > 0) {
             i32x4 p3[M3];
-            relunorm_pack<M3>(acc3, p3, h);
+            relunorm_pack<M3, DBL>(acc3, p3, h);
             i32x16 acc4[M4];
             layer_mma<M4, M3, SPLIT>(A4, p3, acc4);
             cls = argmax_rows<M4>(acc4, h, n_classes);
@@ -510,7 +579,6 @@ __global__ __launch_bounds__(256, 2) void fused_fc_kernel(const int8_t *__restri
             cls = argmax_rows<M3>(acc3, h, n_classes);
             if (logits_out && img < n) store_logits<M3>(acc3, logits_out + img * n_classes, h, n_classes);
         }
-        (void)MLAST;
         if (h == 0 && img < n) cls_out[img] = cls;
     }
 }
@@ -523,30 +591,34 @@ struct FusedEntry {
     int variant;
     fused_fn fn;
 };
-#define FUSED(KT0, M1, M2, M3, M4, SPLIT, VAR) \
-    { {KT0, {M1, M2, M3, M4}, SPLIT}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, VAR> }
+#define FUSED(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR) \
+    { {KT0, {M1, M2, M3, M4}, SPLIT, DBL}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, DBL, VAR> }
 const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
-    FUSED(8, 2, 2, 2, 1, false, 1),
-    FUSED(8, 2, 2, 2, 1, false, 0),
+    FUSED(8, 2, 2, 2, 1, false, true, 1),
+    FUSED(8, 2, 2, 2, 1, false, true, 2),
+    FUSED(8, 2, 2, 2, 1, false, true, 0),
+    // same shape with codecs whose weights cannot be doubled in int8 (8-bit two's complement)
+    FUSED(8, 2, 2, 2, 1, false, false, 1),
+    FUSED(8, 2, 2, 2, 1, false, false, 0),
     // same shape, FP1.3.0 weights (mcu/BitNetMCU_model_12k_FP130.h): +-128 split over two A passes
-    FUSED(8, 2, 2, 2, 1, true, 1),
-    FUSED(8, 2, 2, 2, 1, true, 0),
+    FUSED(8, 2, 2, 2, 1, true, false, 1),
+    FUSED(8, 2, 2, 2, 1, true, false, 0),
     // FC 256-16-16-10 2bitsym (mcu/BitNetMCU_model_1k.h)
-    FUSED(8, 1, 1, 1, 0, false, 1),
-    FUSED(8, 1, 1, 1, 0, false, 0),
+    FUSED(8, 1, 1, 1, 0, false, true, 1),
+    FUSED(8, 1, 1, 1, 0, false, true, 0),
     // ternary FC 256-96-96-96-10 through the MFMA path (optional; config 3's product path is the ALU kernel)
-    FUSED(8, 3, 3, 3, 1, false, 1),
-    FUSED(8, 3, 3, 3, 1, false, 0),
+    FUSED(8, 3, 3, 3, 1, false, true, 1),
+    FUSED(8, 3, 3, 3, 1, false, true, 0),
     // CNN FC tails: 4C-96-64-10 (cnn_64/48/32/16), 64-64-48-10 (cnn_16small), 256-96-64-37 (letters)
-    FUSED(8, 3, 2, 1, 0, false, 1),
-    FUSED(8, 3, 2, 1, 0, false, 0),
-    FUSED(6, 3, 2, 1, 0, false, 0),
-    FUSED(4, 3, 2, 1, 0, false, 0),
-    FUSED(2, 3, 2, 1, 0, false, 0),
-    FUSED(2, 2, 2, 1, 0, false, 0),
-    FUSED(8, 3, 2, 2, 0, false, 1),
-    FUSED(8, 3, 2, 2, 0, false, 0),
+    FUSED(8, 3, 2, 1, 0, false, true, 1),
+    FUSED(8, 3, 2, 1, 0, false, true, 0),
+    FUSED(6, 3, 2, 1, 0, false, true, 0),
+    FUSED(4, 3, 2, 1, 0, false, true, 0),
+    FUSED(2, 3, 2, 1, 0, false, true, 0),
+    FUSED(2, 2, 2, 1, 0, false, true, 0),
+    FUSED(8, 3, 2, 2, 0, false, true, 1),
+    FUSED(8, 3, 2, 2, 0, false, true, 0),
 };
 const FusedEntry *find_fused(const BnmFusedShape &sh, int variant) {
     for (const FusedEntry &e : kFused)
@@ -572,11 +644,13 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
     const FusedEntry *e = find_fused(sh, variant);
     if (!e) return hipErrorInvalidValue;
     if (a.n == 0) return hipSuccess;
+    const int wpb = fused_wpb(variant);
     uint64_t n_tiles = (a.n + 31ull) / 32ull;
-    uint64_t want = (n_tiles + FUSED_WPB - 1) / FUSED_WPB;
-    uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)num_cus() * 2ull;   // 2 x 256 threads per CU
+    uint64_t want = (n_tiles + wpb - 1) / wpb;
+    // default: 8 resident waves per CU (2 x 256 threads or 1 x 512 threads)
+    uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)num_cus() * (uint64_t)(8 / wpb);
     unsigned blocks = (unsigned)(want < cap ? want : cap);
-    e->fn<<<dim3(blocks), dim3(64 * FUSED_WPB), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits);
+    e->fn<<<dim3(blocks), dim3(64 * wpb), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits);
     return hipGetLastError();
 }
 
