@@ -62,6 +62,7 @@ PROTOTYPES = {
     "bnm_unpack_layer_host": (C.c_int, [_vp, C.c_int32, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint32]),
     "bnm_synth_fill_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "bnm_class_digest_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, _vp]),
+    "bnm_diag_stream_device": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, _vp, _vp]),
     "bnm_bind_default_model": (C.c_int, [_vp]),
     "bnm_device_count": (C.c_int, []),
     "bnm_device_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),

@@ -525,6 +525,13 @@ int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint64_t n, u
     return BNM_OK;
 }
 
+int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out, void *stream) {
+    if (n && (!d_images || !d_out)) return fail(BNM_EINVAL, "null pointer");
+    if (mode < 0 || mode > 2) return fail(BNM_EINVAL, "mode must be 0, 1 or 2");
+    HIP_TRY(bnmk_diag_stream(d_images, n, mode, grid_blocks, d_out, (hipStream_t)stream));
+    return BNM_OK;
+}
+
 int bnm_device_malloc(void **p, size_t bytes) { HIP_TRY(hipMalloc(p, bytes)); return BNM_OK; }
 int bnm_device_free(void *p) { HIP_TRY(hipFree(p)); return BNM_OK; }
 int bnm_memcpy_h2d(void *d, const void *h, size_t bytes) { HIP_TRY(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return BNM_OK; }

@@ -77,3 +77,6 @@ struct BnmTernArgs {
     int32_t *logits;
 };
 hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s);
+
+// ---- diagnostics: cost of the image stream alone (profiles/stream_ceiling.py) ----------------------
+hipError_t bnmk_diag_stream(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out, hipStream_t s);

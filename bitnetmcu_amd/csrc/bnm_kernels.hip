@@ -1104,3 +1104,71 @@ hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s
                                                                        a.stride[3], a.n_out[3], a.cls, a.logits);
     return hipGetLastError();
 }
+
+// =================================================================================================
+// Diagnostics: what the image stream alone costs.  mode 0: plain 16 B/lane global loads, grid-stride;
+// mode 1: the fused kernel's own tile loop (LDS-DMA double buffer, counted vmcnt) with the math replaced by one
+// ds_read per tile.  Both write one dword per 32 images so the result cannot be optimised away.  Used by
+// profiles/stream_ceiling.py to put the achieved GB/s of the real kernel next to the practical read ceiling.
+// =================================================================================================
+__global__ __launch_bounds__(256) void diag_stream_plain_kernel(const u32x4 *__restrict__ src, uint64_t n16,
+                                                                uint32_t *__restrict__ out) {
+    uint32_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        acc ^= a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3] ^ c[0] ^ c[1] ^ c[2] ^ c[3] ^ d[0] ^ d[1] ^ d[2] ^ d[3];
+    }
+    for (; i < n16; i += stride) {
+        u32x4 a = __builtin_nontemporal_load(src + i);
+        acc ^= a[0] ^ a[1] ^ a[2] ^ a[3];
+    }
+    if (acc == 0x12345678u) out[0] = acc;   // practically never: keeps the loads alive without a store stream
+}
+
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) void diag_stream_tiles_kernel(const int8_t *__restrict__ images, uint64_t n,
+                                                                        uint32_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(1024))) char smem[WPB * 2 * FUSED_TILE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t voff[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
+    const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
+    const uint64_t n_tiles = n >> 5;   // whole tiles only
+    const uint64_t stride = (uint64_t)gridDim.x * WPB;
+    uint64_t tile = (uint64_t)blockIdx.x * WPB + wave;
+    auto dma = [&](uint64_t t, int par) {
+        const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
+        lds_dma_tile8(lds_wave + (uint32_t)par * FUSED_TILE_BYTES, base, base + 1024, base + 2048, base + 3072, base + 4096,
+                      base + 5120, base + 6144, base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0], voff[1], voff[2], voff[3]);
+    };
+    int par = 0;
+    if (tile < n_tiles) dma(tile, 0);
+    for (; tile < n_tiles; tile += stride) {
+        const uint64_t next = tile + stride;
+        if (next < n_tiles) { dma(next, par ^ 1); bnm_wait_vmcnt<8>(); } else { bnm_wait_vmcnt<0>(); }
+        uint32_t v = *(const uint32_t *)(smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)par * FUSED_TILE_BYTES + 128u * lane);
+        if (lane < 32) out[(tile << 5) + lane] = v;
+        par ^= 1;
+    }
+}
+
+hipError_t bnmk_diag_stream(const int8_t *images, uint64_t n, int mode, int grid_blocks, uint32_t *out, hipStream_t s) {
+    if (!n) return hipSuccess;
+    int cus = num_cus();
+    if (mode == 0) {
+        unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 8u;
+        diag_stream_plain_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const u32x4 *)images, n * 16ull, out);
+    } else if (mode == 1) {
+        unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 2u;
+        diag_stream_tiles_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
+    } else {
+        unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus;
+        diag_stream_tiles_kernel<8><<<dim3(blocks), dim3(512), 0, s>>>(images, n, out);
+    }
+    return hipGetLastError();
+}

@@ -174,6 +174,12 @@ BNM_API int bnm_synth_fill_device(int8_t *d_images, uint64_t first, uint64_t cou
 BNM_API int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint64_t n,
                                     uint64_t *d_out, uint32_t n_bins, void *stream);
 
+/* Diagnostics: read the image stream without the model math.  mode 0: plain 16 B/lane loads; mode 1/2: the fused
+ * kernel's own LDS-DMA tile loop (4- / 8-wave workgroups).  d_out: uint32 [n].  Puts the practical read ceiling of
+ * this access pattern next to the real kernel (profiles/stream_ceiling.py). */
+BNM_API int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out,
+                                   void *stream);
+
 /* ---- model binding for group A ------------------------------------------------------------ */
 /* Bind the model that Inference()/BitMnistInference() run.  A `Bitnet_inf.dll` built by
  * bitnetmcu_amd/build.py --dll <header> does this itself from the embedded header text. */
