@@ -396,43 +396,51 @@ BNM_DEVICE void store_logits(const i32x16 (&acc)[MT], int32_t *dst, int h, uint3
 // offsets, lds wave-uniform LDS byte address of the tile buffer.  The DMA destination is
 // M0 + lane*16 (lane-linear); the swizzle lives in v[].  hipcc neither counts these loads nor waits for
 // them: the caller retires them with bnm_wait_vmcnt<N>().
+// NT: non-temporal policy (the image stream is read exactly once).  WAITLDS: first retire this wave's own
+// outstanding ds_reads (s_waitcnt lgkmcnt(0)) — needed when the destination buffer was being read just before.
+#define BNM_DMA8(NTS, PRE)                                                                                           \
+    asm volatile(PRE "s_nop 4\n\t"                                                                                    \
+                 "s_mov_b32 %0, m0\n\t"                                                                                \
+                 "s_mov_b32 m0, %1\n\t"                                                                                \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %10, %2" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %11, %3" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %12, %4" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %13, %5" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %14, %6" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %15, %7" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %16, %8" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %17, %9" NTS "\n\t"                                                          \
+                 "s_mov_b32 m0, %0"                                                                                    \
+                 : "=&s"(keep)                                                                                         \
+                 : "s"(lds), "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(p6), "s"(p7), "v"(v0), "v"(v1), \
+                   "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7)                                                \
+                 : "memory", "scc")
+
+template <bool NT = false, bool WAITLDS = false>
 BNM_DEVICE void lds_dma_tile8(uint32_t lds, const int8_t *p0, const int8_t *p1, const int8_t *p2, const int8_t *p3,
                               const int8_t *p4, const int8_t *p5, const int8_t *p6, const int8_t *p7, uint32_t v0,
                               uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t v5, uint32_t v6,
                               uint32_t v7) {
     uint32_t keep;
-    asm volatile(
-        "s_nop 4\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %10, %2\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %11, %3\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %12, %4\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %13, %5\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %14, %6\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %15, %7\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %16, %8\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %17, %9\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds), "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(p6), "s"(p7), "v"(v0), "v"(v1), "v"(v2),
-          "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7)
-        : "memory", "scc");
+    if constexpr (NT && WAITLDS) BNM_DMA8(" nt", "s_waitcnt lgkmcnt(0)\n\t");
+    else if constexpr (NT) BNM_DMA8(" nt", "");
+    else if constexpr (WAITLDS) BNM_DMA8("", "s_waitcnt lgkmcnt(0)\n\t");
+    else BNM_DMA8("", "");
 }
 
 template <int N>
@@ -441,10 +449,16 @@ BNM_DEVICE void bnm_wait_vmcnt() {
 }
 
 constexpr int FUSED_TILE_BYTES = 8192;    // 32 images x 256 B
-// waves per workgroup: variants 0/1 = 4 (two workgroups per CU), variant 2 = 8 (one workgroup per CU; the second
-// half of the waves starts half a tile late so that, on every SIMD, one wave's MFMA phase runs beside its
-// partner's VALU phase instead of both contending for the same pipe)
-constexpr int fused_wpb(int variant) { return variant == 2 ? 8 : 4; }
+// Kernel variants (image tile load path):
+//   0  direct global->VGPR loads in operand layout (any row length)
+//   1  LDS-DMA, one tile ahead, 4-wave workgroups (two per CU)
+//   2  as 1 with 8-wave workgroups (one per CU); the second half of the waves starts half a tile late so that, on
+//      every SIMD, one wave's MFMA phase runs beside its partner's VALU phase instead of both contending
+//   3  LDS-DMA, TWO tiles ahead in the same two buffers (all 8 B fragments are pulled into VGPRs at the top of the
+//      iteration, which frees the buffer for tile n+2 at once), non-temporal loads, 4-wave workgroups
+//   4  as 3 with 8-wave staggered workgroups
+constexpr int fused_wpb(int variant) { return (variant == 2 || variant == 4) ? 8 : 4; }
+constexpr bool fused_deep(int variant) { return variant >= 3; }
 
 template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT>
 __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
@@ -491,12 +505,13 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
         rd_base = (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
     }
 
+    constexpr bool DEEP = fused_deep(VARIANT);
     auto dma_tile = [&](uint64_t t, int par) {
         const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
         uint32_t lds = lds_wave + (uint32_t)par * FUSED_TILE_BYTES;
         uint64_t first = t << 5;
         if (first + 32ull <= n) {
-            lds_dma_tile8(lds, base, base + 1024, base + 2048, base + 3072, base + 4096, base + 5120, base + 6144,
+            lds_dma_tile8<DEEP, DEEP>(lds, base, base + 1024, base + 2048, base + 3072, base + 4096, base + 5120, base + 6144,
                           base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0], voff[1], voff[2], voff[3]);
         } else {
             // ragged last tile: rows past the end re-read the last valid image (never out of bounds)
@@ -508,8 +523,8 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
                 uint32_t src = r < nv ? r : nv - 1u;
                 v[tt] = src * 256u + 16u * ((uint32_t)(lane & 15) ^ (r & 15u));
             }
-            lds_dma_tile8(lds, base, base, base, base, base, base, base, base, v[0], v[1], v[2], v[3], v[4], v[5], v[6],
-                          v[7]);
+            lds_dma_tile8<DEEP, DEEP>(lds, base, base, base, base, base, base, base, base, v[0], v[1], v[2], v[3], v[4], v[5],
+                                      v[6], v[7]);
         }
     };
 
@@ -527,7 +542,10 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
         if constexpr (LDSDMA) dma_tile(tile, 0);
         else direct_load(tile, bnext);
     }
-    if constexpr (VARIANT == 2) {
+    if constexpr (DEEP) {
+        if (tile + stride < n_tiles) dma_tile(tile + stride, 1);
+    }
+    if constexpr (FUSED_WPB == 8) {
         if (wave >= 4) __builtin_amdgcn_s_sleep(20);   // ~1300 cycles: half a tile's VALU+MFMA time
     }
 
@@ -536,17 +554,28 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
         i32x4 b0[KT0];
         i32x16 acc1[M1];
         if constexpr (LDSDMA) {
-            if (next < n_tiles) {
-                dma_tile(next, par ^ 1);
-                bnm_wait_vmcnt<8>();
+            if constexpr (!DEEP) {
+                if (next < n_tiles) {
+                    dma_tile(next, par ^ 1);
+                    bnm_wait_vmcnt<8>();
+                } else {
+                    bnm_wait_vmcnt<0>();
+                }
             } else {
-                bnm_wait_vmcnt<0>();
+                // in flight: tile (8 pieces) and, if it exists, next (8 pieces), issued one iteration ago
+                if (next < n_tiles) bnm_wait_vmcnt<8>();
+                else bnm_wait_vmcnt<0>();
             }
             // rd_base carries the slot field (h ^ (j&15)) << 4 in bits 4..7 and nothing else below bit 8, so
             // XOR-ing 32*s (bits 5..7) selects slot (2s+h) ^ (j&15): one v_xor per K-step.
 #pragma unroll
             for (int s = 0; s < KT0; s++)
                 b0[s] = *(const i32x4 *)(smem + ((rd_base ^ (32u * s)) + (uint32_t)par * FUSED_TILE_BYTES));
+            if constexpr (DEEP) {
+                // the buffer just read is free as soon as its 8 ds_reads have returned (the DMA statement waits
+                // lgkmcnt(0) first): refill it with the tile after next
+                if (next + stride < n_tiles) dma_tile(next + stride, par);
+            }
             par ^= 1;
         } else {
 #pragma unroll
@@ -595,6 +624,8 @@ struct FusedEntry {
     { {KT0, {M1, M2, M3, M4}, SPLIT, DBL}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, DBL, VAR> }
 const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
+    FUSED(8, 2, 2, 2, 1, false, true, 3),
+    FUSED(8, 2, 2, 2, 1, false, true, 4),
     FUSED(8, 2, 2, 2, 1, false, true, 1),
     FUSED(8, 2, 2, 2, 1, false, true, 2),
     FUSED(8, 2, 2, 2, 1, false, true, 0),
@@ -638,7 +669,7 @@ int num_cus() {
 }  // namespace
 
 bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fused(sh, variant) != nullptr; }
-int bnmk_fused_default_variant(const BnmFusedShape &sh) { return find_fused(sh, 1) ? 1 : 0; }
+int bnmk_fused_default_variant(const BnmFusedShape &sh) { return find_fused(sh, 1) ? 1 : 0; }   // tuned per shape in capi
 
 hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a, hipStream_t s) {
     const FusedEntry *e = find_fused(sh, variant);
@@ -1128,7 +1159,7 @@ __global__ __launch_bounds__(256) void diag_stream_plain_kernel(const u32x4 *__r
     if (acc == 0x12345678u) out[0] = acc;   // practically never: keeps the loads alive without a store stream
 }
 
-template <int WPB>
+template <int WPB, bool DEEP>
 __global__ __launch_bounds__(64 * WPB, 2) void diag_stream_tiles_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                         uint32_t *__restrict__ out) {
     __shared__ __attribute__((aligned(1024))) char smem[WPB * 2 * FUSED_TILE_BYTES];
@@ -1143,15 +1174,22 @@ __global__ __launch_bounds__(64 * WPB, 2) void diag_stream_tiles_kernel(const in
     uint64_t tile = (uint64_t)blockIdx.x * WPB + wave;
     auto dma = [&](uint64_t t, int par) {
         const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
-        lds_dma_tile8(lds_wave + (uint32_t)par * FUSED_TILE_BYTES, base, base + 1024, base + 2048, base + 3072, base + 4096,
-                      base + 5120, base + 6144, base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0], voff[1], voff[2], voff[3]);
+        lds_dma_tile8<DEEP, DEEP>(lds_wave + (uint32_t)par * FUSED_TILE_BYTES, base, base + 1024, base + 2048, base + 3072,
+                                  base + 4096, base + 5120, base + 6144, base + 7168, voff[0], voff[1], voff[2], voff[3],
+                                  voff[0], voff[1], voff[2], voff[3]);
     };
     int par = 0;
     if (tile < n_tiles) dma(tile, 0);
+    if (DEEP && tile + stride < n_tiles) dma(tile + stride, 1);
     for (; tile < n_tiles; tile += stride) {
         const uint64_t next = tile + stride;
-        if (next < n_tiles) { dma(next, par ^ 1); bnm_wait_vmcnt<8>(); } else { bnm_wait_vmcnt<0>(); }
+        if constexpr (!DEEP) {
+            if (next < n_tiles) { dma(next, par ^ 1); bnm_wait_vmcnt<8>(); } else { bnm_wait_vmcnt<0>(); }
+        } else {
+            if (next < n_tiles) bnm_wait_vmcnt<8>(); else bnm_wait_vmcnt<0>();
+        }
         uint32_t v = *(const uint32_t *)(smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)par * FUSED_TILE_BYTES + 128u * lane);
+        if (DEEP && next + stride < n_tiles) dma(next + stride, par);
         if (lane < 32) out[(tile << 5) + lane] = v;
         par ^= 1;
     }
@@ -1163,12 +1201,14 @@ hipError_t bnmk_diag_stream(const int8_t *images, uint64_t n, int mode, int grid
     if (mode == 0) {
         unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 8u;
         diag_stream_plain_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const u32x4 *)images, n * 16ull, out);
-    } else if (mode == 1) {
+    } else if (mode == 1 || mode == 3) {
         unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 2u;
-        diag_stream_tiles_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
+        if (mode == 1) diag_stream_tiles_kernel<4, false><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
+        else diag_stream_tiles_kernel<4, true><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
     } else {
         unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus;
-        diag_stream_tiles_kernel<8><<<dim3(blocks), dim3(512), 0, s>>>(images, n, out);
+        if (mode == 2) diag_stream_tiles_kernel<8, false><<<dim3(blocks), dim3(512), 0, s>>>(images, n, out);
+        else diag_stream_tiles_kernel<8, true><<<dim3(blocks), dim3(512), 0, s>>>(images, n, out);
     }
     return hipGetLastError();
 }
