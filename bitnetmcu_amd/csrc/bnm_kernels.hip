@@ -457,7 +457,7 @@ constexpr int FUSED_TILE_BYTES = 8192;    // 32 images x 256 B
 //   3  LDS-DMA, TWO tiles ahead in the same two buffers (all 8 B fragments are pulled into VGPRs at the top of the
 //      iteration, which frees the buffer for tile n+2 at once), non-temporal loads, 4-wave workgroups
 //   4  as 3 with 8-wave staggered workgroups
-constexpr int fused_wpb(int variant) { return (variant == 2 || variant == 4) ? 8 : 4; }
+constexpr int fused_wpb(int variant) { return (variant == 2 || variant == 4 || variant == 6) ? 8 : 4; }
 constexpr bool fused_deep(int variant) { return variant >= 3; }
 
 template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT>
@@ -612,6 +612,205 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
     }
 }
 
+// =================================================================================================
+// Software-pipelined form of the fused kernel (variants 5 / 6; KT0 == 8, doubled weights).
+//
+// Profile of variants 1-4 (profiles/r01): VALU ~57 % + MFMA ~29 % of SIMD time with almost no overlap — the two
+// waves of a SIMD run the same code in phase, so both want the matrix pipe, then both want the VALU.  Here a wave
+// overlaps the two pipes by itself: the 16 layer-1 MFMAs of tile k+1 (62 % of all MFMA time, operands straight
+// from the LDS tile that landed one iteration ago) are issued one at a time between ~8-instruction slices of
+// tile k's layer-1 ReLUNorm (max tree, shift, then one packed dword = 4 x v_med3 + 4 x SDWA shift per slice).
+// A 32x32x32 i8 MFMA occupies the matrix pipe for 32 cycles = 8 VALU issue slots, so each slice hides under
+// the MFMA issued before it.  __builtin_amdgcn_sched_barrier(0) pins the hand-made order.
+// LDS ring: tile_k lives in buffer k&1; at iteration k the buffer of tile_k (drained during iteration k-1) is
+// refilled with tile_{k+2} while tile_{k+1} is read.
+// =================================================================================================
+#define BNM_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// one packed dword: y_b = clamp(v_b, 0, hi) >> s for 4 values; SDWA writes are one instruction apart (dst_sel
+// forwarding hazard), 8 VALU + 1 nop
+BNM_DEVICE int clamp_shift_pack4(int a, int b, int c, int d, int hi, int s) {
+    int out, t0, t1;
+    asm("v_med3_i32 %1, %3, 0, %7\n\t"
+        "v_med3_i32 %2, %4, 0, %7\n\t"
+        "v_lshrrev_b32_sdwa %0, %8, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_med3_i32 %1, %5, 0, %7\n\t"
+        "v_lshrrev_b32_sdwa %0, %8, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_med3_i32 %2, %6, 0, %7\n\t"
+        "v_lshrrev_b32_sdwa %0, %8, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0\n\t"
+        "v_lshrrev_b32_sdwa %0, %8, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(out), "=&v"(t0), "=&v"(t1)
+        : "v"(a), "v"(b), "v"(c), "v"(d), "v"(hi), "v"(s));
+    return out;
+}
+
+// ReLUNorm state machine for the doubled-weight path, cut into slices of <= ~8 VALU.  MT == 2.
+struct RnSlices2 {
+    int mx, sh, hi;
+    BNM_DEVICE void max_part(const i32x16 &a, int lo, bool first) {   // 8 values -> 4 max3
+        int m = first ? a[lo] : mx;
+        m = max(max(m, a[lo + (first ? 1 : 0)]), a[lo + (first ? 2 : 1)]);
+        if (first) {
+            m = max(max(m, a[lo + 3]), a[lo + 4]);
+            m = max(max(m, a[lo + 5]), a[lo + 6]);
+            m = max(m, a[lo + 7]);
+        } else {
+            m = max(max(m, a[lo + 2]), a[lo + 3]);
+            m = max(max(m, a[lo + 4]), a[lo + 5]);
+            m = max(max(m, a[lo + 6]), a[lo + 7]);
+        }
+        mx = m;
+    }
+    BNM_DEVICE void finish_max(int h) {
+        mx = max(mx, partner32(mx, h));
+        mx = max(mx, 0);
+        uint32_t t = (uint32_t)mx >> 8;
+        sh = t ? 32 - __builtin_clz(t) : 0;
+        hi = (255 << sh) - 1;
+    }
+    BNM_DEVICE int dword(const i32x16 &a, int q) const {
+        int y = clamp_shift_pack4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], hi, sh);
+        return (int)__builtin_amdgcn_lerp((uint32_t)y, 0u, 0x01010101u);
+    }
+};
+
+template <int M2, int M3, int M4, int VARIANT>
+__global__ __launch_bounds__(64 * (VARIANT == 6 ? 8 : 4), 2) void fused_fc_pipelined_kernel(
+    const int8_t *__restrict__ images, uint64_t n, const i32x4 *__restrict__ frags, uint32_t n_classes,
+    uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out) {
+    constexpr int KT0 = 8, M1 = 2;
+    constexpr int WPB = VARIANT == 6 ? 8 : 4;
+    __shared__ __attribute__((aligned(1024))) char smem[WPB * 2 * FUSED_TILE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    AFrags<M1, KT0> A1;
+    AFrags<M2, M1> A2;
+    AFrags<M3, M2> A3;
+    AFrags<(M4 > 0 ? M4 : 1), M3> A4;
+    const i32x4 *fp = frags;
+    A1.load(fp, lane);  fp += M1 * KT0 * 64;
+    A2.load(fp, lane);  fp += M2 * M1 * 64;
+    A3.load(fp, lane);  fp += M3 * M2 * 64;
+    if constexpr (M4 > 0) A4.load(fp, lane);
+
+    const uint64_t n_tiles = (n + 31ull) >> 5;
+    const uint64_t stride = (uint64_t)gridDim.x * WPB;
+    uint64_t tile = (uint64_t)blockIdx.x * WPB + wave;
+    if (tile >= n_tiles) return;
+
+    uint32_t voff[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
+    const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
+    const uint32_t rd_base = (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
+
+    auto dma_tile = [&](uint64_t t, int par) {
+        const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
+        uint32_t lds = lds_wave + (uint32_t)par * FUSED_TILE_BYTES;
+        uint64_t first = t << 5;
+        if (first + 32ull <= n) {
+            lds_dma_tile8<true, true>(lds, base, base + 1024, base + 2048, base + 3072, base + 4096, base + 5120, base + 6144,
+                                      base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0], voff[1], voff[2], voff[3]);
+        } else {
+            uint32_t nv = (uint32_t)(n - first);
+            uint32_t v[8];
+#pragma unroll
+            for (int tt = 0; tt < 8; tt++) {
+                uint32_t r = 4u * tt + (uint32_t)(lane >> 4);
+                uint32_t src = r < nv ? r : nv - 1u;
+                v[tt] = src * 256u + 16u * ((uint32_t)(lane & 15) ^ (r & 15u));
+            }
+            lds_dma_tile8<true, true>(lds, base, base, base, base, base, base, base, base, v[0], v[1], v[2], v[3], v[4], v[5],
+                                      v[6], v[7]);
+        }
+    };
+    auto bfrag = [&](int par, int s) -> i32x4 {
+        return *(const i32x4 *)(smem + ((rd_base ^ (32u * s)) + (uint32_t)par * FUSED_TILE_BYTES));
+    };
+
+    // ---- prologue: tile_0 (and tile_1) in flight, layer 1 of tile_0 ----------------------------------------
+    dma_tile(tile, 0);
+    if (tile + stride < n_tiles) { dma_tile(tile + stride, 1); bnm_wait_vmcnt<8>(); } else { bnm_wait_vmcnt<0>(); }
+    if constexpr (WPB == 8) {
+        if (wave >= 4) __builtin_amdgcn_s_sleep(16);
+    }
+    i32x16 acc1[M1];
+    {
+        i32x4 b[KT0];
+#pragma unroll
+        for (int s = 0; s < KT0; s++) b[s] = bfrag(0, s);
+        layer_mma<M1, KT0, false>(A1, b, acc1);
+    }
+
+    int par = 0;   // buffer of the CURRENT tile (already drained)
+    for (;; tile += stride) {
+        const uint64_t next = tile + stride;
+        const bool has_next = next < n_tiles;
+        i32x4 p1[M1];
+        i32x16 acc1n[M1];
+        if (has_next) {
+            if (next + stride < n_tiles) { dma_tile(next + stride, par); bnm_wait_vmcnt<8>(); } else { bnm_wait_vmcnt<0>(); }
+            // ---- interleave: 16 layer-1 MFMAs of tile `next`  ||  ReLUNorm of acc1 (current tile) ----------
+            const int np = par ^ 1;
+            RnSlices2 rn;
+            i32x4 b0 = bfrag(np, 0), b1 = bfrag(np, 1), b2;
+            acc1n[0] = zero16();
+            acc1n[1] = zero16();
+            BNM_PIN();
+#define BNM_MM(S, M, B) acc1n[M] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1.a[M][S], B, acc1n[M], 0, 0, 0); BNM_PIN()
+            BNM_MM(0, 0, b0); rn.max_part(acc1[0], 0, true);  b2 = bfrag(np, 2); BNM_PIN();
+            BNM_MM(0, 1, b0); rn.max_part(acc1[0], 8, false); BNM_PIN();
+            BNM_MM(1, 0, b1); rn.max_part(acc1[1], 0, false); b0 = bfrag(np, 3); BNM_PIN();
+            BNM_MM(1, 1, b1); rn.max_part(acc1[1], 8, false); BNM_PIN();
+            BNM_MM(2, 0, b2); rn.finish_max(h); b1 = bfrag(np, 4); BNM_PIN();
+            BNM_MM(2, 1, b2); p1[0][0] = rn.dword(acc1[0], 0); BNM_PIN();
+            BNM_MM(3, 0, b0); p1[0][1] = rn.dword(acc1[0], 1); b2 = bfrag(np, 5); BNM_PIN();
+            BNM_MM(3, 1, b0); p1[0][2] = rn.dword(acc1[0], 2); BNM_PIN();
+            BNM_MM(4, 0, b1); p1[0][3] = rn.dword(acc1[0], 3); b0 = bfrag(np, 6); BNM_PIN();
+            BNM_MM(4, 1, b1); p1[1][0] = rn.dword(acc1[1], 0); BNM_PIN();
+            BNM_MM(5, 0, b2); p1[1][1] = rn.dword(acc1[1], 1); b1 = bfrag(np, 7); BNM_PIN();
+            BNM_MM(5, 1, b2); p1[1][2] = rn.dword(acc1[1], 2); BNM_PIN();
+            BNM_MM(6, 0, b0); p1[1][3] = rn.dword(acc1[1], 3); BNM_PIN();
+            BNM_MM(6, 1, b0);
+            BNM_MM(7, 0, b1);
+            BNM_MM(7, 1, b1);
+#undef BNM_MM
+        } else {
+            relunorm_pack<M1, true>(acc1, p1, h);
+        }
+
+        i32x16 acc2[M2];
+        layer_mma<M2, M1, false>(A2, p1, acc2);
+        i32x4 p2[M2];
+        relunorm_pack<M2, true>(acc2, p2, h);
+        i32x16 acc3[M3];
+        layer_mma<M3, M2, false>(A3, p2, acc3);
+
+        const uint64_t img = (tile << 5) + (uint64_t)j;
+        uint32_t cls;
+        if constexpr (M4 > 0) {
+            i32x4 p3[M3];
+            relunorm_pack<M3, true>(acc3, p3, h);
+            i32x16 acc4[M4];
+            layer_mma<M4, M3, false>(A4, p3, acc4);
+            cls = argmax_rows<M4>(acc4, h, n_classes);
+            if (logits_out && img < n) store_logits<M4>(acc4, logits_out + img * n_classes, h, n_classes);
+        } else {
+            cls = argmax_rows<M3>(acc3, h, n_classes);
+            if (logits_out && img < n) store_logits<M3>(acc3, logits_out + img * n_classes, h, n_classes);
+        }
+        if (h == 0 && img < n) cls_out[img] = cls;
+        if (!has_next) break;
+#pragma unroll
+        for (int m = 0; m < M1; m++) acc1[m] = acc1n[m];
+        par ^= 1;
+    }
+}
+
 // ---- dispatch table: model shapes of the reference zoo (+ ternary) -----------------------------
 namespace {
 typedef void (*fused_fn)(const int8_t *, uint64_t, const i32x4 *, uint32_t, uint32_t *, int32_t *);
@@ -624,6 +823,8 @@ struct FusedEntry {
     { {KT0, {M1, M2, M3, M4}, SPLIT, DBL}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, DBL, VAR> }
 const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
+    { {8, {2, 2, 2, 1}, false, true}, 5, fused_fc_pipelined_kernel<2, 2, 1, 5> },
+    { {8, {2, 2, 2, 1}, false, true}, 6, fused_fc_pipelined_kernel<2, 2, 1, 6> },
     FUSED(8, 2, 2, 2, 1, false, true, 3),
     FUSED(8, 2, 2, 2, 1, false, true, 4),
     FUSED(8, 2, 2, 2, 1, false, true, 1),
