@@ -178,7 +178,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "16x16 int8 MNIST inferences/s, FC 4bitsym 64-64-64 (BitNetMCU_model_fc.h), bit-exact vs C reference",
+            "metric": ("16x16 int8 MNIST inferences/s, FC 4bitsym 64-64-64 (BitNetMCU_model_fc.h), bit-exact vs C reference"
+                       if a.model == "fc_4bitsym_64" else f"16x16 int8 inferences/s, model {a.model}, bit-exact vs C reference"),
             "value": total / elapsed,
             "unit": "inferences/s",
             "n_gpus": world,
@@ -205,7 +206,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "fused_fc_kernel",
+                "kernel": {1: "fused_fc_kernel", 2: "fc_layer_bitserial_kernel+relunorm_kernel", 3: "ternary_alu_kernel"}.get(ctx.path, "?")
+                          + ("+cnn_front_kernel" if model.kind == b.KIND_CNN else ""),
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": n * bpi,
             },

@@ -102,6 +102,13 @@ def load(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # PyTorch-ROCm wheels bundle their own HIP runtime.  If this library pulled in the system libamdhip64 first, a
+    # later `import torch` would find two runtimes in the process and report "No HIP GPUs are available"; importing
+    # torch first makes both share torch's copy.  (Pure C hosts never see this: they have one runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise BnmError(f"{p} not found: build it with `python bitnetmcu_amd/build.py` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
