@@ -28,6 +28,12 @@ def cpu_baseline(model_name, dist, seconds):
     """The reference's UNMODIFIED BitMnistInference (oracle/_ref/<model>/Bitnet_inf_O3.dll) on all host cores
     over a bounded sample of the same synthetic workload.  Reported next to the GPU number; not a target."""
     cores = len(os.sched_getaffinity(0))
+    try:   # container CPU quota (cgroup v2): "max" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per) + 0.5)))
+    except Exception:
+        pass
     dll = os.path.join(REPO, "oracle", "_ref", model_name, "Bitnet_inf_O3.dll")
     exe = os.path.join(REPO, "oracle", "cpu_bench")
     if os.path.isfile(dll) and os.path.isfile(exe):

@@ -249,6 +249,30 @@ BNM_DEVICE i32x16 zero16() {
     return z;
 }
 
+// A operands read from an LDS copy of the fragment buffer (variant 7): frag (m, s) of a layer whose fragments start
+// at `base` (in 16-byte units), this lane's 16 bytes
+struct ALds {
+    const i32x4 *base;
+    int ks, lane;
+    BNM_DEVICE i32x4 operator()(int m, int s) const { return base[(m * ks + s) * 64 + lane]; }
+};
+
+template <int MT, int KT, bool SPLIT>
+BNM_DEVICE void layer_mma_lds(const ALds &A, const i32x4 (&b)[KT], i32x16 (&acc)[MT]) {
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = zero16();
+#pragma unroll
+    for (int s = 0; s < KT; s++)
+#pragma unroll
+        for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A(m, s), b[s], acc[m], 0, 0, 0);
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int s = 0; s < KT; s++)
+#pragma unroll
+            for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A(m, KT + s), b[s], acc[m], 0, 0, 0);
+    }
+}
+
 template <int MT, int KT, bool SPLIT>
 BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 (&b)[KT], i32x16 (&acc)[MT]) {
 #pragma unroll
@@ -457,11 +481,16 @@ constexpr int FUSED_TILE_BYTES = 8192;    // 32 images x 256 B
 //   3  LDS-DMA, TWO tiles ahead in the same two buffers (all 8 B fragments are pulled into VGPRs at the top of the
 //      iteration, which frees the buffer for tile n+2 at once), non-temporal loads, 4-wave workgroups
 //   4  as 3 with 8-wave staggered workgroups
+//   5/6 software-pipelined kernel (fused_fc_pipelined_kernel below)
 constexpr int fused_wpb(int variant) { return (variant == 2 || variant == 4 || variant == 6) ? 8 : 4; }
-constexpr bool fused_deep(int variant) { return variant >= 3; }
+constexpr bool fused_deep(int variant) { return variant == 3 || variant == 4; }
+//   7  three waves per SIMD: one 8 KiB LDS tile per wave (its 8 B fragments are pulled into VGPRs at the top of the
+//      iteration and the buffer is refilled with the next tile at once), layer >= 2 weight fragments in LDS
+//      instead of VGPRs (<= 168 VGPRs), three 4-wave workgroups per CU
+constexpr bool fused_single(int variant) { return variant == 7; }
 
 template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT>
-__global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
+__global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 : 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                           const i32x4 *__restrict__ frags, uint32_t n_classes,
                                                           uint32_t *__restrict__ cls_out,
                                                           int32_t *__restrict__ logits_out) {
@@ -471,7 +500,10 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
     constexpr bool LDSDMA = VARIANT != 0;
     static_assert(!LDSDMA || KT0 == 8, "the LDS-DMA tile layout is for 256-byte rows");
     static_assert(!(SPLIT && DBL), "FP1.3.0 weights cannot be doubled in int8");
-    __shared__ __attribute__((aligned(1024))) char smem[LDSDMA ? FUSED_WPB * 2 * FUSED_TILE_BYTES : 16];
+    constexpr bool SINGLE = fused_single(VARIANT);
+    constexpr int BUFS = SINGLE ? 1 : 2;
+    constexpr int WFRAGS = SINGLE ? (M2 * M1 + M3 * M2 + (M4 > 0 ? M4 * M3 : 0)) * SP : 0;   // 1 KiB each
+    __shared__ __attribute__((aligned(1024))) char smem[LDSDMA ? FUSED_WPB * BUFS * FUSED_TILE_BYTES + WFRAGS * 1024 : 16];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -479,14 +511,23 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
 
     // weights: unpacked fragments -> registers, once
     AFrags<M1, KT0 * SP> A1;
-    AFrags<M2, M1 * SP> A2;
-    AFrags<M3, M2 * SP> A3;
-    AFrags<(M4 > 0 ? M4 : 1), M3 * SP> A4;
+    AFrags<(SINGLE ? 1 : M2), (SINGLE ? 1 : M1 * SP)> A2;
+    AFrags<(SINGLE ? 1 : M3), (SINGLE ? 1 : M2 * SP)> A3;
+    AFrags<((M4 > 0 && !SINGLE) ? M4 : 1), (SINGLE ? 1 : M3 * SP)> A4;
     const i32x4 *fp = frags;
     A1.load(fp, lane);  fp += M1 * KT0 * SP * 64;
-    A2.load(fp, lane);  fp += M2 * M1 * SP * 64;
-    A3.load(fp, lane);  fp += M3 * M2 * SP * 64;
-    if constexpr (M4 > 0) A4.load(fp, lane);
+    const i32x4 *wl = (const i32x4 *)(smem + FUSED_WPB * BUFS * FUSED_TILE_BYTES);   // LDS weight copy (variant 7)
+    if constexpr (SINGLE) {
+        i32x4 *dst = (i32x4 *)(smem + FUSED_WPB * BUFS * FUSED_TILE_BYTES);
+        for (int i = threadIdx.x; i < WFRAGS * 64; i += 64 * FUSED_WPB) dst[i] = fp[i];
+        __syncthreads();
+    } else {
+        A2.load(fp, lane);  fp += M2 * M1 * SP * 64;
+        A3.load(fp, lane);  fp += M3 * M2 * SP * 64;
+        if constexpr (M4 > 0) A4.load(fp, lane);
+    }
+    const ALds L2a{wl, M1 * SP, lane}, L3a{wl + M2 * M1 * SP * 64, M2 * SP, lane},
+        L4a{wl + (M2 * M1 + M3 * M2) * SP * 64, M3 * SP, lane};
 
     const uint64_t n_tiles = (n + 31ull) >> 5;
     const uint64_t stride = (uint64_t)gridDim.x * FUSED_WPB;
@@ -500,12 +541,12 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
     if constexpr (LDSDMA) {
 #pragma unroll
         for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
-        lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
+        lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * BUFS * FUSED_TILE_BYTES;
         // B-operand read of K-step s: row j, global slot 2s+h -> LDS slot (2s+h) ^ (j&15) = (2s) ^ (h ^ (j&15))
-        rd_base = (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
+        rd_base = (uint32_t)wave * BUFS * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
     }
 
-    constexpr bool DEEP = fused_deep(VARIANT);
+    constexpr bool DEEP = fused_deep(VARIANT) || SINGLE;   // DMA statements: non-temporal + wait for own ds_reads
     auto dma_tile = [&](uint64_t t, int par) {
         const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
         uint32_t lds = lds_wave + (uint32_t)par * FUSED_TILE_BYTES;
@@ -542,7 +583,7 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
         if constexpr (LDSDMA) dma_tile(tile, 0);
         else direct_load(tile, bnext);
     }
-    if constexpr (DEEP) {
+    if constexpr (DEEP && !SINGLE) {
         if (tile + stride < n_tiles) dma_tile(tile + stride, 1);
     }
     if constexpr (FUSED_WPB == 8) {
@@ -554,7 +595,9 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
         i32x4 b0[KT0];
         i32x16 acc1[M1];
         if constexpr (LDSDMA) {
-            if constexpr (!DEEP) {
+            if constexpr (SINGLE) {
+                bnm_wait_vmcnt<0>();     // this wave's only tile in flight
+            } else if constexpr (!DEEP) {
                 if (next < n_tiles) {
                     dma_tile(next, par ^ 1);
                     bnm_wait_vmcnt<8>();
@@ -571,12 +614,14 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
 #pragma unroll
             for (int s = 0; s < KT0; s++)
                 b0[s] = *(const i32x4 *)(smem + ((rd_base ^ (32u * s)) + (uint32_t)par * FUSED_TILE_BYTES));
-            if constexpr (DEEP) {
+            if constexpr (SINGLE) {
+                if (next < n_tiles) dma_tile(next, 0);    // same buffer, after its 8 ds_reads have returned
+            } else if constexpr (DEEP) {
                 // the buffer just read is free as soon as its 8 ds_reads have returned (the DMA statement waits
                 // lgkmcnt(0) first): refill it with the tile after next
                 if (next + stride < n_tiles) dma_tile(next + stride, par);
             }
-            par ^= 1;
+            if constexpr (!SINGLE) par ^= 1;
         } else {
 #pragma unroll
             for (int s = 0; s < KT0; s++) b0[s] = bnext[s];
@@ -588,12 +633,14 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
         relunorm_pack<M1, DBL>(acc1, p1, h);
 
         i32x16 acc2[M2];
-        layer_mma<M2, M1, SPLIT>(A2, p1, acc2);
+        if constexpr (SINGLE) layer_mma_lds<M2, M1, SPLIT>(L2a, p1, acc2);
+        else layer_mma<M2, M1, SPLIT>(A2, p1, acc2);
         i32x4 p2[M2];
         relunorm_pack<M2, DBL>(acc2, p2, h);
 
         i32x16 acc3[M3];
-        layer_mma<M3, M2, SPLIT>(A3, p2, acc3);
+        if constexpr (SINGLE) layer_mma_lds<M3, M2, SPLIT>(L3a, p2, acc3);
+        else layer_mma<M3, M2, SPLIT>(A3, p2, acc3);
 
         const uint64_t img = (tile << 5) + (uint64_t)j;
         uint32_t cls;
@@ -601,7 +648,8 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), 2) void fused_fc_kernel(co
             i32x4 p3[M3];
             relunorm_pack<M3, DBL>(acc3, p3, h);
             i32x16 acc4[M4];
-            layer_mma<M4, M3, SPLIT>(A4, p3, acc4);
+            if constexpr (SINGLE) layer_mma_lds<M4, M3, SPLIT>(L4a, p3, acc4);
+            else layer_mma<M4, M3, SPLIT>(A4, p3, acc4);
             cls = argmax_rows<M4>(acc4, h, n_classes);
             if (logits_out && img < n) store_logits<M4>(acc4, logits_out + img * n_classes, h, n_classes);
         } else {
@@ -823,6 +871,7 @@ struct FusedEntry {
     { {KT0, {M1, M2, M3, M4}, SPLIT, DBL}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, DBL, VAR> }
 const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
+    FUSED(8, 2, 2, 2, 1, false, true, 7),
     { {8, {2, 2, 2, 1}, false, true}, 5, fused_fc_pipelined_kernel<2, 2, 1, 5> },
     { {8, {2, 2, 2, 1}, false, true}, 6, fused_fc_pipelined_kernel<2, 2, 1, 6> },
     FUSED(8, 2, 2, 2, 1, false, true, 3),
@@ -879,8 +928,8 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
     const int wpb = fused_wpb(variant);
     uint64_t n_tiles = (a.n + 31ull) / 32ull;
     uint64_t want = (n_tiles + wpb - 1) / wpb;
-    // default: 8 resident waves per CU (2 x 256 threads or 1 x 512 threads)
-    uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)num_cus() * (uint64_t)(8 / wpb);
+    // default: 8 resident waves per CU (2 x 256 threads or 1 x 512 threads); variant 7: 12 (3 x 256 threads)
+    uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)num_cus() * (uint64_t)(fused_single(variant) ? 3 : 8 / wpb);
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     e->fn<<<dim3(blocks), dim3(64 * wpb), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits);
     return hipGetLastError();
@@ -1233,29 +1282,28 @@ hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, co
 // cross-lane traffic at all); layer outputs are parked in a lane-private LDS column between the two
 // ReLUNorm passes because VGPRs cannot be indexed by the (runtime) neuron loop.
 // =================================================================================================
+// Hidden-layer sums are parked AFTER ReLU as uint16 pairs: max(sum, 0) <= 256*128 = 32768 fits 16 bits, negative
+// sums become 0 exactly as ReLUNorm would make them, and the maximum is unchanged (an all-negative vector has
+// maximum 0 and every output 0 either way).  Halves the LDS column: 12 KiB per wave -> 3 waves per SIMD.
 template <int H>
-BNM_DEVICE void tern_norm_pack(const int32_t *col, int mx, int (&act)[H / 4]) {
+BNM_DEVICE void tern_norm_pack(const uint32_t *col, int mx, int (&act)[H / 4]) {
     mx = max(mx, 0);
     uint32_t t = (uint32_t)mx >> 7;
     int sh = t ? 32 - __builtin_clz(t) : 0;
     int rnd = (1 << sh) >> 1;
 #pragma unroll
     for (int q = 0; q < H / 4; q++) {
-        uint32_t d = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            int v = (col[(4 * q + b) * 64] + rnd) >> sh;
-            v = min(max(v, 0), 127);
-            d |= (uint32_t)v << (8 * b);
-        }
-        act[q] = (int)d;
+        uint32_t lo = col[(2 * q) * 64], hi = col[(2 * q + 1) * 64];   // neurons 4q,4q+1 | 4q+2,4q+3
+        int v0 = min((int)((lo & 0xFFFFu) + rnd) >> sh, 127), v1 = min((int)((lo >> 16) + rnd) >> sh, 127);
+        int v2 = min((int)((hi & 0xFFFFu) + rnd) >> sh, 127), v3 = min((int)((hi >> 16) + rnd) >> sh, 127);
+        act[q] = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
     }
 }
 
 // out rows [0,H) of one layer: acc = sum_q dot4(act[q], W[n][q]);  returns the running max
 template <int KQ, int H>
-BNM_DEVICE int tern_layer(const int (&act)[KQ], const int8_t *__restrict__ rows, uint32_t stride, int32_t *col) {
-    int mx = -INT_MAX;
+BNM_DEVICE int tern_layer(const int (&act)[KQ], const int8_t *__restrict__ rows, uint32_t stride, uint32_t *col) {
+    int mx = 0;
 #pragma unroll 1
     for (int nn = 0; nn < H; nn += 4) {
         const int *__restrict__ w0 = (const int *)(rows + (size_t)(nn + 0) * stride);
@@ -1270,10 +1318,9 @@ BNM_DEVICE int tern_layer(const int (&act)[KQ], const int8_t *__restrict__ rows,
             a2 = __builtin_amdgcn_sdot4(act[q], w2[q], a2, false);
             a3 = __builtin_amdgcn_sdot4(act[q], w3[q], a3, false);
         }
-        col[(nn + 0) * 64] = a0;
-        col[(nn + 1) * 64] = a1;
-        col[(nn + 2) * 64] = a2;
-        col[(nn + 3) * 64] = a3;
+        a0 = max(a0, 0); a1 = max(a1, 0); a2 = max(a2, 0); a3 = max(a3, 0);
+        col[(nn / 2 + 0) * 64] = (uint32_t)a0 | ((uint32_t)a1 << 16);
+        col[(nn / 2 + 1) * 64] = (uint32_t)a2 | ((uint32_t)a3 << 16);
         mx = max(max(mx, max(a0, a1)), max(a2, a3));
     }
     return mx;
@@ -1287,9 +1334,9 @@ __global__ __launch_bounds__(64) void ternary_alu_kernel(const int8_t *__restric
                                                          uint32_t n_classes, uint32_t *__restrict__ cls_out,
                                                          int32_t *__restrict__ logits_out) {
     constexpr int HM = H1 > H2 ? (H1 > H3 ? H1 : H3) : (H2 > H3 ? H2 : H3);
-    __shared__ int32_t s_col[HM * 64];
+    __shared__ uint32_t s_col[HM / 2 * 64];
     const int lane = threadIdx.x;
-    int32_t *col = s_col + lane;
+    uint32_t *col = s_col + lane;
     for (uint64_t base = (uint64_t)blockIdx.x * 64ull; base < n; base += (uint64_t)gridDim.x * 64ull) {
         uint64_t img = base + (uint64_t)lane;
         const bool live = img < n;
@@ -1329,7 +1376,7 @@ hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s
         a.n_in[1] != 96 || a.n_in[2] != 96 || a.n_in[3] != 96)
         return hipErrorInvalidValue;
     uint64_t want = (a.n + 63ull) / 64ull;
-    uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)num_cus() * 6ull;
+    uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)num_cus() * 12ull;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     ternary_alu_kernel<96, 96, 96><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.rows[0], a.rows[1], a.rows[2],
                                                                        a.rows[3], a.stride[0], a.stride[1], a.stride[2],
