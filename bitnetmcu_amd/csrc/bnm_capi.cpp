@@ -212,6 +212,7 @@ int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32
     a.n_classes = c->model.num_classes();
     a.cls = d_cls;
     a.logits = d_logits;
+    if (const char *w = std::getenv("BNM_DIAG_SRC_WRAP")) a.src_wrap = std::strtoull(w, nullptr, 10);   // diagnostics only
     HIP_TRY(bnmk_fused_fc(c->shape, c->variant, c->grid_blocks, a, s));
     return BNM_OK;
 }

@@ -39,6 +39,7 @@ struct BnmFusedArgs {
     uint32_t n_classes;
     uint32_t *cls;          // [n]
     int32_t *logits;        // [n][n_classes] or nullptr
+    uint64_t src_wrap = 0;  // diagnostics: read tile (t mod src_wrap) — keeps the source cache-resident
 };
 // variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (KT0 == 8 only), 2 = LDS-DMA with
 // 8-wave workgroups and staggered halves

@@ -493,7 +493,7 @@ template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VAR
 __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 : 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                           const i32x4 *__restrict__ frags, uint32_t n_classes,
                                                           uint32_t *__restrict__ cls_out,
-                                                          int32_t *__restrict__ logits_out) {
+                                                          int32_t *__restrict__ logits_out, uint64_t src_wrap) {
     constexpr int SP = SPLIT ? 2 : 1;
     constexpr int ROW = 32 * KT0;
     constexpr int FUSED_WPB = fused_wpb(VARIANT);
@@ -548,7 +548,9 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
 
     constexpr bool DEEP = fused_deep(VARIANT) || SINGLE;   // DMA statements: non-temporal + wait for own ds_reads
     auto dma_tile = [&](uint64_t t, int par) {
-        const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
+        // src_wrap != 0 (diagnostics only, BNM_DIAG_SRC_WRAP): read tile (t mod src_wrap) instead, so the source stays
+        // cache-resident and the kernel's compute-side time can be measured without HBM in the way
+        const int8_t *base = images + (src_wrap ? t % src_wrap : t) * (uint64_t)FUSED_TILE_BYTES;
         uint32_t lds = lds_wave + (uint32_t)par * FUSED_TILE_BYTES;
         uint64_t first = t << 5;
         if (first + 32ull <= n) {
@@ -727,7 +729,7 @@ struct RnSlices2 {
 template <int M2, int M3, int M4, int VARIANT>
 __global__ __launch_bounds__(64 * (VARIANT == 6 ? 8 : 4), 2) void fused_fc_pipelined_kernel(
     const int8_t *__restrict__ images, uint64_t n, const i32x4 *__restrict__ frags, uint32_t n_classes,
-    uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out) {
+    uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out, uint64_t /*src_wrap*/) {
     constexpr int KT0 = 8, M1 = 2;
     constexpr int WPB = VARIANT == 6 ? 8 : 4;
     __shared__ __attribute__((aligned(1024))) char smem[WPB * 2 * FUSED_TILE_BYTES];
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(64 * (VARIANT == 6 ? 8 : 4), 2) void fused_fc_pipel
 
 // ---- dispatch table: model shapes of the reference zoo (+ ternary) -----------------------------
 namespace {
-typedef void (*fused_fn)(const int8_t *, uint64_t, const i32x4 *, uint32_t, uint32_t *, int32_t *);
+typedef void (*fused_fn)(const int8_t *, uint64_t, const i32x4 *, uint32_t, uint32_t *, int32_t *, uint64_t);
 struct FusedEntry {
     BnmFusedShape sh;
     int variant;
@@ -931,7 +933,7 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
     // default: 8 resident waves per CU (2 x 256 threads or 1 x 512 threads); variant 7: 12 (3 x 256 threads)
     uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)num_cus() * (uint64_t)(fused_single(variant) ? 3 : 8 / wpb);
     unsigned blocks = (unsigned)(want < cap ? want : cap);
-    e->fn<<<dim3(blocks), dim3(64 * wpb), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits);
+    e->fn<<<dim3(blocks), dim3(64 * wpb), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap);
     return hipGetLastError();
 }
 
