@@ -488,6 +488,11 @@ constexpr bool fused_deep(int variant) { return variant == 3 || variant == 4; }
 //      iteration and the buffer is refilled with the next tile at once), layer >= 2 weight fragments in LDS
 //      instead of VGPRs (<= 168 VGPRs), three 4-wave workgroups per CU
 constexpr bool fused_single(int variant) { return variant == 7; }
+//   8  as 1, but TWO tiles in flight per wave: the DMA for tile k+2 is issued right AFTER tile k's layer-1 MFMAs
+//      (which consumed the last B fragment of its buffer), not at the top of the iteration, so nothing is
+//      serialised in front of the MFMAs.  Profile finding (profiles/r01): with one tile in flight per wave the
+//      kernel is bound by per-wave memory-level parallelism (8 KiB / HBM latency x 2048 waves ~ 5.5 TB/s).
+constexpr bool fused_late(int variant) { return variant == 8; }
 
 template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT>
 __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 : 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
@@ -546,7 +551,8 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
         rd_base = (uint32_t)wave * BUFS * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
     }
 
-    constexpr bool DEEP = fused_deep(VARIANT) || SINGLE;   // DMA statements: non-temporal + wait for own ds_reads
+    constexpr bool LATE = fused_late(VARIANT);
+    constexpr bool DEEP = fused_deep(VARIANT) || SINGLE || LATE;   // DMA statements: non-temporal + wait for own ds_reads
     auto dma_tile = [&](uint64_t t, int par) {
         // src_wrap != 0 (diagnostics only, BNM_DIAG_SRC_WRAP): read tile (t mod src_wrap) instead, so the source stays
         // cache-resident and the kernel's compute-side time can be measured without HBM in the way
@@ -618,12 +624,12 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
                 b0[s] = *(const i32x4 *)(smem + ((rd_base ^ (32u * s)) + (uint32_t)par * FUSED_TILE_BYTES));
             if constexpr (SINGLE) {
                 if (next < n_tiles) dma_tile(next, 0);    // same buffer, after its 8 ds_reads have returned
-            } else if constexpr (DEEP) {
+            } else if constexpr (DEEP && !LATE) {
                 // the buffer just read is free as soon as its 8 ds_reads have returned (the DMA statement waits
                 // lgkmcnt(0) first): refill it with the tile after next
                 if (next + stride < n_tiles) dma_tile(next + stride, par);
             }
-            if constexpr (!SINGLE) par ^= 1;
+            if constexpr (!SINGLE && !LATE) par ^= 1;
         } else {
 #pragma unroll
             for (int s = 0; s < KT0; s++) b0[s] = bnext[s];
@@ -631,6 +637,11 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
         }
 
         layer_mma<M1, KT0, SPLIT>(A1, b0, acc1);
+        if constexpr (LATE) {
+            // all 8 B fragments of this tile's buffer have been consumed: refill it with the tile after next
+            if (next + stride < n_tiles) dma_tile(next + stride, par);
+            par ^= 1;
+        }
         i32x4 p1[M1];
         relunorm_pack<M1, DBL>(acc1, p1, h);
 
@@ -873,6 +884,7 @@ struct FusedEntry {
     { {KT0, {M1, M2, M3, M4}, SPLIT, DBL}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, DBL, VAR> }
 const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
+    FUSED(8, 2, 2, 2, 1, false, true, 8),
     FUSED(8, 2, 2, 2, 1, false, true, 7),
     { {8, {2, 2, 2, 1}, false, true}, 5, fused_fc_pipelined_kernel<2, 2, 1, 5> },
     { {8, {2, 2, 2, 1}, false, true}, 6, fused_fc_pipelined_kernel<2, 2, 1, 6> },
