@@ -512,6 +512,13 @@ int bnm_unpack_layer_host(const void *weights, int32_t bpw, uint32_t n_input, ui
     return BNM_OK;
 }
 
+int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_out, void *stream) {
+    if (n && (!d_x || !d_out)) return fail(BNM_EINVAL, "null pointer");
+    if (((uintptr_t)d_x & 15u) || ((uintptr_t)d_out & 3u)) return fail(BNM_EINVAL, "d_x must be 16-byte aligned");
+    HIP_TRY(bnmk_quantize_input(d_x, n, d_out, (hipStream_t)stream));
+    return BNM_OK;
+}
+
 int bnm_synth_fill_device(int8_t *d_images, uint64_t first, uint64_t count, uint64_t seed, int dist, void *stream) {
     if (count && !d_images) return fail(BNM_EINVAL, "null pointer");
     if (dist != BNM_DIST_U && dist != BNM_DIST_M) return fail(BNM_EINVAL, "dist must be 0 or 1");

@@ -81,3 +81,6 @@ hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s
 
 // ---- diagnostics: cost of the image stream alone (profiles/stream_ceiling.py) ----------------------
 hipError_t bnmk_diag_stream(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out, hipStream_t s);
+
+// ---- input quantisation: float32 [n][256] -> int8 [n][256] (test_inference.py:140-141) --------------
+hipError_t bnmk_quantize_input(const float *d_x, uint64_t n, int8_t *d_out, hipStream_t s);

@@ -933,7 +933,8 @@ int num_cus() {
 }  // namespace
 
 bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fused(sh, variant) != nullptr; }
-int bnmk_fused_default_variant(const BnmFusedShape &sh) { return find_fused(sh, 1) ? 1 : 0; }   // tuned per shape in capi
+// measured best first (profiles/r01): 8 (two tiles in flight) > 1 (LDS-DMA) > 0 (direct loads)
+int bnmk_fused_default_variant(const BnmFusedShape &sh) { return find_fused(sh, 8) ? 8 : find_fused(sh, 1) ? 1 : 0; }
 
 hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a, hipStream_t s) {
     const FusedEntry *e = find_fused(sh, variant);
@@ -1472,5 +1473,40 @@ hipError_t bnmk_diag_stream(const int8_t *images, uint64_t n, int mode, int grid
         if (mode == 2) diag_stream_tiles_kernel<8, false><<<dim3(blocks), dim3(512), 0, s>>>(images, n, out);
         else diag_stream_tiles_kernel<8, true><<<dim3(blocks), dim3(512), 0, s>>>(images, n, out);
     }
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// Input quantisation: the step immediately before the path, which the reference does in
+// Python for every image (test_inference.py:140-141, same formula BitNetMCU.py:435-436):
+//     scale = 127.0 / max(max|x|, 1e-5);  q = clip(round_half_even(x * scale), -128, 127)   all in float32.
+// One wavefront per image (256 floats = one float4 per lane); IEEE float32 divide/multiply and v_rndne_f32, so the
+// result is bit-identical to numpy's float32 arithmetic.
+// =================================================================================================
+__global__ __launch_bounds__(256) void quantize_input_kernel(const float *__restrict__ x, uint64_t n, int8_t *__restrict__ out) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    for (uint64_t img = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); img < n; img += (uint64_t)gridDim.x * 4u) {
+        f32x4 v = *(const f32x4 *)(x + img * 256ull + 4u * lane);
+        float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const float scale = __fdiv_rn(127.0f, fmaxf(m, 1e-5f));
+        uint32_t d = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            float r = rintf(__fmul_rn(v[b], scale));
+            r = fminf(fmaxf(r, -128.0f), 127.0f);
+            d |= (uint32_t)(uint8_t)(int8_t)(int)r << (8 * b);
+        }
+        *(uint32_t *)(out + img * 256ull + 4u * lane) = d;
+    }
+}
+
+hipError_t bnmk_quantize_input(const float *x, uint64_t n, int8_t *out, hipStream_t s) {
+    if (!n) return hipSuccess;
+    uint64_t blocks = (n + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    quantize_input_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, n, out);
     return hipGetLastError();
 }

@@ -153,3 +153,16 @@ class Context:
                                                       logits.data_ptr() if logits is not None else None,
                                                       s.cuda_stream), "bnm_infer_device")
         return cls
+
+    def quantize_device(self, x, out=None, stream=None):
+        """float32 cuda tensor [n,256] -> int8 [n,256] on the GPU with the reference's input quantisation
+        (test_inference.py:140-141), bit-identical to harness.quantize_input."""
+        import torch
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+        n = x.numel() // 256
+        if out is None:
+            out = torch.empty((n, 256), dtype=torch.int8, device=x.device)
+        s = stream if stream is not None else torch.cuda.current_stream(x.device)
+        L.check(self._lib, self._lib.bnm_quantize_input_device(x.data_ptr(), n, out.data_ptr(), s.cuda_stream),
+                "bnm_quantize_input_device")
+        return out

@@ -161,6 +161,11 @@ BNM_API int bnm_relunorm_device(const int32_t *d_in, uint32_t n, int8_t *d_out,
 BNM_API int bnm_unpack_layer_host(const void *weights, int32_t bits_per_weight, uint32_t n_input,
                                   uint32_t n_output, int8_t *lo, int8_t *hi, uint32_t row_stride);
 
+/* Input quantisation on the GPU — the step the reference does in Python before every Inference() call
+ * (test_inference.py:140-141; BitNetMCU.py:435-436): scale = 127/max(max|x|,1e-5), round half to even, clip.
+ * d_x: float32 [n][256], d_out: int8 [n][256]; bit-identical to the numpy float32 formula. */
+BNM_API int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_out, void *stream);
+
 /* ---- synthetic workload + digests ---------------------------------------- */
 #define BNM_DIST_U 0
 #define BNM_DIST_M 1

@@ -200,3 +200,47 @@ def test_relunorm_extremes_through_model_path(gpu_ok, orc):
             got = ctx.infer(x, logits=True)
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (name, label)
         ctx.close()
+
+
+def test_input_quantisation_matches_numpy_float32(gpu_ok):
+    """the Python-side quantisation step (test_inference.py:140-141) on the GPU."""
+    import torch
+    from bitnetmcu_amd import harness
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(5000, 256)).astype(np.float32)
+    x[0] = 0.0                                   # max|x| below the 1e-5 floor
+    x[1] = np.linspace(-1, 1, 256, dtype=np.float32) * 127 / 127   # many exact .5 ties after scaling
+    x[2, :] = 0.5; x[2, 0] = 127.0               # x*scale = 0.5 exactly -> rounds to even (0)
+    x[3, :] = -1.5; x[3, 0] = 127.0              # -1.5 -> -2
+    x[4] = rng.integers(-300, 300, 256).astype(np.float32) / 2.0
+    x[4, 0] = 150.0
+    x[5] = x[5] * 1e-7                           # tiny values, scale hits the floor
+    x[6] = x[6] * 1e20
+    ctx = b.Context(util.load_golden_model("mcu_1k"))
+    q = ctx.quantize_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.array_equal(q, harness.quantize_input(x))
+    # and the two steps chained on device == the reference's per-image Python flow
+    cls = torch.empty(len(x), dtype=torch.int32, device="cuda")
+    ctx.infer_device(ctx.quantize_device(torch.from_numpy(x).cuda()), cls)
+    assert np.array_equal(cls.cpu().numpy().astype(np.uint32), util.OracleModel(ctx.model).infer(harness.quantize_input(x)))
+    ctx.close()
+
+
+def test_bench_json_contract(gpu_ok):
+    """bench.py on a small N: one JSON line with the contract's keys, verified against the oracle."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(util.REPO, "bench.py"), "--images", "300000", "--steps", "3", "--warmup", "1",
+                          "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "i8" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["verified_vs_oracle"] is True and "workload" in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"]
