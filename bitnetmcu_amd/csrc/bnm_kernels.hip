@@ -1147,7 +1147,29 @@ hipError_t bnmk_maxpool22(const int32_t *in, uint32_t xy, int32_t *out, hipStrea
 // < 2^23 (needs n_shift >= 4, the only value the reference uses), so every MAC is one v_mad_i32_i24.
 // The ReLUNorm over all 4*C pooled values (:80) is fused: per-lane max, wave max, shift, pack 4 bytes.
 // =================================================================================================
-BNM_DEVICE int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+// hipcc turns a 9-tap "__mul24 + add" chain into 9 v_mul_i32_i24 + 4 v_add3 (13 issues); one fused multiply-add per
+// tap is 9.  Same for the packed-dot chain, where it emits v_mov 0 + v_dot4c.  Pin the instruction choice.
+BNM_DEVICE int mul24(int a, int b) {
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+BNM_DEVICE int mad24(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// w: per-lane packed int8x4 (VGPR), p: wave-uniform packed int8x4 (SGPR)
+BNM_DEVICE int dot4_su(int w, int p) {
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(w), "s"(p));
+    return r;
+}
+BNM_DEVICE int dot4_su(int w, int p, int acc) {
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(p), "v"(acc));
+    return r;
+}
 
 // c0: first channel handled by this launch (lane -> channel c0 + lane).  FUSE: C <= 64, the whole
 // feature vector lives in one wave and ReLUNorm is fused; otherwise the int32 features are written and
@@ -1164,10 +1186,17 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
     const uint32_t c = c0 + (uint32_t)lane;
     const bool live = c < C;
 
-    int k1[9], k2[9], k3[9];
+    // conv1 weights as three packed rows (w0,w1,w2,0) for v_dot4_i32_i8; conv2/conv3 weights as 24-bit mad operands
+    int wk[3], k2[9], k3[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) w |= (uint32_t)(uint8_t)(live ? w1[9u * c + 3 * dy + dx] : (int8_t)0) << (8 * dx);
+        wk[dy] = (int)w;
+    }
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-        k1[t] = live ? (int)w1[9u * c + t] : 0;
         k2[t] = live ? (int)w2[9u * c + t] : 0;
         k3[t] = live ? (int)w3[9u * c + t] : 0;
     }
@@ -1176,19 +1205,24 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
         const uint32_t *__restrict__ iw = (const uint32_t *)(images + img * 256ull);   // wave-uniform
         int f[4];
         {
-            int pix[3][16];     // rolling image rows (uniform -> SGPRs)
-            int r1[3][14];      // rolling conv1 rows
-            int r2[2][12];      // conv2 row pair feeding the first pool
+            // Stage 1 reads the int8 image: for output column x the three pixels x..x+2 of an image row are one packed
+            // scalar (s_lshr_b64 of two image dwords on the scalar unit), so a kernel row is ONE v_dot4_i32_i8 with the
+            // lane's packed weights: 3 dots per output instead of 9 multiply-adds.
+            // ReLU and the shift commute with max-pooling (both monotonic), so stages that feed a pool are pooled
+            // first: max(a,b,c,d,0) >> n == max over the window of (max(v,0) >> n).
+            int pk[3][14];      // rolling packed pixel triples of three image rows (uniform -> SGPRs)
+            int r1[3][14];      // rolling conv1 rows (after ReLU and shift)
+            int r2[2][12];      // raw conv2 sums of a row pair feeding the first pool
             int p1[6][6];       // pooled 6x6 plane
             auto load_row = [&](auto Y) {
                 constexpr int y = decltype(Y)::value;
-                static_for<0, 4>([&](auto Q) {
-                    constexpr int q = decltype(Q)::value;
-                    const uint32_t d = iw[4 * y + q];
-                    pix[y % 3][4 * q + 0] = (int)(int8_t)(d);
-                    pix[y % 3][4 * q + 1] = (int)(int8_t)(d >> 8);
-                    pix[y % 3][4 * q + 2] = (int)(int8_t)(d >> 16);
-                    pix[y % 3][4 * q + 3] = (int)(int8_t)(d >> 24);
+                const uint32_t d0 = iw[4 * y], d1 = iw[4 * y + 1], d2 = iw[4 * y + 2], d3 = iw[4 * y + 3];
+                static_for<0, 14>([&](auto X) {
+                    constexpr int x = decltype(X)::value;
+                    const uint32_t lo = x / 4 == 0 ? d0 : x / 4 == 1 ? d1 : x / 4 == 2 ? d2 : d3;
+                    const uint32_t hi = x / 4 == 0 ? d1 : x / 4 == 1 ? d2 : x / 4 == 2 ? d3 : 0u;
+                    const uint64_t pair = ((uint64_t)hi << 32) | lo;
+                    pk[y % 3][x] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(pair >> (8 * (x % 4))));
                 });
             };
             load_row(std::integral_constant<int, 0>{});
@@ -1198,28 +1232,27 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
                 load_row(std::integral_constant<int, y1 + 2>{});
                 static_for<0, 14>([&](auto X) {
                     constexpr int x = decltype(X)::value;
-                    int s = 0;
-                    static_for<0, 9>([&](auto T) {
-                        constexpr int t = decltype(T)::value;
-                        s = mad24(k1[t], pix[(y1 + t / 3) % 3][x + t % 3], s);
-                    });
-                    r1[y1 % 3][x] = s < 0 ? 0 : (s >> n_shift);
+                    int s = dot4_su(wk[0], pk[y1 % 3][x]);
+                    s = dot4_su(wk[1], pk[(y1 + 1) % 3][x], s);
+                    s = dot4_su(wk[2], pk[(y1 + 2) % 3][x], s);
+                    r1[y1 % 3][x] = max(s, 0) >> n_shift;
                 });
                 if constexpr (y1 >= 2) {
                     constexpr int y2 = y1 - 2;
                     static_for<0, 12>([&](auto X) {
                         constexpr int x = decltype(X)::value;
-                        int s = 0;
-                        static_for<0, 9>([&](auto T) {
+                        int s = mul24(k2[0], r1[y2 % 3][x]);
+                        static_for<1, 9>([&](auto T) {
                             constexpr int t = decltype(T)::value;
                             s = mad24(k2[t], r1[(y2 + t / 3) % 3][x + t % 3], s);
                         });
-                        r2[y2 & 1][x] = s < 0 ? 0 : (s >> n_shift);
+                        r2[y2 & 1][x] = s;
                     });
                     if constexpr (y2 & 1) {
                         static_for<0, 6>([&](auto X) {
                             constexpr int x = decltype(X)::value;
-                            p1[y2 >> 1][x] = max(max(r2[0][2 * x], r2[0][2 * x + 1]), max(r2[1][2 * x], r2[1][2 * x + 1]));
+                            int m = max(max(r2[0][2 * x], r2[0][2 * x + 1]), r2[1][2 * x]);
+                            p1[y2 >> 1][x] = max(max(m, r2[1][2 * x + 1]), 0) >> n_shift;
                         });
                     }
                 }
@@ -1229,18 +1262,18 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
             for (int y = 0; y < 4; y++)
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
-                    int s = 0;
+                    int s = mul24(k3[0], p1[y][x]);
 #pragma unroll
-                    for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-                        for (int dx = 0; dx < 3; dx++) s = mad24(k3[3 * dy + dx], p1[y + dy][x + dx], s);
-                    o3[y][x] = s < 0 ? 0 : (s >> n_shift);
+                    for (int t = 1; t < 9; t++) s = mad24(k3[t], p1[y + t / 3][x + t % 3], s);
+                    o3[y][x] = s;
                 }
 #pragma unroll
             for (int y = 0; y < 2; y++)
 #pragma unroll
-                for (int x = 0; x < 2; x++)
-                    f[2 * y + x] = max(max(o3[2 * y][2 * x], o3[2 * y][2 * x + 1]), max(o3[2 * y + 1][2 * x], o3[2 * y + 1][2 * x + 1]));
+                for (int x = 0; x < 2; x++) {
+                    int m = max(max(o3[2 * y][2 * x], o3[2 * y][2 * x + 1]), o3[2 * y + 1][2 * x]);
+                    f[2 * y + x] = max(max(m, o3[2 * y + 1][2 * x + 1]), 0) >> n_shift;
+                }
         }
         if (feat && live) {
             i32x4 v = {f[0], f[1], f[2], f[3]};
