@@ -1170,6 +1170,14 @@ BNM_DEVICE int dot4_su(int w, int p, int acc) {
     asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(p), "v"(acc));
     return r;
 }
+// last dot of a chain: gfx940+ needs 3 wait states between a DOT write and a different VALU reading the result
+// (LLVM GCNHazardRecognizer DotWriteDifferentVALURead); hipcc cannot see the opcode inside an asm statement and
+// pads only one state, so the pad lives in the string.  Dot -> same-opcode dot through src2 needs none.
+BNM_DEVICE int dot4_su_last(int w, int p, int acc) {
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, %3\n\ts_nop 2" : "=v"(r) : "v"(w), "s"(p), "v"(acc));
+    return r;
+}
 
 // c0: first channel handled by this launch (lane -> channel c0 + lane).  FUSE: C <= 64, the whole
 // feature vector lives in one wave and ReLUNorm is fused; otherwise the int32 features are written and
@@ -1234,7 +1242,7 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
                     constexpr int x = decltype(X)::value;
                     int s = dot4_su(wk[0], pk[y1 % 3][x]);
                     s = dot4_su(wk[1], pk[(y1 + 1) % 3][x], s);
-                    s = dot4_su(wk[2], pk[(y1 + 2) % 3][x], s);
+                    s = dot4_su_last(wk[2], pk[(y1 + 2) % 3][x], s);
                     r1[y1 % 3][x] = max(s, 0) >> n_shift;
                 });
                 if constexpr (y1 >= 2) {
