@@ -244,3 +244,63 @@ def test_bench_json_contract(gpu_ok):
         assert k in d["roofline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"]
+
+
+def _random_model_text(rng, codecs, widths, n_classes=10):
+    """Header text of an FC model with RANDOM packed weights: every codec id through the whole-model kernels, in
+    shapes of the fused table.  Ternary layers get the exporter's padding to a multiple of 10 (pad trits = 0)."""
+    lines = ["#include <stdint.h>", "#define MODEL_FCMNIST", "#define NUM_LAYERS %d" % len(codecs), "#define MAX_N_ACTIVATIONS 256"]
+    n_in = 256
+    outs = list(widths) + [n_classes]
+    for k, (bpw, n_out) in enumerate(zip(codecs, outs), start=1):
+        if bpw == 64:
+            padded = (n_in + 9) // 10 * 10
+            trits = rng.integers(0, 3, size=(n_out, padded))
+            trits[:, n_in:] = 2                                   # pad = zero weight (exportquant.py:132-137)
+            # base-3, most significant trit first, per 10-trit group (exportquant.py:146-156)
+            g = trits.reshape(n_out, padded // 10, 10)
+            v = np.zeros((n_out, padded // 10), np.int64)
+            for t in range(10):
+                v = v * 3 + g[:, :, t]
+            w = ((v * 65536 + 59048) // 59049).astype(np.uint16).ravel()
+            decl, n_decl = "uint16_t", padded
+        else:
+            fb = {1: 1, 2: 2, 4: 4, 12: 4, 20: 4, 16: 8}[bpw]
+            w = rng.integers(0, 2**32, size=n_out * (n_in * fb // 32), dtype=np.uint32)
+            decl, n_decl = "uint32_t", n_in
+        lines += [f"#define L{k}_active", f"#define L{k}_bitperweight {bpw}", f"#define L{k}_incoming_weights {n_decl}",
+                  f"#define L{k}_outgoing_weights {n_out}", f"const {decl} L{k}_weights[] = {{" + ",".join(hex(int(x)) for x in w) + "};"]
+        n_in = n_out
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("codecs,widths", [
+    ((1, 1, 1, 1), (64, 64, 64)),          # binary
+    ((2, 2, 2, 2), (64, 64, 64)),
+    ((12, 12, 12, 12), (64, 64, 64)),      # 4-bit two's complement
+    ((16, 16, 16, 16), (64, 64, 64)),      # 8-bit: weights cannot be doubled -> DBL = false kernels
+    ((16, 4, 1, 12), (64, 64, 64)),        # mixed
+    ((20, 20, 20, 20), (64, 64, 64)),      # FP1.3.0 split path
+    ((20, 4, 4, 4), (64, 64, 64)),
+    ((64, 64, 64, 64), (96, 96, 96)),      # ternary, random trits (dense), exporter padding
+    ((64, 4, 2, 4), (64, 64, 64)),         # ternary first layer + others (fused table shape)
+    ((4, 4, 4), (16, 16)),                 # three-layer model
+    ((36, 4, 4, 4), (64, 64, 64)),         # unknown codec (NF4 id): layer outputs zeros -> layer-wise path only
+])
+def test_random_models_every_codec_through_model_kernels(codecs, widths, gpu_ok, orc):
+    rng = np.random.default_rng(hash((codecs, widths)) % 2**32)
+    model = b.Model.from_header_text(_random_model_text(rng, codecs, widths))
+    om = util.OracleModel(model, orc)
+    x = np.concatenate([synth.images(5, 3000, DIST_U), synth.images(5, 3000, DIST_M), np.zeros((3, 256), np.int8),
+                        np.full((3, 256), -128, np.int8), np.full((3, 256), 127, np.int8)])
+    want = om.infer(x, logits=True)
+    ctx = b.Context(model)
+    labels = []
+    for label, setup in paths_for(ctx):
+        setup(ctx)
+        got = ctx.infer(x, logits=True)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (codecs, label)
+        labels.append(label)
+    if 36 not in codecs:
+        assert any(l.startswith("fused") for l in labels), (codecs, labels)
+    ctx.close()
