@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(const void *packed, in
             uint32_t k = 4u * q + b;
             int w = (k < n_real) ? decode_weight(packed, bpw, n_input, row, k) : 0;
             int l = w, h = 0;
-            if (w == 128 || w == -128) { l = w / 2; h = w / 2; }   // FP1.3.0 +-2^7 does not fit int8
+            if (w == 128) { l = 64; h = 64; }   // only FP1.3.0's +2^7 does not fit int8 (-128 does)
             plo |= (uint32_t)(uint8_t)(int8_t)l << (8u * b);
             phi |= (uint32_t)(uint8_t)(int8_t)h << (8u * b);
         }
