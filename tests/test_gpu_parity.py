@@ -265,7 +265,7 @@ def _random_model_text(rng, codecs, widths, n_classes=10):
             w = ((v * 65536 + 59048) // 59049).astype(np.uint16).ravel()
             decl, n_decl = "uint16_t", padded
         else:
-            fb = {1: 1, 2: 2, 4: 4, 12: 4, 20: 4, 16: 8}[bpw]
+            fb = {1: 1, 2: 2, 4: 4, 12: 4, 20: 4, 16: 8}.get(bpw, 4)
             w = rng.integers(0, 2**32, size=n_out * (n_in * fb // 32), dtype=np.uint32)
             decl, n_decl = "uint32_t", n_in
         lines += [f"#define L{k}_active", f"#define L{k}_bitperweight {bpw}", f"#define L{k}_incoming_weights {n_decl}",
