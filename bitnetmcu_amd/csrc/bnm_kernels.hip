@@ -467,6 +467,35 @@ BNM_DEVICE void lds_dma_tile8(uint32_t lds, const int8_t *p0, const int8_t *p1, 
     else BNM_DMA8("", "");
 }
 
+// 4 x 1 KiB pieces (half a tile), non-temporal; WAITLDS as above
+template <bool WAITLDS>
+BNM_DEVICE void lds_dma_half4(uint32_t lds, const int8_t *p0, const int8_t *p1, const int8_t *p2, const int8_t *p3, uint32_t v0,
+                              uint32_t v1, uint32_t v2, uint32_t v3) {
+    uint32_t keep;
+#define BNM_DMA4(PRE)                                                                                                   \
+    asm volatile(PRE "s_nop 4\n\t"                                                                                     \
+                 "s_mov_b32 %0, m0\n\t"                                                                                 \
+                 "s_mov_b32 m0, %1\n\t"                                                                                 \
+                 "s_nop 0\n\t"                                                                                          \
+                 "global_load_lds_dwordx4 %6, %2 nt\n\t"                                                                \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                          \
+                 "s_nop 0\n\t"                                                                                          \
+                 "global_load_lds_dwordx4 %7, %3 nt\n\t"                                                                \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                          \
+                 "s_nop 0\n\t"                                                                                          \
+                 "global_load_lds_dwordx4 %8, %4 nt\n\t"                                                                \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                          \
+                 "s_nop 0\n\t"                                                                                          \
+                 "global_load_lds_dwordx4 %9, %5 nt\n\t"                                                                \
+                 "s_mov_b32 m0, %0"                                                                                     \
+                 : "=&s"(keep)                                                                                          \
+                 : "s"(lds), "s"(p0), "s"(p1), "s"(p2), "s"(p3), "v"(v0), "v"(v1), "v"(v2), "v"(v3)                     \
+                 : "memory", "scc")
+    if constexpr (WAITLDS) BNM_DMA4("s_waitcnt lgkmcnt(0)\n\t");
+    else BNM_DMA4("");
+#undef BNM_DMA4
+}
+
 template <int N>
 BNM_DEVICE void bnm_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -492,7 +521,11 @@ constexpr bool fused_single(int variant) { return variant == 7; }
 //      (which consumed the last B fragment of its buffer), not at the top of the iteration, so nothing is
 //      serialised in front of the MFMAs.  Profile finding (profiles/r01): with one tile in flight per wave the
 //      kernel is bound by per-wave memory-level parallelism (8 KiB / HBM latency x 2048 waves ~ 5.5 TB/s).
-constexpr bool fused_late(int variant) { return variant == 8; }
+//   9  as 8, with the refill split in two half-tile groups (after the layer-1 and after the layer-2 MFMAs) and the
+//      waves of the grid started a few hundred cycles apart, so the chip's requests arrive as a steady stream rather
+//      than in 16 MiB bursts
+constexpr bool fused_late(int variant) { return variant == 8 || variant == 9; }
+constexpr bool fused_halves(int variant) { return variant == 9; }
 
 template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT>
 __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 : 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
@@ -597,6 +630,12 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
     if constexpr (FUSED_WPB == 8) {
         if (wave >= 4) __builtin_amdgcn_s_sleep(20);   // ~1300 cycles: half a tile's VALU+MFMA time
     }
+    if constexpr (fused_halves(VARIANT)) {
+        // de-phase the grid: blocks start 0..7 x 256 cycles apart, waves within a block 0..3 x 64 cycles
+        const int ph = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) & 7));
+        for (int i = 0; i < ph; i++) __builtin_amdgcn_s_sleep(4);
+        for (int i = 0; i < wave; i++) __builtin_amdgcn_s_sleep(1);
+    }
 
     for (; tile < n_tiles; tile += stride) {
         const uint64_t next = tile + stride;
@@ -637,10 +676,21 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
         }
 
         layer_mma<M1, KT0, SPLIT>(A1, b0, acc1);
+        constexpr bool HALVES = fused_halves(VARIANT);
+        const uint64_t refill = next + stride;
+        // a ragged LAST tile goes through the generic 8-piece path; only whole tiles are split
+        const bool refill_whole = HALVES && refill < n_tiles && ((refill << 5) + 32ull <= n);
         if constexpr (LATE) {
             // all 8 B fragments of this tile's buffer have been consumed: refill it with the tile after next
-            if (next + stride < n_tiles) dma_tile(next + stride, par);
-            par ^= 1;
+            if (refill < n_tiles) {
+                if (refill_whole) {
+                    const int8_t *base = images + (src_wrap ? refill % src_wrap : refill) * (uint64_t)FUSED_TILE_BYTES;
+                    lds_dma_half4<true>(lds_wave + (uint32_t)par * FUSED_TILE_BYTES, base, base + 1024, base + 2048, base + 3072,
+                                        voff[0], voff[1], voff[2], voff[3]);
+                } else {
+                    dma_tile(refill, par);
+                }
+            }
         }
         i32x4 p1[M1];
         relunorm_pack<M1, DBL>(acc1, p1, h);
@@ -648,6 +698,14 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
         i32x16 acc2[M2];
         if constexpr (SINGLE) layer_mma_lds<M2, M1, SPLIT>(L2a, p1, acc2);
         else layer_mma<M2, M1, SPLIT>(A2, p1, acc2);
+        if constexpr (LATE) {
+            if (refill_whole) {
+                const int8_t *base = images + (src_wrap ? refill % src_wrap : refill) * (uint64_t)FUSED_TILE_BYTES + 4096;
+                lds_dma_half4<false>(lds_wave + (uint32_t)par * FUSED_TILE_BYTES + 4096u, base, base + 1024, base + 2048,
+                                     base + 3072, voff[0], voff[1], voff[2], voff[3]);
+            }
+            par ^= 1;
+        }
         i32x4 p2[M2];
         relunorm_pack<M2, DBL>(acc2, p2, h);
 
@@ -884,6 +942,7 @@ struct FusedEntry {
     { {KT0, {M1, M2, M3, M4}, SPLIT, DBL}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, DBL, VAR> }
 const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
+    FUSED(8, 2, 2, 2, 1, false, true, 9),
     FUSED(8, 2, 2, 2, 1, false, true, 8),
     FUSED(8, 2, 2, 2, 1, false, true, 7),
     { {8, {2, 2, 2, 1}, false, true}, 5, fused_fc_pipelined_kernel<2, 2, 1, 5> },
