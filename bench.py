@@ -96,7 +96,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # launched by torch.distributed.run (even with one rank): go through the process group, so the N>1 code path
+    # (RCCL init, model broadcast, barriers, MAX-reduced time, all-reduced digest) is the one that runs
+    distributed = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if distributed:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -105,7 +108,7 @@ def main():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if distributed:
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- model: rank 0 reads the blob, RCCL-broadcasts it (~13 KB) ------------------------------------
@@ -113,7 +116,7 @@ def main():
     if rank == 0:
         with open(os.path.join(REPO, "tests", "golden", "models", a.model + ".bnm"), "rb") as f:
             model = b.Model.from_blob(f.read())
-    if world > 1:
+    if distributed:
         model = b.dist.broadcast_model(model, src=0, device=dev)
     ctx = b.Context(model, device=local_rank)
     if a.path:
@@ -136,7 +139,7 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         td.barrier()
     torch.cuda.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
@@ -146,11 +149,11 @@ def main():
         step()
         evs[k + 1].record()            # same stream as the launches
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         td.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -159,7 +162,7 @@ def main():
     # ---- outside the timed region: verification ----------------------------------------------------------
     verified = None
     digest = b.synth.digest_device(cls, first=first, n_bins=model.num_classes)
-    if world > 1:
+    if distributed:
         digest = b.dist.allreduce_digest(digest)
     torch.cuda.synchronize()
     hist = digest[1:].cpu().numpy().astype(np.int64)
@@ -227,7 +230,7 @@ def main():
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(a.model, a.dist, a.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         td.destroy_process_group()
 
 

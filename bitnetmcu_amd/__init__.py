@@ -7,8 +7,8 @@ launches.  PyTorch is used only for device memory, streams and torch.distributed
 from ._lib import (BnmError, LayerInfo, load, LIB_PATH, PATH_AUTO, PATH_FUSED_MFMA, PATH_LAYERWISE_ALU,
                    PATH_TERNARY_ALU, DIST_U, DIST_M, SEED_DIST_U, SEED_DIST_M, KIND_FC, KIND_CNN)
 from .model import Model, Context
-from . import harness, synth, dist
+from . import harness, synth, dist, evaluate
 
-__all__ = ["BnmError", "LayerInfo", "load", "LIB_PATH", "Model", "Context", "harness", "synth", "dist",
+__all__ = ["BnmError", "LayerInfo", "load", "LIB_PATH", "Model", "Context", "harness", "synth", "dist", "evaluate",
            "PATH_AUTO", "PATH_FUSED_MFMA", "PATH_LAYERWISE_ALU", "PATH_TERNARY_ALU", "DIST_U", "DIST_M",
            "SEED_DIST_U", "SEED_DIST_M", "KIND_FC", "KIND_CNN"]

@@ -10,8 +10,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu --no-verify $*"
 cd /tmp
-# 1. kernel trace + stats (timing; never combined with counters)
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
+# 1. kernel trace + stats (timing; never combined with counters): bench.py's DEFAULT step counts, so the kernel's
+#    average duration here is comparable with the live HIP-event number bench.py prints
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- python $REPO/bench.py --no-cpu $* > "$OUT/stats.log" 2>&1
 # 2. counters, one block per pass (TCC: FETCH_SIZE needs 3 of 4 slots, WRITE_SIZE 2 — separate passes)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$OUT/pmc_fetch" -o pmc -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$OUT/pmc_write" -o pmc -- $BENCH > "$OUT/pmc_write.log" 2>&1

@@ -304,3 +304,20 @@ def test_random_models_every_codec_through_model_kernels(codecs, widths, gpu_ok,
     if 36 not in codecs:
         assert any(l.startswith("fused") for l in labels), (codecs, labels)
     ctx.close()
+
+
+def test_evaluate_binding_and_latency_numbers(gpu_ok, orc, capsys):
+    """float dataset -> class ids with the C engine's arithmetic, in two launches."""
+    from bitnetmcu_amd import harness, evaluate
+    r = np.load(os.path.join(GOLDEN, "real_images.npz"))
+    model = util.load_golden_model("fc_4bitsym_64")
+    ctx = b.Context(model)
+    # the 13 real images, de-quantised to floats whose maximum magnitude is 127 -> quantise back to themselves
+    xf = r["images"].astype(np.float32) / 127.0 * 3.0
+    assert np.array_equal(harness.quantize_input(xf), r["images"])
+    acc, pred = evaluate.accuracy(ctx, xf, r["labels"])
+    assert acc == 1.0 and np.array_equal(pred, r["labels"])
+    rng = np.random.default_rng(2)
+    xr = rng.normal(size=(20000, 256)).astype(np.float32)
+    assert np.array_equal(evaluate.predict(ctx, xr), util.OracleModel(model, orc).infer(harness.quantize_input(xr)))
+    ctx.close()
