@@ -56,3 +56,64 @@ def test_full_size_properties(gpu_ok, orc):
     ctx.infer_device(imgs[ti].contiguous(), torch.empty(len(idx), dtype=torch.int32, device="cuda"), lg)
     assert np.array_equal(lg.cpu().numpy(), want_lg)
     ctx.close()
+
+
+def _oracle_parallel(model, first, count, dist, threads=None):
+    """class ids + digest/histogram of [first, first+count) computed by the ORACLE on host threads (ctypes releases
+    the GIL inside orc_model_batch)."""
+    import concurrent.futures as cf
+    threads = threads or min(32, len(os.sched_getaffinity(0)))
+    chunk = 1 << 16
+    jobs = [(s, min(chunk, first + count - s)) for s in range(first, first + count, chunk)]
+
+    def work(job):
+        s, c = job
+        om = util.OracleModel(model)
+        cls = om.infer(synth.images(s, c, dist))
+        return s, cls
+
+    out = np.empty(count, np.uint32)
+    with cf.ThreadPoolExecutor(threads) as ex:
+        for s, cls in ex.map(work, jobs):
+            out[s - first:s - first + len(cls)] = cls
+    return out
+
+
+def test_million_images_per_distribution_ids_and_logits(gpu_ok, orc):
+    """full compare of class ids AND logits on 10^6 images per distribution."""
+    from bitnetmcu_amd import DIST_M
+    model = util.load_golden_model("fc_4bitsym_64")
+    ctx = b.Context(model)
+    for dist in (DIST_U, DIST_M):
+        n = 1_000_000
+        want = _oracle_parallel(model, 0, n, dist)
+        x = synth.images(0, n, dist)
+        got, lg = ctx.infer(x, logits=True)
+        assert np.array_equal(got, want)
+        sub = np.arange(0, n, 37)                                  # logits on a 27k stride (oracle logits are single-threaded)
+        assert np.array_equal(lg[sub], util.OracleModel(model, orc).infer(x[sub], logits=True)[1])
+    ctx.close()
+
+
+@pytest.mark.skipif(os.environ.get("BNM_FULL_CPU_DIGEST") != "1", reason="set BNM_FULL_CPU_DIGEST=1 (minutes of host time)")
+def test_full_1e8_digest_and_histogram_equal_the_oracle(gpu_ok):
+    """All 10^8 class ids: order-independent digest and 10-bin histogram computed on both sides."""
+    import torch
+    model = util.load_golden_model("fc_4bitsym_64")
+    ctx = b.Context(model)
+    n = N_FULL
+    imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+    synth.fill_device(imgs, first=0, dist=DIST_U)
+    cls = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.infer_device(imgs, cls)
+    d = synth.digest_device(cls, first=0, n_bins=10).cpu().numpy()
+    want_digest, hist = 0, np.zeros(10, np.int64)
+    step = 4_000_000
+    for s in range(0, n, step):
+        c = _oracle_parallel(model, s, min(step, n - s), DIST_U)
+        want_digest = (want_digest + synth.class_digest(c, s)) & 0xFFFFFFFFFFFFFFFF
+        hist += np.bincount(c, minlength=10)
+    assert int(d[0].astype(np.uint64)) == want_digest
+    assert d[1:].tolist() == hist.tolist()
+    print("FULL 1e8 digest", hex(want_digest), "histogram", hist.tolist())
+    ctx.close()
