@@ -66,11 +66,15 @@ def _oracle_parallel(model, first, count, dist, threads=None):
     chunk = 1 << 16
     jobs = [(s, min(chunk, first + count - s)) for s in range(first, first + count, chunk)]
 
+    orc = util.load_oracle()
+    seed = b.SEED_DIST_U if dist == DIST_U else b.SEED_DIST_M
+
     def work(job):
         s, c = job
-        om = util.OracleModel(model)
-        cls = om.infer(synth.images(s, c, dist))
-        return s, cls
+        om = util.OracleModel(model, orc)
+        x = np.empty((c, 256), np.int8)
+        orc.orc_synth(seed, dist, s, c, x.ctypes.data)      # host-C generator: fast and releases the GIL
+        return s, om.infer(x)
 
     out = np.empty(count, np.uint32)
     with cf.ThreadPoolExecutor(threads) as ex:
@@ -87,7 +91,10 @@ def test_million_images_per_distribution_ids_and_logits(gpu_ok, orc):
     for dist in (DIST_U, DIST_M):
         n = 1_000_000
         want = _oracle_parallel(model, 0, n, dist)
-        x = synth.images(0, n, dist)
+        import torch
+        xt = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+        synth.fill_device(xt, first=0, dist=dist)
+        x = xt.cpu().numpy()
         got, lg = ctx.infer(x, logits=True)
         assert np.array_equal(got, want)
         sub = np.arange(0, n, 37)                                  # logits on a 27k stride (oracle logits are single-threaded)
