@@ -9,6 +9,7 @@
  */
 #include "bitnet_oracle.h"
 #include "synth.h"
+#include <stdlib.h>
 #include <string.h>
 
 /* ---------------------------------------------------------------------------------------------
@@ -69,20 +70,41 @@ int32_t orc_weight_at(const void *weights, int32_t bpw, uint32_t n_input, uint32
     return 0;
 }
 
+/* Decode a whole layer once: W[row][k], zero for an unknown codec.  (int16: FP1.3.0 reaches +128.) */
+static void decode_layer(const void *weights, int32_t bpw, uint32_t n_input, uint32_t n_output, int16_t *W) {
+    for (uint32_t row = 0; row < n_output; row++)
+        for (uint32_t k = 0; k < n_input; k++)
+            W[(size_t)row * n_input + k] = (int16_t)orc_weight_at(weights, bpw, n_input, row, k);
+}
+
+/* sum_k act[k] * W[row][k]; weights of value 0 never touch their activation (ternary pads, :128-131) */
+static void fc_dense(const int8_t *act, const int16_t *W, uint32_t n_input, uint32_t n_act, uint32_t n_output,
+                     int32_t *output) {
+    for (uint32_t row = 0; row < n_output; row++) {
+        const int16_t *w = W + (size_t)row * n_input;
+        int32_t sum = 0;
+        for (uint32_t k = 0; k < n_act; k++) sum += (int32_t)w[k] * (int32_t)act[k];
+        output[row] = sum;
+    }
+}
+
+/* highest k + 1 with a non-zero weight: the activations a layer can touch */
+static uint32_t used_inputs(const int16_t *W, uint32_t n_input, uint32_t n_output) {
+    uint32_t used = 0;
+    for (uint32_t row = 0; row < n_output; row++)
+        for (uint32_t k = n_input; k > used; k--)
+            if (W[(size_t)row * n_input + k - 1]) { used = k; break; }
+    return used;
+}
+
 /* BitNetMCU_inference.c:88-208.  Activations past the last non-zero ternary trit are never
  * dereferenced in the reference (:128-131); the same holds here. */
 void orc_processfclayer(const int8_t *activations, const uint32_t *weights, int32_t bpw,
                         uint32_t n_input, uint32_t n_output, int32_t *output) {
-    for (uint32_t row = 0; row < n_output; row++) {
-        int32_t sum = 0;
-        if (bpw == 64 || codec_field_bits(bpw)) {
-            for (uint32_t k = 0; k < n_input; k++) {
-                int32_t w = orc_weight_at(weights, bpw, n_input, row, k);
-                if (w != 0) sum += w * (int32_t)activations[k];
-            }
-        }
-        output[row] = sum;
-    }
+    int16_t *W = (int16_t *)malloc((size_t)n_input * n_output * sizeof(int16_t) + 2);
+    decode_layer(weights, bpw, n_input, n_output, W);
+    fc_dense(activations, W, n_input, used_inputs(W, n_input, n_output), n_output, output);
+    free(W);
 }
 
 /* BitNetMCU_inference.c:23-72.  First strict maximum (:32-37); shift = number of significant
@@ -147,14 +169,17 @@ int32_t *orc_processmaxpool22(int32_t *act, uint32_t xy, int32_t *out) {
 #define ORC_MAX_ACT 1024
 
 /* FC tail shared by both schedules: fc -> ReLUNorm, repeated; the class id is the argmax
- * returned by the last ReLUNorm (BitNetMCU_MNIST_dll.c:99-120 / :83-90). */
-static uint32_t run_fc_chain(int8_t *act, const orc_fc_layer *L, uint32_t n_layers,
+ * returned by the last ReLUNorm (BitNetMCU_MNIST_dll.c:99-120 / :83-90).  `dec` (optional): the layers'
+ * weights already decoded by decode_model(), so a batch pays for the unpacking once. */
+typedef struct { int16_t *W; uint32_t used; } dec_layer;
+
+static uint32_t run_fc_chain(int8_t *act, const orc_fc_layer *L, uint32_t n_layers, const dec_layer *dec,
                              int32_t *logits, int8_t *acts_out) {
     int32_t acc[ORC_MAX_ACT];
     uint32_t cls = 255;
     for (uint32_t l = 0; l < n_layers; l++) {
-        orc_processfclayer(act, (const uint32_t *)L[l].weights, L[l].bits_per_weight,
-                           L[l].n_input, L[l].n_output, acc);
+        if (dec) fc_dense(act, dec[l].W, L[l].n_input, dec[l].used, L[l].n_output, acc);
+        else orc_processfclayer(act, (const uint32_t *)L[l].weights, L[l].bits_per_weight, L[l].n_input, L[l].n_output, acc);
         if (l + 1 == n_layers && logits)
             memcpy(logits, acc, sizeof(int32_t) * L[l].n_output);
         cls = orc_ReLUNorm(acc, act, L[l].n_output);
@@ -163,19 +188,39 @@ static uint32_t run_fc_chain(int8_t *act, const orc_fc_layer *L, uint32_t n_laye
     return cls;
 }
 
-uint32_t orc_fc_model(const int8_t *image, const orc_fc_layer *L, uint32_t n_layers,
-                      int32_t *logits, int8_t *acts) {
+static dec_layer *decode_model(const orc_fc_layer *L, uint32_t n_layers) {
+    dec_layer *d = (dec_layer *)calloc(n_layers, sizeof(dec_layer));
+    for (uint32_t l = 0; l < n_layers; l++) {
+        d[l].W = (int16_t *)malloc((size_t)L[l].n_input * L[l].n_output * sizeof(int16_t) + 2);
+        decode_layer(L[l].weights, L[l].bits_per_weight, L[l].n_input, L[l].n_output, d[l].W);
+        d[l].used = used_inputs(d[l].W, L[l].n_input, L[l].n_output);
+    }
+    return d;
+}
+
+static void free_model(dec_layer *d, uint32_t n_layers) {
+    for (uint32_t l = 0; l < n_layers; l++) free(d[l].W);
+    free(d);
+}
+
+static uint32_t fc_model_dec(const int8_t *image, const orc_fc_layer *L, uint32_t n_layers, const dec_layer *dec,
+                             int32_t *logits, int8_t *acts) {
     int8_t act[ORC_MAX_ACT];
     memset(act, 0, sizeof act);
     memcpy(act, image, 256);
-    return run_fc_chain(act, L, n_layers, logits, acts);
+    return run_fc_chain(act, L, n_layers, dec, logits, acts);
+}
+
+uint32_t orc_fc_model(const int8_t *image, const orc_fc_layer *L, uint32_t n_layers,
+                      int32_t *logits, int8_t *acts) {
+    return fc_model_dec(image, L, n_layers, 0, logits, acts);
 }
 
 /* BitNetMCU_MNIST_dll.c:48-91.  Per channel: widen the image to int32 (:68-70), conv 16->14,
  * conv 14->12, pool ->6, conv 6->4, pool ->2 appended channel-major (:71-76); one ReLUNorm over
  * all channels*4 values (:80); FC layers. */
-uint32_t orc_cnn_model(const int8_t *image, const orc_cnn_front *F, const orc_fc_layer *L,
-                       uint32_t n_layers, int32_t *logits, int8_t *acts) {
+static uint32_t cnn_model_dec(const int8_t *image, const orc_cnn_front *F, const orc_fc_layer *L,
+                              uint32_t n_layers, const dec_layer *dec, int32_t *logits, int8_t *acts) {
     int32_t plane[256];
     int32_t feat[ORC_MAX_ACT];
     int8_t act[ORC_MAX_ACT];
@@ -191,17 +236,24 @@ uint32_t orc_cnn_model(const int8_t *image, const orc_cnn_front *F, const orc_fc
     memset(act, 0, sizeof act);
     orc_ReLUNorm(feat, act, F->channels * 4u);
     if (acts) { memcpy(acts, act, F->channels * 4u); acts += F->channels * 4u; }
-    return run_fc_chain(act, L, n_layers, logits, acts);
+    return run_fc_chain(act, L, n_layers, dec, logits, acts);
+}
+
+uint32_t orc_cnn_model(const int8_t *image, const orc_cnn_front *F, const orc_fc_layer *L,
+                       uint32_t n_layers, int32_t *logits, int8_t *acts) {
+    return cnn_model_dec(image, F, L, n_layers, 0, logits, acts);
 }
 
 void orc_model_batch(const int8_t *images, uint64_t n, const orc_cnn_front *F,
                      const orc_fc_layer *L, uint32_t n_layers, uint32_t *cls, int32_t *logits) {
     uint32_t n_out = L[n_layers - 1].n_output;
+    dec_layer *dec = decode_model(L, n_layers);
     for (uint64_t i = 0; i < n; i++) {
         int32_t *lg = logits ? logits + i * n_out : 0;
-        cls[i] = F ? orc_cnn_model(images + 256 * i, F, L, n_layers, lg, 0)
-                   : orc_fc_model(images + 256 * i, L, n_layers, lg, 0);
+        cls[i] = F ? cnn_model_dec(images + 256 * i, F, L, n_layers, dec, lg, 0)
+                   : fc_model_dec(images + 256 * i, L, n_layers, dec, lg, 0);
     }
+    free_model(dec, n_layers);
 }
 
 void orc_synth(uint64_t seed, int dist, uint64_t first, uint64_t count, int8_t *out) {
