@@ -41,8 +41,8 @@ struct BnmFusedArgs {
     int32_t *logits;        // [n][n_classes] or nullptr
     uint64_t src_wrap = 0;  // diagnostics: read tile (t mod src_wrap) — keeps the source cache-resident
 };
-// variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (KT0 == 8 only), 2 = LDS-DMA with
-// 8-wave workgroups and staggered halves
+// variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (256-byte rows only), 2 = LDS-DMA with two
+// tiles in flight per wave (default where instantiated)
 bool bnmk_fused_supported(const BnmFusedShape &sh, int variant);
 hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a,
                          hipStream_t s);

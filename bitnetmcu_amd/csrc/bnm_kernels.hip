@@ -249,30 +249,6 @@ BNM_DEVICE i32x16 zero16() {
     return z;
 }
 
-// A operands read from an LDS copy of the fragment buffer (variant 7): frag (m, s) of a layer whose fragments start
-// at `base` (in 16-byte units), this lane's 16 bytes
-struct ALds {
-    const i32x4 *base;
-    int ks, lane;
-    BNM_DEVICE i32x4 operator()(int m, int s) const { return base[(m * ks + s) * 64 + lane]; }
-};
-
-template <int MT, int KT, bool SPLIT>
-BNM_DEVICE void layer_mma_lds(const ALds &A, const i32x4 (&b)[KT], i32x16 (&acc)[MT]) {
-#pragma unroll
-    for (int m = 0; m < MT; m++) acc[m] = zero16();
-#pragma unroll
-    for (int s = 0; s < KT; s++)
-#pragma unroll
-        for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A(m, s), b[s], acc[m], 0, 0, 0);
-    if constexpr (SPLIT) {
-#pragma unroll
-        for (int s = 0; s < KT; s++)
-#pragma unroll
-            for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A(m, KT + s), b[s], acc[m], 0, 0, 0);
-    }
-}
-
 template <int MT, int KT, bool SPLIT>
 BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 (&b)[KT], i32x16 (&acc)[MT]) {
 #pragma unroll
@@ -467,81 +443,37 @@ BNM_DEVICE void lds_dma_tile8(uint32_t lds, const int8_t *p0, const int8_t *p1, 
     else BNM_DMA8("", "");
 }
 
-// 4 x 1 KiB pieces (half a tile), non-temporal; WAITLDS as above
-template <bool WAITLDS>
-BNM_DEVICE void lds_dma_half4(uint32_t lds, const int8_t *p0, const int8_t *p1, const int8_t *p2, const int8_t *p3, uint32_t v0,
-                              uint32_t v1, uint32_t v2, uint32_t v3) {
-    uint32_t keep;
-#define BNM_DMA4(PRE)                                                                                                   \
-    asm volatile(PRE "s_nop 4\n\t"                                                                                     \
-                 "s_mov_b32 %0, m0\n\t"                                                                                 \
-                 "s_mov_b32 m0, %1\n\t"                                                                                 \
-                 "s_nop 0\n\t"                                                                                          \
-                 "global_load_lds_dwordx4 %6, %2 nt\n\t"                                                                \
-                 "s_add_u32 m0, m0, 0x400\n\t"                                                                          \
-                 "s_nop 0\n\t"                                                                                          \
-                 "global_load_lds_dwordx4 %7, %3 nt\n\t"                                                                \
-                 "s_add_u32 m0, m0, 0x400\n\t"                                                                          \
-                 "s_nop 0\n\t"                                                                                          \
-                 "global_load_lds_dwordx4 %8, %4 nt\n\t"                                                                \
-                 "s_add_u32 m0, m0, 0x400\n\t"                                                                          \
-                 "s_nop 0\n\t"                                                                                          \
-                 "global_load_lds_dwordx4 %9, %5 nt\n\t"                                                                \
-                 "s_mov_b32 m0, %0"                                                                                     \
-                 : "=&s"(keep)                                                                                          \
-                 : "s"(lds), "s"(p0), "s"(p1), "s"(p2), "s"(p3), "v"(v0), "v"(v1), "v"(v2), "v"(v3)                     \
-                 : "memory", "scc")
-    if constexpr (WAITLDS) BNM_DMA4("s_waitcnt lgkmcnt(0)\n\t");
-    else BNM_DMA4("");
-#undef BNM_DMA4
-}
-
 template <int N>
 BNM_DEVICE void bnm_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 constexpr int FUSED_TILE_BYTES = 8192;    // 32 images x 256 B
-// Kernel variants (image tile load path):
-//   0  direct global->VGPR loads in operand layout (any row length)
-//   1  LDS-DMA, one tile ahead, 4-wave workgroups (two per CU)
-//   2  as 1 with 8-wave workgroups (one per CU); the second half of the waves starts half a tile late so that, on
-//      every SIMD, one wave's MFMA phase runs beside its partner's VALU phase instead of both contending
-//   3  LDS-DMA, TWO tiles ahead in the same two buffers (all 8 B fragments are pulled into VGPRs at the top of the
-//      iteration, which frees the buffer for tile n+2 at once), non-temporal loads, 4-wave workgroups
-//   4  as 3 with 8-wave staggered workgroups
-//   5/6 software-pipelined kernel (fused_fc_pipelined_kernel below)
-constexpr int fused_wpb(int variant) { return (variant == 2 || variant == 4 || variant == 6) ? 8 : 4; }
-constexpr bool fused_deep(int variant) { return variant == 3 || variant == 4; }
-//   7  three waves per SIMD: one 8 KiB LDS tile per wave (its 8 B fragments are pulled into VGPRs at the top of the
-//      iteration and the buffer is refilled with the next tile at once), layer >= 2 weight fragments in LDS
-//      instead of VGPRs (<= 168 VGPRs), three 4-wave workgroups per CU
-constexpr bool fused_single(int variant) { return variant == 7; }
-//   8  as 1, but TWO tiles in flight per wave: the DMA for tile k+2 is issued right AFTER tile k's layer-1 MFMAs
-//      (which consumed the last B fragment of its buffer), not at the top of the iteration, so nothing is
-//      serialised in front of the MFMAs.  Profile finding (profiles/r01): with one tile in flight per wave the
-//      kernel is bound by per-wave memory-level parallelism (8 KiB / HBM latency x 2048 waves ~ 5.5 TB/s).
-//   9  as 8, with the refill split in two half-tile groups (after the layer-1 and after the layer-2 MFMAs) and the
-//      waves of the grid started a few hundred cycles apart, so the chip's requests arrive as a steady stream rather
-//      than in 16 MiB bursts
-constexpr bool fused_late(int variant) { return variant == 8 || variant == 9; }
-constexpr bool fused_halves(int variant) { return variant == 9; }
+constexpr int FUSED_WPB = 4;              // waves per workgroup; two workgroups per CU (LDS 64 KiB each)
+
+// Kernel variants = how the image tile reaches the B operands:
+//   0  DIRECT     global -> VGPR loads in operand layout (any row length; CNN tails with 64/128/192-byte rows)
+//   1  LDSDMA     8 x 1 KiB LDS-DMA pieces into a per-wave double buffer, next tile issued at the top of the iteration
+//   2  LDSDMA2    as 1 with TWO tiles in flight per wave (default where available): the refill of the buffer a tile
+//                 just vacated (tile k+2) is issued right AFTER tile k's layer-1 MFMAs, non-temporal.  With one tile
+//                 in flight the kernel is bound by per-wave memory-level parallelism (8 KiB / latency x 2048 waves);
+//                 issuing the second DMA in front of the MFMAs instead serialises the wave (profiles/r01).
+// Tried and dropped in round 1 (tag r01-experiments-all-variants): 8-wave workgroups with staggered halves, a
+// software-pipelined MFMA||VALU form, three waves per SIMD with weights in LDS, split half-tile refills.
+enum { FUSED_DIRECT = 0, FUSED_LDSDMA = 1, FUSED_LDSDMA2 = 2 };
 
 template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT>
-__global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 : 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
-                                                          const i32x4 *__restrict__ frags, uint32_t n_classes,
-                                                          uint32_t *__restrict__ cls_out,
-                                                          int32_t *__restrict__ logits_out, uint64_t src_wrap) {
+__global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
+                                                                     const i32x4 *__restrict__ frags, uint32_t n_classes,
+                                                                     uint32_t *__restrict__ cls_out,
+                                                                     int32_t *__restrict__ logits_out, uint64_t src_wrap) {
     constexpr int SP = SPLIT ? 2 : 1;
     constexpr int ROW = 32 * KT0;
-    constexpr int FUSED_WPB = fused_wpb(VARIANT);
-    constexpr bool LDSDMA = VARIANT != 0;
+    constexpr bool LDSDMA = VARIANT != FUSED_DIRECT;
+    constexpr bool TWO = VARIANT == FUSED_LDSDMA2;
     static_assert(!LDSDMA || KT0 == 8, "the LDS-DMA tile layout is for 256-byte rows");
     static_assert(!(SPLIT && DBL), "FP1.3.0 weights cannot be doubled in int8");
-    constexpr bool SINGLE = fused_single(VARIANT);
-    constexpr int BUFS = SINGLE ? 1 : 2;
-    constexpr int WFRAGS = SINGLE ? (M2 * M1 + M3 * M2 + (M4 > 0 ? M4 * M3 : 0)) * SP : 0;   // 1 KiB each
-    __shared__ __attribute__((aligned(1024))) char smem[LDSDMA ? FUSED_WPB * BUFS * FUSED_TILE_BYTES + WFRAGS * 1024 : 16];
+    __shared__ __attribute__((aligned(1024))) char smem[LDSDMA ? FUSED_WPB * 2 * FUSED_TILE_BYTES : 16];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -549,29 +481,20 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
 
     // weights: unpacked fragments -> registers, once
     AFrags<M1, KT0 * SP> A1;
-    AFrags<(SINGLE ? 1 : M2), (SINGLE ? 1 : M1 * SP)> A2;
-    AFrags<(SINGLE ? 1 : M3), (SINGLE ? 1 : M2 * SP)> A3;
-    AFrags<((M4 > 0 && !SINGLE) ? M4 : 1), (SINGLE ? 1 : M3 * SP)> A4;
+    AFrags<M2, M1 * SP> A2;
+    AFrags<M3, M2 * SP> A3;
+    AFrags<(M4 > 0 ? M4 : 1), M3 * SP> A4;
     const i32x4 *fp = frags;
     A1.load(fp, lane);  fp += M1 * KT0 * SP * 64;
-    const i32x4 *wl = (const i32x4 *)(smem + FUSED_WPB * BUFS * FUSED_TILE_BYTES);   // LDS weight copy (variant 7)
-    if constexpr (SINGLE) {
-        i32x4 *dst = (i32x4 *)(smem + FUSED_WPB * BUFS * FUSED_TILE_BYTES);
-        for (int i = threadIdx.x; i < WFRAGS * 64; i += 64 * FUSED_WPB) dst[i] = fp[i];
-        __syncthreads();
-    } else {
-        A2.load(fp, lane);  fp += M2 * M1 * SP * 64;
-        A3.load(fp, lane);  fp += M3 * M2 * SP * 64;
-        if constexpr (M4 > 0) A4.load(fp, lane);
-    }
-    const ALds L2a{wl, M1 * SP, lane}, L3a{wl + M2 * M1 * SP * 64, M2 * SP, lane},
-        L4a{wl + (M2 * M1 + M3 * M2) * SP * 64, M3 * SP, lane};
+    A2.load(fp, lane);  fp += M2 * M1 * SP * 64;
+    A3.load(fp, lane);  fp += M3 * M2 * SP * 64;
+    if constexpr (M4 > 0) A4.load(fp, lane);
 
     const uint64_t n_tiles = (n + 31ull) >> 5;
     const uint64_t stride = (uint64_t)gridDim.x * FUSED_WPB;
     uint64_t tile = (uint64_t)blockIdx.x * FUSED_WPB + wave;
 
-    // ---- variant 1 addressing -------------------------------------------------------------------
+    // ---- LDS-DMA addressing ------------------------------------------------------------------------
     // LDS tile image: row r (image) at r*256, 16-byte slot c' holds global slot c = c' ^ (r & 15).
     // DMA piece t covers rows 4t..4t+3: lane l -> row 4t + (l>>4), slot l&15.
     uint32_t voff[4];
@@ -579,13 +502,11 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
     if constexpr (LDSDMA) {
 #pragma unroll
         for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
-        lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * BUFS * FUSED_TILE_BYTES;
+        lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
         // B-operand read of K-step s: row j, global slot 2s+h -> LDS slot (2s+h) ^ (j&15) = (2s) ^ (h ^ (j&15))
-        rd_base = (uint32_t)wave * BUFS * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
+        rd_base = (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
     }
 
-    constexpr bool LATE = fused_late(VARIANT);
-    constexpr bool DEEP = fused_deep(VARIANT) || SINGLE || LATE;   // DMA statements: non-temporal + wait for own ds_reads
     auto dma_tile = [&](uint64_t t, int par) {
         // src_wrap != 0 (diagnostics only, BNM_DIAG_SRC_WRAP): read tile (t mod src_wrap) instead, so the source stays
         // cache-resident and the kernel's compute-side time can be measured without HBM in the way
@@ -593,8 +514,8 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
         uint32_t lds = lds_wave + (uint32_t)par * FUSED_TILE_BYTES;
         uint64_t first = t << 5;
         if (first + 32ull <= n) {
-            lds_dma_tile8<DEEP, DEEP>(lds, base, base + 1024, base + 2048, base + 3072, base + 4096, base + 5120, base + 6144,
-                          base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0], voff[1], voff[2], voff[3]);
+            lds_dma_tile8<TWO, TWO>(lds, base, base + 1024, base + 2048, base + 3072, base + 4096, base + 5120, base + 6144,
+                                    base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0], voff[1], voff[2], voff[3]);
         } else {
             // ragged last tile: rows past the end re-read the last valid image (never out of bounds)
             uint32_t nv = (uint32_t)(n - first);
@@ -605,8 +526,8 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
                 uint32_t src = r < nv ? r : nv - 1u;
                 v[tt] = src * 256u + 16u * ((uint32_t)(lane & 15) ^ (r & 15u));
             }
-            lds_dma_tile8<DEEP, DEEP>(lds, base, base, base, base, base, base, base, base, v[0], v[1], v[2], v[3], v[4], v[5],
-                                      v[6], v[7]);
+            lds_dma_tile8<TWO, TWO>(lds, base, base, base, base, base, base, base, base, v[0], v[1], v[2], v[3], v[4], v[5],
+                                    v[6], v[7]);
         }
     };
 
@@ -624,17 +545,8 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
         if constexpr (LDSDMA) dma_tile(tile, 0);
         else direct_load(tile, bnext);
     }
-    if constexpr (DEEP && !SINGLE) {
+    if constexpr (TWO) {
         if (tile + stride < n_tiles) dma_tile(tile + stride, 1);
-    }
-    if constexpr (FUSED_WPB == 8) {
-        if (wave >= 4) __builtin_amdgcn_s_sleep(20);   // ~1300 cycles: half a tile's VALU+MFMA time
-    }
-    if constexpr (fused_halves(VARIANT)) {
-        // de-phase the grid: blocks start 0..7 x 256 cycles apart, waves within a block 0..3 x 64 cycles
-        const int ph = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) & 7));
-        for (int i = 0; i < ph; i++) __builtin_amdgcn_s_sleep(4);
-        for (int i = 0; i < wave; i++) __builtin_amdgcn_s_sleep(1);
     }
 
     for (; tile < n_tiles; tile += stride) {
@@ -642,9 +554,7 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
         i32x4 b0[KT0];
         i32x16 acc1[M1];
         if constexpr (LDSDMA) {
-            if constexpr (SINGLE) {
-                bnm_wait_vmcnt<0>();     // this wave's only tile in flight
-            } else if constexpr (!DEEP) {
+            if constexpr (!TWO) {
                 if (next < n_tiles) {
                     dma_tile(next, par ^ 1);
                     bnm_wait_vmcnt<8>();
@@ -652,7 +562,7 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
                     bnm_wait_vmcnt<0>();
                 }
             } else {
-                // in flight: tile (8 pieces) and, if it exists, next (8 pieces), issued one iteration ago
+                // in flight: this tile (8 pieces) and, if it exists, the next one (8 pieces, issued an iteration ago)
                 if (next < n_tiles) bnm_wait_vmcnt<8>();
                 else bnm_wait_vmcnt<0>();
             }
@@ -661,14 +571,7 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
 #pragma unroll
             for (int s = 0; s < KT0; s++)
                 b0[s] = *(const i32x4 *)(smem + ((rd_base ^ (32u * s)) + (uint32_t)par * FUSED_TILE_BYTES));
-            if constexpr (SINGLE) {
-                if (next < n_tiles) dma_tile(next, 0);    // same buffer, after its 8 ds_reads have returned
-            } else if constexpr (DEEP && !LATE) {
-                // the buffer just read is free as soon as its 8 ds_reads have returned (the DMA statement waits
-                // lgkmcnt(0) first): refill it with the tile after next
-                if (next + stride < n_tiles) dma_tile(next + stride, par);
-            }
-            if constexpr (!SINGLE && !LATE) par ^= 1;
+            if constexpr (!TWO) par ^= 1;
         } else {
 #pragma unroll
             for (int s = 0; s < KT0; s++) b0[s] = bnext[s];
@@ -676,42 +579,22 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
         }
 
         layer_mma<M1, KT0, SPLIT>(A1, b0, acc1);
-        constexpr bool HALVES = fused_halves(VARIANT);
-        const uint64_t refill = next + stride;
-        // a ragged LAST tile goes through the generic 8-piece path; only whole tiles are split
-        const bool refill_whole = HALVES && refill < n_tiles && ((refill << 5) + 32ull <= n);
-        if constexpr (LATE) {
-            // all 8 B fragments of this tile's buffer have been consumed: refill it with the tile after next
-            if (refill < n_tiles) {
-                if (refill_whole) {
-                    const int8_t *base = images + (src_wrap ? refill % src_wrap : refill) * (uint64_t)FUSED_TILE_BYTES;
-                    lds_dma_half4<true>(lds_wave + (uint32_t)par * FUSED_TILE_BYTES, base, base + 1024, base + 2048, base + 3072,
-                                        voff[0], voff[1], voff[2], voff[3]);
-                } else {
-                    dma_tile(refill, par);
-                }
-            }
+        if constexpr (TWO) {
+            // all 8 B fragments of this tile's buffer have been consumed (the DMA statement first retires the wave's
+            // own ds_reads): refill it with the tile after next
+            if (next + stride < n_tiles) dma_tile(next + stride, par);
+            par ^= 1;
         }
         i32x4 p1[M1];
         relunorm_pack<M1, DBL>(acc1, p1, h);
 
         i32x16 acc2[M2];
-        if constexpr (SINGLE) layer_mma_lds<M2, M1, SPLIT>(L2a, p1, acc2);
-        else layer_mma<M2, M1, SPLIT>(A2, p1, acc2);
-        if constexpr (LATE) {
-            if (refill_whole) {
-                const int8_t *base = images + (src_wrap ? refill % src_wrap : refill) * (uint64_t)FUSED_TILE_BYTES + 4096;
-                lds_dma_half4<false>(lds_wave + (uint32_t)par * FUSED_TILE_BYTES + 4096u, base, base + 1024, base + 2048,
-                                     base + 3072, voff[0], voff[1], voff[2], voff[3]);
-            }
-            par ^= 1;
-        }
+        layer_mma<M2, M1, SPLIT>(A2, p1, acc2);
         i32x4 p2[M2];
         relunorm_pack<M2, DBL>(acc2, p2, h);
 
         i32x16 acc3[M3];
-        if constexpr (SINGLE) layer_mma_lds<M3, M2, SPLIT>(L3a, p2, acc3);
-        else layer_mma<M3, M2, SPLIT>(A3, p2, acc3);
+        layer_mma<M3, M2, SPLIT>(A3, p2, acc3);
 
         const uint64_t img = (tile << 5) + (uint64_t)j;
         uint32_t cls;
@@ -719,8 +602,7 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
             i32x4 p3[M3];
             relunorm_pack<M3, DBL>(acc3, p3, h);
             i32x16 acc4[M4];
-            if constexpr (SINGLE) layer_mma_lds<M4, M3, SPLIT>(L4a, p3, acc4);
-            else layer_mma<M4, M3, SPLIT>(A4, p3, acc4);
+            layer_mma<M4, M3, SPLIT>(A4, p3, acc4);
             cls = argmax_rows<M4>(acc4, h, n_classes);
             if (logits_out && img < n) store_logits<M4>(acc4, logits_out + img * n_classes, h, n_classes);
         } else {
@@ -728,205 +610,6 @@ __global__ __launch_bounds__(64 * fused_wpb(VARIANT), fused_single(VARIANT) ? 3 
             if (logits_out && img < n) store_logits<M3>(acc3, logits_out + img * n_classes, h, n_classes);
         }
         if (h == 0 && img < n) cls_out[img] = cls;
-    }
-}
-
-// =================================================================================================
-// Software-pipelined form of the fused kernel (variants 5 / 6; KT0 == 8, doubled weights).
-//
-// Profile of variants 1-4 (profiles/r01): VALU ~57 % + MFMA ~29 % of SIMD time with almost no overlap — the two
-// waves of a SIMD run the same code in phase, so both want the matrix pipe, then both want the VALU.  Here a wave
-// overlaps the two pipes by itself: the 16 layer-1 MFMAs of tile k+1 (62 % of all MFMA time, operands straight
-// from the LDS tile that landed one iteration ago) are issued one at a time between ~8-instruction slices of
-// tile k's layer-1 ReLUNorm (max tree, shift, then one packed dword = 4 x v_med3 + 4 x SDWA shift per slice).
-// A 32x32x32 i8 MFMA occupies the matrix pipe for 32 cycles = 8 VALU issue slots, so each slice hides under
-// the MFMA issued before it.  __builtin_amdgcn_sched_barrier(0) pins the hand-made order.
-// LDS ring: tile_k lives in buffer k&1; at iteration k the buffer of tile_k (drained during iteration k-1) is
-// refilled with tile_{k+2} while tile_{k+1} is read.
-// =================================================================================================
-#define BNM_PIN() __builtin_amdgcn_sched_barrier(0)
-
-// one packed dword: y_b = clamp(v_b, 0, hi) >> s for 4 values; SDWA writes are one instruction apart (dst_sel
-// forwarding hazard), 8 VALU + 1 nop
-BNM_DEVICE int clamp_shift_pack4(int a, int b, int c, int d, int hi, int s) {
-    int out, t0, t1;
-    asm("v_med3_i32 %1, %3, 0, %7\n\t"
-        "v_med3_i32 %2, %4, 0, %7\n\t"
-        "v_lshrrev_b32_sdwa %0, %8, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_med3_i32 %1, %5, 0, %7\n\t"
-        "v_lshrrev_b32_sdwa %0, %8, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_med3_i32 %2, %6, 0, %7\n\t"
-        "v_lshrrev_b32_sdwa %0, %8, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "s_nop 0\n\t"
-        "v_lshrrev_b32_sdwa %0, %8, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "s_nop 0"
-        : "=&v"(out), "=&v"(t0), "=&v"(t1)
-        : "v"(a), "v"(b), "v"(c), "v"(d), "v"(hi), "v"(s));
-    return out;
-}
-
-// ReLUNorm state machine for the doubled-weight path, cut into slices of <= ~8 VALU.  MT == 2.
-struct RnSlices2 {
-    int mx, sh, hi;
-    BNM_DEVICE void max_part(const i32x16 &a, int lo, bool first) {   // 8 values -> 4 max3
-        int m = first ? a[lo] : mx;
-        m = max(max(m, a[lo + (first ? 1 : 0)]), a[lo + (first ? 2 : 1)]);
-        if (first) {
-            m = max(max(m, a[lo + 3]), a[lo + 4]);
-            m = max(max(m, a[lo + 5]), a[lo + 6]);
-            m = max(m, a[lo + 7]);
-        } else {
-            m = max(max(m, a[lo + 2]), a[lo + 3]);
-            m = max(max(m, a[lo + 4]), a[lo + 5]);
-            m = max(max(m, a[lo + 6]), a[lo + 7]);
-        }
-        mx = m;
-    }
-    BNM_DEVICE void finish_max(int h) {
-        mx = max(mx, partner32(mx, h));
-        mx = max(mx, 0);
-        uint32_t t = (uint32_t)mx >> 8;
-        sh = t ? 32 - __builtin_clz(t) : 0;
-        hi = (255 << sh) - 1;
-    }
-    BNM_DEVICE int dword(const i32x16 &a, int q) const {
-        int y = clamp_shift_pack4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3], hi, sh);
-        return (int)__builtin_amdgcn_lerp((uint32_t)y, 0u, 0x01010101u);
-    }
-};
-
-template <int M2, int M3, int M4, int VARIANT>
-__global__ __launch_bounds__(64 * (VARIANT == 6 ? 8 : 4), 2) void fused_fc_pipelined_kernel(
-    const int8_t *__restrict__ images, uint64_t n, const i32x4 *__restrict__ frags, uint32_t n_classes,
-    uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out, uint64_t /*src_wrap*/) {
-    constexpr int KT0 = 8, M1 = 2;
-    constexpr int WPB = VARIANT == 6 ? 8 : 4;
-    __shared__ __attribute__((aligned(1024))) char smem[WPB * 2 * FUSED_TILE_BYTES];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, h = lane >> 5;
-
-    AFrags<M1, KT0> A1;
-    AFrags<M2, M1> A2;
-    AFrags<M3, M2> A3;
-    AFrags<(M4 > 0 ? M4 : 1), M3> A4;
-    const i32x4 *fp = frags;
-    A1.load(fp, lane);  fp += M1 * KT0 * 64;
-    A2.load(fp, lane);  fp += M2 * M1 * 64;
-    A3.load(fp, lane);  fp += M3 * M2 * 64;
-    if constexpr (M4 > 0) A4.load(fp, lane);
-
-    const uint64_t n_tiles = (n + 31ull) >> 5;
-    const uint64_t stride = (uint64_t)gridDim.x * WPB;
-    uint64_t tile = (uint64_t)blockIdx.x * WPB + wave;
-    if (tile >= n_tiles) return;
-
-    uint32_t voff[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
-    const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
-    const uint32_t rd_base = (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
-
-    auto dma_tile = [&](uint64_t t, int par) {
-        const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
-        uint32_t lds = lds_wave + (uint32_t)par * FUSED_TILE_BYTES;
-        uint64_t first = t << 5;
-        if (first + 32ull <= n) {
-            lds_dma_tile8<true, true>(lds, base, base + 1024, base + 2048, base + 3072, base + 4096, base + 5120, base + 6144,
-                                      base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0], voff[1], voff[2], voff[3]);
-        } else {
-            uint32_t nv = (uint32_t)(n - first);
-            uint32_t v[8];
-#pragma unroll
-            for (int tt = 0; tt < 8; tt++) {
-                uint32_t r = 4u * tt + (uint32_t)(lane >> 4);
-                uint32_t src = r < nv ? r : nv - 1u;
-                v[tt] = src * 256u + 16u * ((uint32_t)(lane & 15) ^ (r & 15u));
-            }
-            lds_dma_tile8<true, true>(lds, base, base, base, base, base, base, base, base, v[0], v[1], v[2], v[3], v[4], v[5],
-                                      v[6], v[7]);
-        }
-    };
-    auto bfrag = [&](int par, int s) -> i32x4 {
-        return *(const i32x4 *)(smem + ((rd_base ^ (32u * s)) + (uint32_t)par * FUSED_TILE_BYTES));
-    };
-
-    // ---- prologue: tile_0 (and tile_1) in flight, layer 1 of tile_0 ----------------------------------------
-    dma_tile(tile, 0);
-    if (tile + stride < n_tiles) { dma_tile(tile + stride, 1); bnm_wait_vmcnt<8>(); } else { bnm_wait_vmcnt<0>(); }
-    if constexpr (WPB == 8) {
-        if (wave >= 4) __builtin_amdgcn_s_sleep(16);
-    }
-    i32x16 acc1[M1];
-    {
-        i32x4 b[KT0];
-#pragma unroll
-        for (int s = 0; s < KT0; s++) b[s] = bfrag(0, s);
-        layer_mma<M1, KT0, false>(A1, b, acc1);
-    }
-
-    int par = 0;   // buffer of the CURRENT tile (already drained)
-    for (;; tile += stride) {
-        const uint64_t next = tile + stride;
-        const bool has_next = next < n_tiles;
-        i32x4 p1[M1];
-        i32x16 acc1n[M1];
-        if (has_next) {
-            if (next + stride < n_tiles) { dma_tile(next + stride, par); bnm_wait_vmcnt<8>(); } else { bnm_wait_vmcnt<0>(); }
-            // ---- interleave: 16 layer-1 MFMAs of tile `next`  ||  ReLUNorm of acc1 (current tile) ----------
-            const int np = par ^ 1;
-            RnSlices2 rn;
-            i32x4 b0 = bfrag(np, 0), b1 = bfrag(np, 1), b2;
-            acc1n[0] = zero16();
-            acc1n[1] = zero16();
-            BNM_PIN();
-#define BNM_MM(S, M, B) acc1n[M] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1.a[M][S], B, acc1n[M], 0, 0, 0); BNM_PIN()
-            BNM_MM(0, 0, b0); rn.max_part(acc1[0], 0, true);  b2 = bfrag(np, 2); BNM_PIN();
-            BNM_MM(0, 1, b0); rn.max_part(acc1[0], 8, false); BNM_PIN();
-            BNM_MM(1, 0, b1); rn.max_part(acc1[1], 0, false); b0 = bfrag(np, 3); BNM_PIN();
-            BNM_MM(1, 1, b1); rn.max_part(acc1[1], 8, false); BNM_PIN();
-            BNM_MM(2, 0, b2); rn.finish_max(h); b1 = bfrag(np, 4); BNM_PIN();
-            BNM_MM(2, 1, b2); p1[0][0] = rn.dword(acc1[0], 0); BNM_PIN();
-            BNM_MM(3, 0, b0); p1[0][1] = rn.dword(acc1[0], 1); b2 = bfrag(np, 5); BNM_PIN();
-            BNM_MM(3, 1, b0); p1[0][2] = rn.dword(acc1[0], 2); BNM_PIN();
-            BNM_MM(4, 0, b1); p1[0][3] = rn.dword(acc1[0], 3); b0 = bfrag(np, 6); BNM_PIN();
-            BNM_MM(4, 1, b1); p1[1][0] = rn.dword(acc1[1], 0); BNM_PIN();
-            BNM_MM(5, 0, b2); p1[1][1] = rn.dword(acc1[1], 1); b1 = bfrag(np, 7); BNM_PIN();
-            BNM_MM(5, 1, b2); p1[1][2] = rn.dword(acc1[1], 2); BNM_PIN();
-            BNM_MM(6, 0, b0); p1[1][3] = rn.dword(acc1[1], 3); BNM_PIN();
-            BNM_MM(6, 1, b0);
-            BNM_MM(7, 0, b1);
-            BNM_MM(7, 1, b1);
-#undef BNM_MM
-        } else {
-            relunorm_pack<M1, true>(acc1, p1, h);
-        }
-
-        i32x16 acc2[M2];
-        layer_mma<M2, M1, false>(A2, p1, acc2);
-        i32x4 p2[M2];
-        relunorm_pack<M2, true>(acc2, p2, h);
-        i32x16 acc3[M3];
-        layer_mma<M3, M2, false>(A3, p2, acc3);
-
-        const uint64_t img = (tile << 5) + (uint64_t)j;
-        uint32_t cls;
-        if constexpr (M4 > 0) {
-            i32x4 p3[M3];
-            relunorm_pack<M3, true>(acc3, p3, h);
-            i32x16 acc4[M4];
-            layer_mma<M4, M3, false>(A4, p3, acc4);
-            cls = argmax_rows<M4>(acc4, h, n_classes);
-            if (logits_out && img < n) store_logits<M4>(acc4, logits_out + img * n_classes, h, n_classes);
-        } else {
-            cls = argmax_rows<M3>(acc3, h, n_classes);
-            if (logits_out && img < n) store_logits<M3>(acc3, logits_out + img * n_classes, h, n_classes);
-        }
-        if (h == 0 && img < n) cls_out[img] = cls;
-        if (!has_next) break;
-#pragma unroll
-        for (int m = 0; m < M1; m++) acc1[m] = acc1n[m];
-        par ^= 1;
     }
 }
 
@@ -942,37 +625,31 @@ struct FusedEntry {
     { {KT0, {M1, M2, M3, M4}, SPLIT, DBL}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, DBL, VAR> }
 const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
-    FUSED(8, 2, 2, 2, 1, false, true, 9),
-    FUSED(8, 2, 2, 2, 1, false, true, 8),
-    FUSED(8, 2, 2, 2, 1, false, true, 7),
-    { {8, {2, 2, 2, 1}, false, true}, 5, fused_fc_pipelined_kernel<2, 2, 1, 5> },
-    { {8, {2, 2, 2, 1}, false, true}, 6, fused_fc_pipelined_kernel<2, 2, 1, 6> },
-    FUSED(8, 2, 2, 2, 1, false, true, 3),
-    FUSED(8, 2, 2, 2, 1, false, true, 4),
-    FUSED(8, 2, 2, 2, 1, false, true, 1),
-    FUSED(8, 2, 2, 2, 1, false, true, 2),
-    FUSED(8, 2, 2, 2, 1, false, true, 0),
+    FUSED(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA2),
+    FUSED(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA),
+    FUSED(8, 2, 2, 2, 1, false, true, FUSED_DIRECT),
     // same shape with codecs whose weights cannot be doubled in int8 (8-bit two's complement)
-    FUSED(8, 2, 2, 2, 1, false, false, 1),
-    FUSED(8, 2, 2, 2, 1, false, false, 0),
-    // same shape, FP1.3.0 weights (mcu/BitNetMCU_model_12k_FP130.h): +-128 split over two A passes
-    FUSED(8, 2, 2, 2, 1, true, false, 1),
-    FUSED(8, 2, 2, 2, 1, true, false, 0),
+    FUSED(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA),
+    FUSED(8, 2, 2, 2, 1, false, false, FUSED_DIRECT),
+    // same shape, FP1.3.0 weights (mcu/BitNetMCU_model_12k_FP130.h): +128 split over two A passes
+    FUSED(8, 2, 2, 2, 1, true, false, FUSED_LDSDMA),
+    FUSED(8, 2, 2, 2, 1, true, false, FUSED_DIRECT),
     // FC 256-16-16-10 2bitsym (mcu/BitNetMCU_model_1k.h)
-    FUSED(8, 1, 1, 1, 0, false, true, 1),
-    FUSED(8, 1, 1, 1, 0, false, true, 0),
+    FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA2),
+    FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA),
+    FUSED(8, 1, 1, 1, 0, false, true, FUSED_DIRECT),
     // ternary FC 256-96-96-96-10 through the MFMA path (optional; config 3's product path is the ALU kernel)
-    FUSED(8, 3, 3, 3, 1, false, true, 1),
-    FUSED(8, 3, 3, 3, 1, false, true, 0),
+    FUSED(8, 3, 3, 3, 1, false, true, FUSED_LDSDMA),
+    FUSED(8, 3, 3, 3, 1, false, true, FUSED_DIRECT),
     // CNN FC tails: 4C-96-64-10 (cnn_64/48/32/16), 64-64-48-10 (cnn_16small), 256-96-64-37 (letters)
-    FUSED(8, 3, 2, 1, 0, false, true, 1),
-    FUSED(8, 3, 2, 1, 0, false, true, 0),
-    FUSED(6, 3, 2, 1, 0, false, true, 0),
-    FUSED(4, 3, 2, 1, 0, false, true, 0),
-    FUSED(2, 3, 2, 1, 0, false, true, 0),
-    FUSED(2, 2, 2, 1, 0, false, true, 0),
-    FUSED(8, 3, 2, 2, 0, false, true, 1),
-    FUSED(8, 3, 2, 2, 0, false, true, 0),
+    FUSED(8, 3, 2, 1, 0, false, true, FUSED_LDSDMA),
+    FUSED(8, 3, 2, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(6, 3, 2, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(4, 3, 2, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(2, 3, 2, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(2, 2, 2, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(8, 3, 2, 2, 0, false, true, FUSED_LDSDMA),
+    FUSED(8, 3, 2, 2, 0, false, true, FUSED_DIRECT),
 };
 const FusedEntry *find_fused(const BnmFusedShape &sh, int variant) {
     for (const FusedEntry &e : kFused)
@@ -992,20 +669,21 @@ int num_cus() {
 }  // namespace
 
 bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fused(sh, variant) != nullptr; }
-// measured best first (profiles/r01): 8 (two tiles in flight) > 1 (LDS-DMA) > 0 (direct loads)
-int bnmk_fused_default_variant(const BnmFusedShape &sh) { return find_fused(sh, 8) ? 8 : find_fused(sh, 1) ? 1 : 0; }
+// measured best first (profiles/r01)
+int bnmk_fused_default_variant(const BnmFusedShape &sh) {
+    return find_fused(sh, FUSED_LDSDMA2) ? FUSED_LDSDMA2 : find_fused(sh, FUSED_LDSDMA) ? FUSED_LDSDMA : FUSED_DIRECT;
+}
 
 hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a, hipStream_t s) {
     const FusedEntry *e = find_fused(sh, variant);
     if (!e) return hipErrorInvalidValue;
     if (a.n == 0) return hipSuccess;
-    const int wpb = fused_wpb(variant);
     uint64_t n_tiles = (a.n + 31ull) / 32ull;
-    uint64_t want = (n_tiles + wpb - 1) / wpb;
-    // default: 8 resident waves per CU (2 x 256 threads or 1 x 512 threads); variant 7: 12 (3 x 256 threads)
-    uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)num_cus() * (uint64_t)(fused_single(variant) ? 3 : 8 / wpb);
+    uint64_t want = (n_tiles + FUSED_WPB - 1) / FUSED_WPB;
+    // persistent grid: 8 resident waves per CU (2 workgroups x 4 waves; VGPRs and LDS allow no more)
+    uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)num_cus() * 2ull;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
-    e->fn<<<dim3(blocks), dim3(64 * wpb), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap);
+    e->fn<<<dim3(blocks), dim3(64 * FUSED_WPB), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap);
     return hipGetLastError();
 }
 
@@ -1501,8 +1179,8 @@ hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s
 
 // =================================================================================================
 // Diagnostics: what the image stream alone costs.  mode 0: plain 16 B/lane global loads, grid-stride;
-// mode 1: the fused kernel's own tile loop (LDS-DMA double buffer, counted vmcnt) with the math replaced by one
-// ds_read per tile.  Both write one dword per 32 images so the result cannot be optimised away.  Used by
+// mode 1 / 2: the fused kernel's own tile loop (variant LDSDMA / LDSDMA2) with the math replaced by one ds_read
+// per tile.  Both write one dword per 32 images so the result cannot be optimised away.  Used by
 // profiles/stream_ceiling.py to put the achieved GB/s of the real kernel next to the practical read ceiling.
 // =================================================================================================
 __global__ __launch_bounds__(256) void diag_stream_plain_kernel(const u32x4 *__restrict__ src, uint64_t n16,
@@ -1522,10 +1200,10 @@ __global__ __launch_bounds__(256) void diag_stream_plain_kernel(const u32x4 *__r
     if (acc == 0x12345678u) out[0] = acc;   // practically never: keeps the loads alive without a store stream
 }
 
-template <int WPB, bool DEEP>
-__global__ __launch_bounds__(64 * WPB, 2) void diag_stream_tiles_kernel(const int8_t *__restrict__ images, uint64_t n,
-                                                                        uint32_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(1024))) char smem[WPB * 2 * FUSED_TILE_BYTES];
+template <bool TWO>
+__global__ __launch_bounds__(64 * FUSED_WPB, 2) void diag_stream_tiles_kernel(const int8_t *__restrict__ images, uint64_t n,
+                                                                              uint32_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(1024))) char smem[FUSED_WPB * 2 * FUSED_TILE_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t voff[4];
@@ -1533,26 +1211,26 @@ __global__ __launch_bounds__(64 * WPB, 2) void diag_stream_tiles_kernel(const in
     for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
     const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
     const uint64_t n_tiles = n >> 5;   // whole tiles only
-    const uint64_t stride = (uint64_t)gridDim.x * WPB;
-    uint64_t tile = (uint64_t)blockIdx.x * WPB + wave;
+    const uint64_t stride = (uint64_t)gridDim.x * FUSED_WPB;
+    uint64_t tile = (uint64_t)blockIdx.x * FUSED_WPB + wave;
     auto dma = [&](uint64_t t, int par) {
         const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
-        lds_dma_tile8<DEEP, DEEP>(lds_wave + (uint32_t)par * FUSED_TILE_BYTES, base, base + 1024, base + 2048, base + 3072,
-                                  base + 4096, base + 5120, base + 6144, base + 7168, voff[0], voff[1], voff[2], voff[3],
-                                  voff[0], voff[1], voff[2], voff[3]);
+        lds_dma_tile8<TWO, TWO>(lds_wave + (uint32_t)par * FUSED_TILE_BYTES, base, base + 1024, base + 2048, base + 3072,
+                                base + 4096, base + 5120, base + 6144, base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0],
+                                voff[1], voff[2], voff[3]);
     };
     int par = 0;
     if (tile < n_tiles) dma(tile, 0);
-    if (DEEP && tile + stride < n_tiles) dma(tile + stride, 1);
+    if (TWO && tile + stride < n_tiles) dma(tile + stride, 1);
     for (; tile < n_tiles; tile += stride) {
         const uint64_t next = tile + stride;
-        if constexpr (!DEEP) {
+        if constexpr (!TWO) {
             if (next < n_tiles) { dma(next, par ^ 1); bnm_wait_vmcnt<8>(); } else { bnm_wait_vmcnt<0>(); }
         } else {
             if (next < n_tiles) bnm_wait_vmcnt<8>(); else bnm_wait_vmcnt<0>();
         }
         uint32_t v = *(const uint32_t *)(smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)par * FUSED_TILE_BYTES + 128u * lane);
-        if (DEEP && next + stride < n_tiles) dma(next + stride, par);
+        if (TWO && next + stride < n_tiles) dma(next + stride, par);
         if (lane < 32) out[(tile << 5) + lane] = v;
         par ^= 1;
     }
@@ -1564,14 +1242,10 @@ hipError_t bnmk_diag_stream(const int8_t *images, uint64_t n, int mode, int grid
     if (mode == 0) {
         unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 8u;
         diag_stream_plain_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const u32x4 *)images, n * 16ull, out);
-    } else if (mode == 1 || mode == 3) {
-        unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 2u;
-        if (mode == 1) diag_stream_tiles_kernel<4, false><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
-        else diag_stream_tiles_kernel<4, true><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
     } else {
-        unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus;
-        if (mode == 2) diag_stream_tiles_kernel<8, false><<<dim3(blocks), dim3(512), 0, s>>>(images, n, out);
-        else diag_stream_tiles_kernel<8, true><<<dim3(blocks), dim3(512), 0, s>>>(images, n, out);
+        unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 2u;
+        if (mode == 1) diag_stream_tiles_kernel<false><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
+        else diag_stream_tiles_kernel<true><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
     }
     return hipGetLastError();
 }

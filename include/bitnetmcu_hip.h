@@ -132,8 +132,8 @@ BNM_API int bnm_ctx_device(const bnm_ctx *c);
 #define BNM_PATH_TERNARY_ALU 3     /* fused sign-accumulate kernel, no MFMA (ternary models) */
 BNM_API int bnm_ctx_set_path(bnm_ctx *c, int path);
 BNM_API int bnm_ctx_get_path(const bnm_ctx *c);   /* the path AUTO resolved to */
-/* Tuning knobs of the fused kernel: variant id and grid size
- * (workgroups; 0 = default). */
+/* Tuning knobs of the fused kernel: variant id (0 direct loads, 1 LDS-DMA, 2 LDS-DMA with two tiles in flight;
+ * -1 keeps the current one) and grid size (workgroups; 0 = default). */
 BNM_API int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks);
 
 /* Whole-model batched inference, DEVICE pointers, asynchronous on `stream` (a hipStream_t;
@@ -180,7 +180,7 @@ BNM_API int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint6
                                     uint64_t *d_out, uint32_t n_bins, void *stream);
 
 /* Diagnostics: read the image stream without the model math.  mode 0: plain 16 B/lane loads; mode 1/2: the fused
- * kernel's own LDS-DMA tile loop (4- / 8-wave workgroups).  d_out: uint32 [n].  Puts the practical read ceiling of
+ * kernel's own LDS-DMA tile loop (one tile ahead / two tiles in flight).  d_out: uint32 [n].  Puts the practical read ceiling of
  * this access pattern next to the real kernel (profiles/stream_ceiling.py). */
 BNM_API int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out,
                                    void *stream);

@@ -19,7 +19,7 @@ b.synth.fill_device(imgs)
 out = torch.zeros(n, dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 res = {}
-for mode, grids in ((0, (0, 8192)), (1, (0,)), (2, (0,)), (3, (0, 768, 1024)), (4, (0, 384, 512))):
+for mode, grids in ((0, (0, 8192)), (1, (0, 1024)), (2, (0, 1024))):
     for g in grids:
         for _ in range(3):
             L.check(lib, lib.bnm_diag_stream_device(imgs.data_ptr(), n, mode, g, out.data_ptr(), s))

@@ -26,14 +26,14 @@ def test_full_size_properties(gpu_ok, orc):
     synth.fill_device(imgs, first=0, dist=DIST_U)
     cls = torch.empty(n, dtype=torch.int32, device="cuda")
     digests = {}
-    for variant in (9, 8, 7, 6, 5, 4, 3, 2, 1, 0):
+    for variant in (2, 1, 0):
         ctx.set_tuning(variant=variant)
         cls.fill_(-1)
         ctx.infer_device(imgs, cls)
         d = synth.digest_device(cls, first=0, n_bins=10).cpu().numpy()
         assert int(d[1:].sum()) == n, "histogram does not sum to N"
         digests[variant] = d
-    for v in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+    for v in (1, 2):
         assert np.array_equal(digests[0], digests[v]), f"kernel variant {v} disagrees with the direct-load kernel"
     # sharded run: two ranks' worth of work, digests combined as the all-reduce would
     h = n // 2 + 17

@@ -19,7 +19,7 @@ def paths_for(ctx):
     """(label, setup) for every kernel path this model can run."""
     out = [("auto", lambda c: c.set_path(b.PATH_AUTO))]
     out.append(("layerwise", lambda c: c.set_path(b.PATH_LAYERWISE_ALU)))
-    for v in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
+    for v in (0, 1, 2):
         def fused(c, v=v):
             c.set_path(b.PATH_FUSED_MFMA)
             c.set_tuning(variant=v)
@@ -164,7 +164,7 @@ def test_device_pointer_api_does_not_touch_neighbours(gpu_ok, orc):
     import torch
     model = util.load_golden_model("fc_4bitsym_64")
     ctx = b.Context(model)
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
+    for variant in (0, 1, 2):
         ctx.set_tuning(variant=variant)
         for n in (1, 33, 1000, 70000):
             imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
