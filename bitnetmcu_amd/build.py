@@ -36,10 +36,11 @@ def newer(src_list, out):
 
 def objects(force=False):
     os.makedirs(OBJ, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in ("bnm_kernels.h", "bnm_model.hpp")] + \
+    hdrs = [os.path.join(CSRC, h) for h in ("bnm_kernels.h", "bnm_model.hpp", "bnm_device.hpp")] + \
            [os.path.join(HERE, "..", "include", "bitnetmcu_hip.h")]
-    out = []
-    for src, is_hip in (("bnm_kernels.hip", True), ("bnm_capi.cpp", False), ("bnm_model.cpp", False)):
+    out, jobs = [], []
+    for src, is_hip in (("bnm_fused_fc.hip", True), ("bnm_cnn.hip", True), ("bnm_ternary.hip", True), ("bnm_layerwise.hip", True),
+                        ("bnm_support.hip", True), ("bnm_capi.cpp", False), ("bnm_model.cpp", False)):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or newer([s] + hdrs, o):
@@ -47,8 +48,12 @@ def objects(force=False):
             if not is_hip:
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")
-            run(cmd)
+            jobs.append(cmd)
         out.append(o)
+    if jobs:   # translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
     return out
 
 

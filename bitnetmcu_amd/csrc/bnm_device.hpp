@@ -1,0 +1,90 @@
+// Shared device-side definitions for the gfx950 kernels (wave64, MFMA i8 32x32x32, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstdint>
+#include <type_traits>
+#include "bnm_kernels.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define BNM_DEVICE __device__ __forceinline__
+// compile-time counted loop: the body receives std::integral_constant<int, I>, so every array index derived
+// from I is a constant and the arrays stay in registers
+template <int B, int E, class F>
+BNM_DEVICE void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+
+BNM_DEVICE uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// number of compute units of the current device (cached); grids are sized as multiples of it
+inline int bnm_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// =================================================================================================
+// Weight codecs (exportquant.py:104-187 packs, BitNetMCU_inference.c:96-201 unpacks).
+// decode_weight() is the single device-side statement of all codecs; both the unpack kernel and the
+// bit-serial layer kernel go through it.
+// =================================================================================================
+BNM_DEVICE int codec_field_bits(int bpw) {
+    return bpw == 1 ? 1 : bpw == 2 ? 2 : (bpw == 4 || bpw == 12 || bpw == 20) ? 4 : bpw == 16 ? 8 : 0;
+}
+
+// field f (fb bits, already right-aligned) -> integer weight
+BNM_DEVICE int decode_field(int bpw, uint32_t f) {
+    switch (bpw) {
+        case 1: return f ? 1 : -1;                                          // :96-104
+        case 2: return ((f & 2u) ? -1 : 1) * (int)(1u + 2u * (f & 1u));     // :105-115
+        case 4: return ((f & 8u) ? -1 : 1) * (int)(2u * (f & 7u) + 1u);     // :156-168
+        case 12: return (int)(f ^ 8u) - 8;                                  // :169-178
+        case 16: return (int)(int8_t)f;                                     // :179-188
+        case 20: return ((f & 8u) ? -1 : 1) * (int)(1u << (f & 7u));        // :190-201
+    }
+    return 0;
+}
+
+// trit t (0..9) of a 16-bit ternary chunk (:116-136): multiply-by-3 pops digits MSB first
+BNM_DEVICE int ternary_trit(uint32_t chunk, uint32_t t) {
+    uint32_t digit = 0;
+    for (uint32_t i = 0; i <= t; i++) {
+        chunk *= 3u;
+        digit = chunk >> 16;
+        chunk &= 0xFFFFu;
+    }
+    return digit == 0 ? 1 : (digit == 1 ? -1 : 0);
+}
+
+BNM_DEVICE int decode_weight(const void *packed, int bpw, uint32_t n_input, uint32_t row, uint32_t k) {
+    if (bpw == 64) {
+        uint32_t chunk = ((const uint16_t *)packed)[row * (n_input / 10u) + k / 10u];
+        return ternary_trit(chunk, k % 10u);
+    }
+    int fb = codec_field_bits(bpw);
+    if (!fb) return 0;
+    uint32_t per_word = 32u / (uint32_t)fb;
+    uint32_t words_per_row = (n_input + per_word - 1u) / per_word;
+    uint32_t word = ((const uint32_t *)packed)[row * words_per_row + k / per_word];
+    uint32_t f = (word >> (32u - (uint32_t)fb * (k % per_word + 1u))) & ((1u << fb) - 1u);
+    return decode_field(bpw, f);
+}
+

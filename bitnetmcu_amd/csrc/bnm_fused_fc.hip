@@ -1,0 +1,541 @@
+// Fused whole-model FC kernel (int8 MFMA) + the stream-only diagnostics that share its tile loop.
+// gfx950 (CDNA4 / MI355X) only; see DESIGN.md for layouts and rooflines.  Reference semantics:
+// BitNetMCU_inference.c:23-72 (ReLUNorm), :88-208 (processfclayer), :238-277 (conv), :300-322 (pool);
+// schedule BitNetMCU_MNIST_dll.c:48-121.
+#include "bnm_device.hpp"
+
+// =================================================================================================
+// Fused whole-model FC kernel.
+//
+// Formulation (per wave, per tile of 32 images):  Y^T[neurons x images] = W[neurons x K] * X^T[K x images]
+// on v_mfma_i32_32x32x32_i8.  A = weight fragments (unpacked once per model, held in VGPRs for the whole
+// persistent loop), B = activations: B-lane (j = lane&31, h = lane>>5) holds 16 K-bytes of image j.  The D
+// layout gives lane (j,h) rows (r&3)+8(r>>2)+4h of image j, i.e. every lane owns half of its OWN image's
+// outputs, so ReLUNorm's max is a per-lane reduction plus one v_permlane32_swap, and the normalised int8
+// bytes packed 4 regs -> 1 dword are directly the next layer's B operand (the next layer's A fragments
+// were built with the matching K permutation, kmap 1).  No LDS or cross-lane traffic between layers.
+//
+// Image tile load, variant 1: 8 x global_load_lds_dwordx4 (1 KiB contiguous each) into a per-wave
+// double-buffered LDS tile, XOR-swizzled on the SOURCE side so that the ds_read_b128 B-operand reads are
+// bank-conflict free; the next tile's DMA is issued before the current tile's math and retired with a
+// counted s_waitcnt vmcnt(8).  Variant 0: direct global->VGPR loads in operand layout (any row length).
+// =================================================================================================
+template <int MT, int KS>
+struct AFrags {
+    i32x4 a[MT][KS];
+    BNM_DEVICE void load(const i32x4 *base, int lane) {
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int s = 0; s < KS; s++) a[m][s] = base[(m * KS + s) * 64 + lane];
+    }
+};
+
+BNM_DEVICE i32x16 zero16() {
+    i32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0;
+    return z;
+}
+
+template <int MT, int KT, bool SPLIT>
+BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 (&b)[KT], i32x16 (&acc)[MT]) {
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = zero16();
+#pragma unroll
+    for (int s = 0; s < KT; s++)
+#pragma unroll
+        for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A.a[m][s], b[s], acc[m], 0, 0, 0);
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int s = 0; s < KT; s++)
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+                acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A.a[m][KT + s], b[s], acc[m], 0, 0, 0);
+    }
+}
+
+// value of the partner lane (lane ^ 32)
+BNM_DEVICE int partner32(int x, int h) {
+    auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return h ? r[0] : r[1];
+}
+
+// clamp to [0, hi] in ONE instruction.  hipcc only forms v_med3_i32 from min(max(x, lo), hi) when it can prove
+// lo <= hi (constants); with a run-time hi it emits v_max + v_min.
+BNM_DEVICE int clamp0_med3(int x, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
+    return r;
+}
+
+// 16 clamped values -> 4 dwords, byte b of dword q = c[4q+b] >> s.  One SDWA shift per value writes its result
+// byte straight into place (dst_sel:BYTE_b, dst_unused:UNUSED_PRESERVE), so no separate pack instructions.
+// Same-register writes are 4 instructions apart and a trailing s_nop covers the dst_sel forwarding hazard that
+// hipcc cannot see inside an asm statement.
+BNM_DEVICE i32x4 sdwa_shift_pack16(const int (&c)[16], int s) {
+    int d0, d1, d2, d3;
+#define SD(dst, src, sel, unused) \
+    "v_lshrrev_b32_sdwa " dst ", %4, " src " dst_sel:" sel " dst_unused:" unused " src0_sel:DWORD src1_sel:DWORD\n\t"
+    asm(SD("%0", "%5", "BYTE_0", "UNUSED_PAD") SD("%1", "%9", "BYTE_0", "UNUSED_PAD")
+        SD("%2", "%13", "BYTE_0", "UNUSED_PAD") SD("%3", "%17", "BYTE_0", "UNUSED_PAD")
+        SD("%0", "%6", "BYTE_1", "UNUSED_PRESERVE") SD("%1", "%10", "BYTE_1", "UNUSED_PRESERVE")
+        SD("%2", "%14", "BYTE_1", "UNUSED_PRESERVE") SD("%3", "%18", "BYTE_1", "UNUSED_PRESERVE")
+        SD("%0", "%7", "BYTE_2", "UNUSED_PRESERVE") SD("%1", "%11", "BYTE_2", "UNUSED_PRESERVE")
+        SD("%2", "%15", "BYTE_2", "UNUSED_PRESERVE") SD("%3", "%19", "BYTE_2", "UNUSED_PRESERVE")
+        SD("%0", "%8", "BYTE_3", "UNUSED_PRESERVE") SD("%1", "%12", "BYTE_3", "UNUSED_PRESERVE")
+        SD("%2", "%16", "BYTE_3", "UNUSED_PRESERVE") SD("%3", "%20", "BYTE_3", "UNUSED_PRESERVE")
+        "s_nop 0"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+        : "v"(s), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]),
+          "v"(c[9]), "v"(c[10]), "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
+#undef SD
+    i32x4 r = {d0, d1, d2, d3};
+    return r;
+}
+
+// ReLUNorm (BitNetMCU_inference.c:23-72) on MT x 16 accumulator values per lane (+ the partner lane's),
+// result packed as the next layer's B operand: packed[m][q] byte b = row 32m + 8q + 4h + b.
+// Rows >= n_output are zero weights => value 0: they can only raise a negative maximum to 0, in which case
+// every output is 0 either way.
+//
+// DBL = false: accumulators hold the layer sums x.   out = clamp((x + r) >> s, 0, 127), 4 VALU per value.
+// DBL = true : this layer's weight fragments were built DOUBLED, accumulators hold 2x (exact).  With
+//   s = bitlength(max(2x) >> 8) (= the reference's shift, from max(x) >> 7) and y = clamp(2x, 0, 255*2^s - 1) >> s
+//   (0..254, one v_med3 + one SDWA shift that also packs), the rounded result is
+//   (x + 2^(s-1)) >> s = (2x + 2^s) >> (s+1) = (y + 1) >> 1, which v_lerp_u8 computes for 4 bytes at once;
+//   y <= 254 makes the "clip 128 to 127" case (:62-66) fall out.  2.25 VALU per value, bit-exact.
+template <int MT, bool DBL>
+BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int h) {
+    int mx = acc[0][0];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = max(mx, acc[m][r]);
+    mx = max(mx, partner32(mx, h));
+    mx = max(mx, 0);
+    if constexpr (DBL) {
+        uint32_t t = (uint32_t)mx >> 8;
+        int sh = t ? 32 - __builtin_clz(t) : 0;
+        int hi = (255 << sh) - 1;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            int c[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) c[r] = clamp0_med3(acc[m][r], hi);
+            i32x4 y = sdwa_shift_pack16(c, sh);
+#pragma unroll
+            for (int q = 0; q < 4; q++) packed[m][q] = (int)__builtin_amdgcn_lerp((uint32_t)y[q], 0u, 0x01010101u);
+        }
+    } else {
+        uint32_t t = (uint32_t)mx >> 7;
+        int sh = t ? 32 - __builtin_clz(t) : 0;
+        int rnd = (1 << sh) >> 1;
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t d = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    int v = (acc[m][4 * q + b] + rnd) >> sh;
+                    v = min(max(v, 0), 127);
+                    d |= (uint32_t)v << (8 * b);
+                }
+                packed[m][q] = (int)d;
+            }
+    }
+}
+
+// first strict maximum over rows < n_classes (ReLUNorm's return value, :25-37).  key = value*256 + (255 - row):
+// the largest key is the largest value and, among equals, the smallest row.  |value| < 2^23 for every layer that
+// can be last (K <= 128, |act| <= 127, |w| <= 128).  Registers whose rows are all >= n_classes are skipped by
+// wave-uniform branches.
+template <int MT>
+BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h, uint32_t n_classes) {
+    int best = INT_MIN;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t rowbase = 32u * m + (r & 3) + 8u * (r >> 2);   // row of the h = 0 half; h = 1: +4
+            if (rowbase < n_classes) {
+                int key = (int)(((uint32_t)acc[m][r] << 8) + (255u - rowbase));
+                if (rowbase + 4u >= n_classes) key = h ? INT_MIN : key;
+                best = max(best, key);
+            }
+        }
+    best = best == INT_MIN ? INT_MIN : best - 4 * h;
+    best = max(best, partner32(best, h));
+    return 255u - ((uint32_t)best & 255u);
+}
+
+template <int MT>
+BNM_DEVICE void store_logits(const i32x16 (&acc)[MT], int32_t *dst, int h, uint32_t n_classes) {
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            uint32_t row = 32u * m + (r & 3) + 8u * (r >> 2) + 4u * h;
+            if (row < n_classes) dst[row] = acc[m][r];
+        }
+}
+
+// 8 x 1 KiB LDS-DMA pieces of one 32-image tile.  p[t] wave-uniform base pointers, v[t] per-lane byte
+// offsets, lds wave-uniform LDS byte address of the tile buffer.  The DMA destination is
+// M0 + lane*16 (lane-linear); the swizzle lives in v[].  hipcc neither counts these loads nor waits for
+// them: the caller retires them with bnm_wait_vmcnt<N>().
+// NT: non-temporal policy (the image stream is read exactly once).  WAITLDS: first retire this wave's own
+// outstanding ds_reads (s_waitcnt lgkmcnt(0)) — needed when the destination buffer was being read just before.
+#define BNM_DMA8(NTS, PRE)                                                                                           \
+    asm volatile(PRE "s_nop 4\n\t"                                                                                    \
+                 "s_mov_b32 %0, m0\n\t"                                                                                \
+                 "s_mov_b32 m0, %1\n\t"                                                                                \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %10, %2" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %11, %3" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %12, %4" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %13, %5" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %14, %6" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %15, %7" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %16, %8" NTS "\n\t"                                                          \
+                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
+                 "s_nop 0\n\t"                                                                                         \
+                 "global_load_lds_dwordx4 %17, %9" NTS "\n\t"                                                          \
+                 "s_mov_b32 m0, %0"                                                                                    \
+                 : "=&s"(keep)                                                                                         \
+                 : "s"(lds), "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(p6), "s"(p7), "v"(v0), "v"(v1), \
+                   "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7)                                                \
+                 : "memory", "scc")
+
+template <bool NT = false, bool WAITLDS = false>
+BNM_DEVICE void lds_dma_tile8(uint32_t lds, const int8_t *p0, const int8_t *p1, const int8_t *p2, const int8_t *p3,
+                              const int8_t *p4, const int8_t *p5, const int8_t *p6, const int8_t *p7, uint32_t v0,
+                              uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t v5, uint32_t v6,
+                              uint32_t v7) {
+    uint32_t keep;
+    if constexpr (NT && WAITLDS) BNM_DMA8(" nt", "s_waitcnt lgkmcnt(0)\n\t");
+    else if constexpr (NT) BNM_DMA8(" nt", "");
+    else if constexpr (WAITLDS) BNM_DMA8("", "s_waitcnt lgkmcnt(0)\n\t");
+    else BNM_DMA8("", "");
+}
+
+template <int N>
+BNM_DEVICE void bnm_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int FUSED_TILE_BYTES = 8192;    // 32 images x 256 B
+constexpr int FUSED_WPB = 4;              // waves per workgroup; two workgroups per CU (LDS 64 KiB each)
+
+// Kernel variants = how the image tile reaches the B operands:
+//   0  DIRECT     global -> VGPR loads in operand layout (any row length; CNN tails with 64/128/192-byte rows)
+//   1  LDSDMA     8 x 1 KiB LDS-DMA pieces into a per-wave double buffer, next tile issued at the top of the iteration
+//   2  LDSDMA2    as 1 with TWO tiles in flight per wave (default where available): the refill of the buffer a tile
+//                 just vacated (tile k+2) is issued right AFTER tile k's layer-1 MFMAs, non-temporal.  With one tile
+//                 in flight the kernel is bound by per-wave memory-level parallelism (8 KiB / latency x 2048 waves);
+//                 issuing the second DMA in front of the MFMAs instead serialises the wave (profiles/r01).
+// Tried and dropped in round 1 (tag r01-experiments-all-variants): 8-wave workgroups with staggered halves, a
+// software-pipelined MFMA||VALU form, three waves per SIMD with weights in LDS, split half-tile refills.
+enum { FUSED_DIRECT = 0, FUSED_LDSDMA = 1, FUSED_LDSDMA2 = 2 };
+
+template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT>
+__global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
+                                                                     const i32x4 *__restrict__ frags, uint32_t n_classes,
+                                                                     uint32_t *__restrict__ cls_out,
+                                                                     int32_t *__restrict__ logits_out, uint64_t src_wrap) {
+    constexpr int SP = SPLIT ? 2 : 1;
+    constexpr int ROW = 32 * KT0;
+    constexpr bool LDSDMA = VARIANT != FUSED_DIRECT;
+    constexpr bool TWO = VARIANT == FUSED_LDSDMA2;
+    static_assert(!LDSDMA || KT0 == 8, "the LDS-DMA tile layout is for 256-byte rows");
+    static_assert(!(SPLIT && DBL), "FP1.3.0 weights cannot be doubled in int8");
+    __shared__ __attribute__((aligned(1024))) char smem[LDSDMA ? FUSED_WPB * 2 * FUSED_TILE_BYTES : 16];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    // weights: unpacked fragments -> registers, once
+    AFrags<M1, KT0 * SP> A1;
+    AFrags<M2, M1 * SP> A2;
+    AFrags<M3, M2 * SP> A3;
+    AFrags<(M4 > 0 ? M4 : 1), M3 * SP> A4;
+    const i32x4 *fp = frags;
+    A1.load(fp, lane);  fp += M1 * KT0 * SP * 64;
+    A2.load(fp, lane);  fp += M2 * M1 * SP * 64;
+    A3.load(fp, lane);  fp += M3 * M2 * SP * 64;
+    if constexpr (M4 > 0) A4.load(fp, lane);
+
+    const uint64_t n_tiles = (n + 31ull) >> 5;
+    const uint64_t stride = (uint64_t)gridDim.x * FUSED_WPB;
+    uint64_t tile = (uint64_t)blockIdx.x * FUSED_WPB + wave;
+
+    // ---- LDS-DMA addressing ------------------------------------------------------------------------
+    // LDS tile image: row r (image) at r*256, 16-byte slot c' holds global slot c = c' ^ (r & 15).
+    // DMA piece t covers rows 4t..4t+3: lane l -> row 4t + (l>>4), slot l&15.
+    uint32_t voff[4];
+    uint32_t lds_wave = 0, rd_base = 0;
+    if constexpr (LDSDMA) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
+        lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
+        // B-operand read of K-step s: row j, global slot 2s+h -> LDS slot (2s+h) ^ (j&15) = (2s) ^ (h ^ (j&15))
+        rd_base = (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
+    }
+
+    auto dma_tile = [&](uint64_t t, int par) {
+        // src_wrap != 0 (diagnostics only, BNM_DIAG_SRC_WRAP): read tile (t mod src_wrap) instead, so the source stays
+        // cache-resident and the kernel's compute-side time can be measured without HBM in the way
+        const int8_t *base = images + (src_wrap ? t % src_wrap : t) * (uint64_t)FUSED_TILE_BYTES;
+        uint32_t lds = lds_wave + (uint32_t)par * FUSED_TILE_BYTES;
+        uint64_t first = t << 5;
+        if (first + 32ull <= n) {
+            lds_dma_tile8<TWO, TWO>(lds, base, base + 1024, base + 2048, base + 3072, base + 4096, base + 5120, base + 6144,
+                                    base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0], voff[1], voff[2], voff[3]);
+        } else {
+            // ragged last tile: rows past the end re-read the last valid image (never out of bounds)
+            uint32_t nv = (uint32_t)(n - first);
+            uint32_t v[8];
+#pragma unroll
+            for (int tt = 0; tt < 8; tt++) {
+                uint32_t r = 4u * tt + (uint32_t)(lane >> 4);
+                uint32_t src = r < nv ? r : nv - 1u;
+                v[tt] = src * 256u + 16u * ((uint32_t)(lane & 15) ^ (r & 15u));
+            }
+            lds_dma_tile8<TWO, TWO>(lds, base, base, base, base, base, base, base, base, v[0], v[1], v[2], v[3], v[4], v[5],
+                                    v[6], v[7]);
+        }
+    };
+
+    int par = 0;
+    i32x4 bnext[KT0];
+    auto direct_load = [&](uint64_t t, i32x4(&dst)[KT0]) {
+        uint64_t img = (t << 5) + (uint64_t)j;
+        if (img >= n) img = n - 1ull;
+        const int8_t *p = images + img * (uint64_t)ROW + 16 * h;
+#pragma unroll
+        for (int s = 0; s < KT0; s++) dst[s] = __builtin_nontemporal_load((const i32x4 *)(p + 32 * s));
+    };
+
+    if (tile < n_tiles) {
+        if constexpr (LDSDMA) dma_tile(tile, 0);
+        else direct_load(tile, bnext);
+    }
+    if constexpr (TWO) {
+        if (tile + stride < n_tiles) dma_tile(tile + stride, 1);
+    }
+
+    for (; tile < n_tiles; tile += stride) {
+        const uint64_t next = tile + stride;
+        i32x4 b0[KT0];
+        i32x16 acc1[M1];
+        if constexpr (LDSDMA) {
+            if constexpr (!TWO) {
+                if (next < n_tiles) {
+                    dma_tile(next, par ^ 1);
+                    bnm_wait_vmcnt<8>();
+                } else {
+                    bnm_wait_vmcnt<0>();
+                }
+            } else {
+                // in flight: this tile (8 pieces) and, if it exists, the next one (8 pieces, issued an iteration ago)
+                if (next < n_tiles) bnm_wait_vmcnt<8>();
+                else bnm_wait_vmcnt<0>();
+            }
+            // rd_base carries the slot field (h ^ (j&15)) << 4 in bits 4..7 and nothing else below bit 8, so
+            // XOR-ing 32*s (bits 5..7) selects slot (2s+h) ^ (j&15): one v_xor per K-step.
+#pragma unroll
+            for (int s = 0; s < KT0; s++)
+                b0[s] = *(const i32x4 *)(smem + ((rd_base ^ (32u * s)) + (uint32_t)par * FUSED_TILE_BYTES));
+            if constexpr (!TWO) par ^= 1;
+        } else {
+#pragma unroll
+            for (int s = 0; s < KT0; s++) b0[s] = bnext[s];
+            if (next < n_tiles) direct_load(next, bnext);
+        }
+
+        layer_mma<M1, KT0, SPLIT>(A1, b0, acc1);
+        if constexpr (TWO) {
+            // all 8 B fragments of this tile's buffer have been consumed (the DMA statement first retires the wave's
+            // own ds_reads): refill it with the tile after next
+            if (next + stride < n_tiles) dma_tile(next + stride, par);
+            par ^= 1;
+        }
+        i32x4 p1[M1];
+        relunorm_pack<M1, DBL>(acc1, p1, h);
+
+        i32x16 acc2[M2];
+        layer_mma<M2, M1, SPLIT>(A2, p1, acc2);
+        i32x4 p2[M2];
+        relunorm_pack<M2, DBL>(acc2, p2, h);
+
+        i32x16 acc3[M3];
+        layer_mma<M3, M2, SPLIT>(A3, p2, acc3);
+
+        const uint64_t img = (tile << 5) + (uint64_t)j;
+        uint32_t cls;
+        if constexpr (M4 > 0) {
+            i32x4 p3[M3];
+            relunorm_pack<M3, DBL>(acc3, p3, h);
+            i32x16 acc4[M4];
+            layer_mma<M4, M3, SPLIT>(A4, p3, acc4);
+            cls = argmax_rows<M4>(acc4, h, n_classes);
+            if (logits_out && img < n) store_logits<M4>(acc4, logits_out + img * n_classes, h, n_classes);
+        } else {
+            cls = argmax_rows<M3>(acc3, h, n_classes);
+            if (logits_out && img < n) store_logits<M3>(acc3, logits_out + img * n_classes, h, n_classes);
+        }
+        if (h == 0 && img < n) cls_out[img] = cls;
+    }
+}
+
+// ---- dispatch table: model shapes of the reference zoo (+ ternary) -----------------------------
+namespace {
+typedef void (*fused_fn)(const int8_t *, uint64_t, const i32x4 *, uint32_t, uint32_t *, int32_t *, uint64_t);
+struct FusedEntry {
+    BnmFusedShape sh;
+    int variant;
+    fused_fn fn;
+};
+#define FUSED(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR) \
+    { {KT0, {M1, M2, M3, M4}, SPLIT, DBL}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, DBL, VAR> }
+const FusedEntry kFused[] = {
+    // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
+    FUSED(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA2),
+    FUSED(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA),
+    FUSED(8, 2, 2, 2, 1, false, true, FUSED_DIRECT),
+    // same shape with codecs whose weights cannot be doubled in int8 (8-bit two's complement)
+    FUSED(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA),
+    FUSED(8, 2, 2, 2, 1, false, false, FUSED_DIRECT),
+    // same shape, FP1.3.0 weights (mcu/BitNetMCU_model_12k_FP130.h): +128 split over two A passes
+    FUSED(8, 2, 2, 2, 1, true, false, FUSED_LDSDMA),
+    FUSED(8, 2, 2, 2, 1, true, false, FUSED_DIRECT),
+    // FC 256-16-16-10 2bitsym (mcu/BitNetMCU_model_1k.h)
+    FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA2),
+    FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA),
+    FUSED(8, 1, 1, 1, 0, false, true, FUSED_DIRECT),
+    // ternary FC 256-96-96-96-10 through the MFMA path (optional; config 3's product path is the ALU kernel)
+    FUSED(8, 3, 3, 3, 1, false, true, FUSED_LDSDMA),
+    FUSED(8, 3, 3, 3, 1, false, true, FUSED_DIRECT),
+    // CNN FC tails: 4C-96-64-10 (cnn_64/48/32/16), 64-64-48-10 (cnn_16small), 256-96-64-37 (letters)
+    FUSED(8, 3, 2, 1, 0, false, true, FUSED_LDSDMA),
+    FUSED(8, 3, 2, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(6, 3, 2, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(4, 3, 2, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(2, 3, 2, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(2, 2, 2, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(8, 3, 2, 2, 0, false, true, FUSED_LDSDMA),
+    FUSED(8, 3, 2, 2, 0, false, true, FUSED_DIRECT),
+};
+const FusedEntry *find_fused(const BnmFusedShape &sh, int variant) {
+    for (const FusedEntry &e : kFused)
+        if (e.sh == sh && e.variant == variant) return &e;
+    return nullptr;
+}
+}  // namespace
+
+bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fused(sh, variant) != nullptr; }
+// measured best first (profiles/r01)
+int bnmk_fused_default_variant(const BnmFusedShape &sh) {
+    return find_fused(sh, FUSED_LDSDMA2) ? FUSED_LDSDMA2 : find_fused(sh, FUSED_LDSDMA) ? FUSED_LDSDMA : FUSED_DIRECT;
+}
+
+hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a, hipStream_t s) {
+    const FusedEntry *e = find_fused(sh, variant);
+    if (!e) return hipErrorInvalidValue;
+    if (a.n == 0) return hipSuccess;
+    uint64_t n_tiles = (a.n + 31ull) / 32ull;
+    uint64_t want = (n_tiles + FUSED_WPB - 1) / FUSED_WPB;
+    // persistent grid: 8 resident waves per CU (2 workgroups x 4 waves; VGPRs and LDS allow no more)
+    uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * 2ull;
+    unsigned blocks = (unsigned)(want < cap ? want : cap);
+    e->fn<<<dim3(blocks), dim3(64 * FUSED_WPB), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap);
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// Diagnostics: what the image stream alone costs.  mode 0: plain 16 B/lane global loads, grid-stride;
+// mode 1 / 2: the fused kernel's own tile loop (variant LDSDMA / LDSDMA2) with the math replaced by one ds_read
+// per tile.  Both write one dword per 32 images so the result cannot be optimised away.  Used by
+// profiles/stream_ceiling.py to put the achieved GB/s of the real kernel next to the practical read ceiling.
+// =================================================================================================
+__global__ __launch_bounds__(256) void diag_stream_plain_kernel(const u32x4 *__restrict__ src, uint64_t n16,
+                                                                uint32_t *__restrict__ out) {
+    uint32_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        acc ^= a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3] ^ c[0] ^ c[1] ^ c[2] ^ c[3] ^ d[0] ^ d[1] ^ d[2] ^ d[3];
+    }
+    for (; i < n16; i += stride) {
+        u32x4 a = __builtin_nontemporal_load(src + i);
+        acc ^= a[0] ^ a[1] ^ a[2] ^ a[3];
+    }
+    if (acc == 0x12345678u) out[0] = acc;   // practically never: keeps the loads alive without a store stream
+}
+
+template <bool TWO>
+__global__ __launch_bounds__(64 * FUSED_WPB, 2) void diag_stream_tiles_kernel(const int8_t *__restrict__ images, uint64_t n,
+                                                                              uint32_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(1024))) char smem[FUSED_WPB * 2 * FUSED_TILE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t voff[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
+    const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
+    const uint64_t n_tiles = n >> 5;   // whole tiles only
+    const uint64_t stride = (uint64_t)gridDim.x * FUSED_WPB;
+    uint64_t tile = (uint64_t)blockIdx.x * FUSED_WPB + wave;
+    auto dma = [&](uint64_t t, int par) {
+        const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
+        lds_dma_tile8<TWO, TWO>(lds_wave + (uint32_t)par * FUSED_TILE_BYTES, base, base + 1024, base + 2048, base + 3072,
+                                base + 4096, base + 5120, base + 6144, base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0],
+                                voff[1], voff[2], voff[3]);
+    };
+    int par = 0;
+    if (tile < n_tiles) dma(tile, 0);
+    if (TWO && tile + stride < n_tiles) dma(tile + stride, 1);
+    for (; tile < n_tiles; tile += stride) {
+        const uint64_t next = tile + stride;
+        if constexpr (!TWO) {
+            if (next < n_tiles) { dma(next, par ^ 1); bnm_wait_vmcnt<8>(); } else { bnm_wait_vmcnt<0>(); }
+        } else {
+            if (next < n_tiles) bnm_wait_vmcnt<8>(); else bnm_wait_vmcnt<0>();
+        }
+        uint32_t v = *(const uint32_t *)(smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)par * FUSED_TILE_BYTES + 128u * lane);
+        if (TWO && next + stride < n_tiles) dma(next + stride, par);
+        if (lane < 32) out[(tile << 5) + lane] = v;
+        par ^= 1;
+    }
+}
+
+hipError_t bnmk_diag_stream(const int8_t *images, uint64_t n, int mode, int grid_blocks, uint32_t *out, hipStream_t s) {
+    if (!n) return hipSuccess;
+    int cus = bnm_num_cus();
+    if (mode == 0) {
+        unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 8u;
+        diag_stream_plain_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const u32x4 *)images, n * 16ull, out);
+    } else {
+        unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 2u;
+        if (mode == 1) diag_stream_tiles_kernel<false><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
+        else diag_stream_tiles_kernel<true><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
+    }
+    return hipGetLastError();
+}
+

@@ -1,4 +1,4 @@
-// Launch wrappers for the gfx950 kernels in bnm_kernels.hip.  Everything here takes DEVICE
+// Launch wrappers for the gfx950 kernels in bnm_*.hip.  Everything here takes DEVICE
 // pointers and a hipStream_t and is asynchronous.
 #pragma once
 #include <hip/hip_runtime.h>

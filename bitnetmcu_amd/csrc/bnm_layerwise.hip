@@ -1,0 +1,193 @@
+// Layer-wise ALU kernels behind the reference's per-function symbols (bit-serial unpack + wave-shuffle reduction).
+// gfx950 (CDNA4 / MI355X) only; see DESIGN.md for layouts and rooflines.  Reference semantics:
+// BitNetMCU_inference.c:23-72 (ReLUNorm), :88-208 (processfclayer), :238-277 (conv), :300-322 (pool);
+// schedule BitNetMCU_MNIST_dll.c:48-121.
+#include "bnm_device.hpp"
+
+// =================================================================================================
+// Layer-wise ALU kernels: the reference's own structure (one call per layer), north-star style:
+// a wavefront owns one output neuron, the packed weight row and the int8 activation vectors are staged
+// in LDS, every lane unpacks its own weight word(s) with shifts/masks, partial int32 dot products are
+// reduced with wave shuffles.  Used behind the processfclayer/ReLUNorm symbols, for codecs/shapes outside
+// the fused table, and as an independent cross-check of the MFMA path.
+// =================================================================================================
+constexpr int LW_IMGS = 8;      // images per workgroup pass
+constexpr int LW_MAXIN = 1024;  // activations per vector
+
+__global__ __launch_bounds__(256) void fc_layer_bitserial_kernel(const int8_t *__restrict__ act, uint32_t act_stride,
+                                                                 const void *__restrict__ packed, int bpw,
+                                                                 uint32_t n_input, uint32_t n_output,
+                                                                 int32_t *__restrict__ out, uint64_t batch) {
+    __shared__ __attribute__((aligned(16))) int8_t s_act[LW_IMGS][LW_MAXIN + 16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_w[4][LW_MAXIN / 4 + 4];   // 4 neuron rows, <= 1 KiB each
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t row = blockIdx.x * 4u + (uint32_t)wave;
+    const int fb = codec_field_bits(bpw);
+    const uint32_t per_word = fb ? 32u / (uint32_t)fb : 10u;
+    // elements of the packed row: 32-bit words, or 16-bit chunks for ternary
+    const uint32_t row_elems = bpw == 64 ? n_input / 10u : (fb ? (n_input + per_word - 1u) / per_word : 0u);
+    const bool known = bpw == 64 || fb != 0;
+
+    // stage this wave's packed weight row
+    if (row < n_output && known) {
+        if (bpw == 64) {
+            const uint16_t *src = (const uint16_t *)packed + (size_t)row * row_elems;
+            for (uint32_t i = lane; i < row_elems; i += 64) s_w[wave][i] = src[i];
+        } else {
+            const uint32_t *src = (const uint32_t *)packed + (size_t)row * row_elems;
+            for (uint32_t i = lane; i < row_elems; i += 64) s_w[wave][i] = src[i];
+        }
+    }
+
+    for (uint64_t base = (uint64_t)blockIdx.y * LW_IMGS; base < batch; base += (uint64_t)gridDim.y * LW_IMGS) {
+        __syncthreads();
+        // stage up to LW_IMGS activation vectors (only bytes < n_input that exist: ternary pads are never read)
+        const uint32_t nimg = (uint32_t)((batch - base) < LW_IMGS ? (batch - base) : LW_IMGS);
+        for (uint32_t i = threadIdx.x; i < nimg * act_stride; i += blockDim.x) {
+            uint32_t im = i / act_stride, k = i % act_stride;
+            if (k < LW_MAXIN) s_act[im][k] = act[(base + im) * act_stride + k];
+        }
+        __syncthreads();
+        if (row >= n_output) continue;
+        int32_t sum[LW_IMGS];
+#pragma unroll
+        for (int im = 0; im < LW_IMGS; im++) sum[im] = 0;
+        if (known) {
+            for (uint32_t e = lane; e < row_elems; e += 64) {
+                uint32_t word = s_w[wave][e];
+                for (uint32_t f = 0; f < per_word; f++) {
+                    uint32_t k = e * per_word + f;
+                    int w;
+                    if (bpw == 64) {
+                        word *= 3u;                       // BitNetMCU_inference.c:121-134
+                        uint32_t digit = word >> 16;
+                        word &= 0xFFFFu;
+                        w = digit == 0 ? 1 : (digit == 1 ? -1 : 0);
+                    } else {
+                        uint32_t field = (word >> (32u - (uint32_t)fb * (f + 1u))) & ((1u << fb) - 1u);
+                        w = decode_field(bpw, field);
+                    }
+                    if (w != 0 && k < act_stride) {
+#pragma unroll
+                        for (int im = 0; im < LW_IMGS; im++) sum[im] += w * (int)s_act[im][k];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int im = 0; im < LW_IMGS; im++) {
+            int v = sum[im];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && (uint32_t)im < nimg) out[(base + im) * n_output + row] = v;
+        }
+    }
+}
+
+hipError_t bnmk_fc_layer(const int8_t *act, uint32_t act_stride, const void *packed, int32_t bpw, uint32_t n_input,
+                         uint32_t n_output, int32_t *out, uint64_t batch, hipStream_t s) {
+    if (!batch || !n_output) return hipSuccess;
+    if (n_input > LW_MAXIN + 15 || act_stride > LW_MAXIN) return hipErrorInvalidValue;
+    uint64_t gy = (batch + LW_IMGS - 1) / LW_IMGS;
+    if (gy > 8192) gy = 8192;
+    fc_layer_bitserial_kernel<<<dim3((n_output + 3u) / 4u, (unsigned)gy), dim3(256), 0, s>>>(act, act_stride, packed, bpw,
+                                                                                            n_input, n_output, out, batch);
+    return hipGetLastError();
+}
+
+// ReLUNorm, one wavefront per vector.  All inputs are read before any output is written, so `out` may
+// alias `in` exactly as BitNetMCU_MNIST_dll.c:80 uses it.
+__global__ __launch_bounds__(256) void relunorm_kernel(const int32_t *in, uint32_t n, int8_t *out, uint32_t out_stride,
+                                                       uint32_t *argmax, uint64_t batch) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    for (uint64_t v = wave0; v < batch; v += (uint64_t)gridDim.x * 4u) {
+        const int32_t *src = in + v * n;
+        int32_t x[LW_MAXIN / 64];
+        int bv = -INT_MAX;
+        uint32_t bi = 255;
+#pragma unroll
+        for (int t = 0; t < LW_MAXIN / 64; t++) {
+            uint32_t i = (uint32_t)lane + 64u * t;
+            x[t] = i < n ? src[i] : INT_MIN;
+            if (i < n && x[t] > bv) { bv = x[t]; bi = i; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            int pv = __shfl_xor(bv, off);
+            uint32_t pi = (uint32_t)__shfl_xor((int)bi, off);
+            if (pv > bv || (pv == bv && pi < bi)) { bv = pv; bi = pi; }
+        }
+        int mx = max(bv, 0);
+        uint32_t tt = (uint32_t)mx >> 7;
+        int sh = tt ? 32 - __builtin_clz(tt) : 0;
+        int rnd = (1 << sh) >> 1;
+        int8_t *dst = out + v * out_stride;
+#pragma unroll
+        for (int t = 0; t < LW_MAXIN / 64; t++) {
+            uint32_t i = (uint32_t)lane + 64u * t;
+            if (i < n) {
+                int q = x[t] < 0 ? 0 : min((x[t] + rnd) >> sh, 127);
+                dst[i] = (int8_t)q;
+            }
+        }
+        if (argmax && lane == 0) argmax[v] = bi;
+    }
+}
+
+hipError_t bnmk_relunorm(const int32_t *in, uint32_t n, int8_t *out, uint32_t out_stride, uint32_t *argmax,
+                         uint64_t batch, hipStream_t s) {
+    if (!batch || !n) return hipSuccess;
+    if (n > LW_MAXIN) return hipErrorInvalidValue;
+    uint64_t blocks = (batch + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    relunorm_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, n, out, out_stride, argmax, batch);
+    return hipGetLastError();
+}
+
+// Single-channel 3x3 conv + ReLU + shift, and 2x2 max pool (the symbol-level entry points).  One
+// workgroup; the whole input plane is read into LDS first so that output may alias input.
+__global__ __launch_bounds__(256) void conv33_kernel(const int32_t *in, const int8_t *w, uint32_t xy, uint32_t n_shift,
+                                                     int32_t *out) {
+    __shared__ int32_t plane[64 * 64];
+    for (uint32_t i = threadIdx.x; i < xy * xy; i += blockDim.x) plane[i] = in[i];
+    int wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) wk[t] = w[t];
+    __syncthreads();
+    uint32_t o = xy - 2u;
+    for (uint32_t i = threadIdx.x; i < o * o; i += blockDim.x) {
+        uint32_t y = i / o, x = i % o;
+        int s = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) s += wk[3 * dy + dx] * plane[(y + dy) * xy + x + dx];
+        out[i] = s < 0 ? 0 : (s >> n_shift);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool22_kernel(const int32_t *in, uint32_t xy, int32_t *out) {
+    __shared__ int32_t plane[64 * 64];
+    for (uint32_t i = threadIdx.x; i < xy * xy; i += blockDim.x) plane[i] = in[i];
+    __syncthreads();
+    uint32_t o = xy / 2u;
+    for (uint32_t i = threadIdx.x; i < o * o; i += blockDim.x) {
+        uint32_t y = i / o, x = i % o;
+        const int32_t *p = plane + 2u * y * xy + 2u * x;
+        out[i] = max(max(p[0], p[1]), max(p[xy], p[xy + 1]));
+    }
+}
+
+hipError_t bnmk_conv33(const int32_t *in, const int8_t *w, uint32_t xy, uint32_t n_shift, int32_t *out, hipStream_t s) {
+    if (xy < 3 || xy > 64) return hipErrorInvalidValue;
+    conv33_kernel<<<dim3(1), dim3(256), 0, s>>>(in, w, xy, n_shift, out);
+    return hipGetLastError();
+}
+hipError_t bnmk_maxpool22(const int32_t *in, uint32_t xy, int32_t *out, hipStream_t s) {
+    if (xy < 2 || xy > 64) return hipErrorInvalidValue;
+    maxpool22_kernel<<<dim3(1), dim3(256), 0, s>>>(in, xy, out);
+    return hipGetLastError();
+}
+

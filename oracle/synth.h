@@ -5,7 +5,7 @@
  * SURVEY.md §8(d).  The reference has no generator of its own (it reads MNIST through
  * torchvision, test_inference.py:82-91, which is not available offline), so this is the
  * workload definition shared by the CPU baseline and the GPU bench.  The HIP statement is
- * bnm_synth_fill_kernel in bitnetmcu_amd/csrc/bnm_kernels.hip; tests compare the two
+ * synth_fill_kernel in bitnetmcu_amd/csrc/bnm_support.hip; tests compare the two
  * byte-for-byte.
  *
  *   word  w of image i (w = 0..31, 8 bytes each):  x  = splitmix64(seed + 32*i + w)
