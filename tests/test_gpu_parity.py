@@ -130,7 +130,7 @@ def test_model_golden_all_paths(name, gpu_ok):
 def test_model_vs_oracle_synthetic(name, gpu_ok, orc):
     model = util.load_golden_model(name)
     om = util.OracleModel(model, orc)
-    n = 20000 if model.kind == b.KIND_FC else 1500
+    n = 150000 if model.kind == b.KIND_FC else 3000
     x = np.concatenate([synth.images(7_000_000, n, DIST_U), synth.images(3_000_000, n, DIST_M)])
     want_cls, want_lg = om.infer(x, logits=True)
     ctx = b.Context(model)
