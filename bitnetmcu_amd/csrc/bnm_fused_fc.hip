@@ -181,36 +181,6 @@ BNM_DEVICE void store_logits(const i32x16 (&acc)[MT], int32_t *dst, int h, uint3
         }
 }
 
-// Logits of one tile, coalesced: every lane parks its rows in a per-wave LDS scratch laid out as the output
-// ([32 images][n_classes] int32 = one contiguous 128*n_classes-byte block in global memory), then the wave streams
-// the block out 16 bytes per lane.  Replaces up to 16 scattered dword stores per lane (40-byte stride across lanes).
-// n_valid: images of this tile that exist (32 except on the ragged last tile).  Same wave writes and reads the
-// scratch, so an lgkmcnt wait (inserted by the compiler) is all the ordering that is needed.
-constexpr int FUSED_LOGIT_SCRATCH = 2048;   // bytes per wave: n_classes <= 16
-template <int MT>
-BNM_DEVICE void store_logits_coalesced(const i32x16 (&acc)[MT], int32_t *scratch, int32_t *__restrict__ dst_tile, int lane,
-                                       uint32_t n_classes, uint32_t n_valid) {
-    const int j = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const uint32_t rowbase = 32u * m + (r & 3) + 8u * (r >> 2);
-            if (rowbase < n_classes) {
-                const uint32_t row = rowbase + 4u * h;
-                if (row < n_classes) scratch[(uint32_t)j * n_classes + row] = acc[m][r];
-            }
-        }
-    const uint32_t total = n_valid * n_classes;          // dwords; the tile block starts 16-byte aligned
-    for (uint32_t i = 4u * lane; i < total; i += 256u) {
-        if (i + 4u <= total) {
-            *(i32x4 *)(dst_tile + i) = *(const i32x4 *)(scratch + i);
-        } else {
-            for (uint32_t k = i; k < total; k++) dst_tile[k] = scratch[k];
-        }
-    }
-}
-
 // 8 x 1 KiB LDS-DMA pieces of one 32-image tile.  p[t] wave-uniform base pointers, v[t] per-lane byte
 // offsets, lds wave-uniform LDS byte address of the tile buffer.  The DMA destination is
 // M0 + lane*16 (lane-linear); the swizzle lives in v[].  hipcc neither counts these loads nor waits for
@@ -292,7 +262,7 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
     constexpr bool TWO = VARIANT == FUSED_LDSDMA2;
     static_assert(!LDSDMA || KT0 == 8, "the LDS-DMA tile layout is for 256-byte rows");
     static_assert(!(SPLIT && DBL), "FP1.3.0 weights cannot be doubled in int8");
-    __shared__ __attribute__((aligned(1024))) char smem[LDSDMA ? FUSED_WPB * (2 * FUSED_TILE_BYTES + FUSED_LOGIT_SCRATCH) : 16];
+    __shared__ __attribute__((aligned(1024))) char smem[LDSDMA ? FUSED_WPB * 2 * FUSED_TILE_BYTES : 16];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -417,30 +387,16 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
 
         const uint64_t img = (tile << 5) + (uint64_t)j;
         uint32_t cls;
-        // logits: coalesced through the LDS scratch when it fits (LDS variants, n_classes <= 16, aligned output)
-        auto emit_logits = [&](auto &accL) {
-            constexpr int ML = sizeof(accL) / sizeof(accL[0]);
-            if constexpr (LDSDMA) {
-                if (n_classes * 128u <= (uint32_t)FUSED_LOGIT_SCRATCH && (((uintptr_t)logits_out) & 15u) == 0) {
-                    int32_t *scr = (int32_t *)(smem + FUSED_WPB * 2 * FUSED_TILE_BYTES + wave * FUSED_LOGIT_SCRATCH);
-                    const uint64_t first = tile << 5;
-                    const uint32_t nv = (uint32_t)(n - first < 32ull ? n - first : 32ull);
-                    store_logits_coalesced<ML>(accL, scr, logits_out + first * n_classes, lane, n_classes, nv);
-                    return;
-                }
-            }
-            if (img < n) store_logits<ML>(accL, logits_out + img * n_classes, h, n_classes);
-        };
         if constexpr (M4 > 0) {
             i32x4 p3[M3];
             relunorm_pack<M3, DBL>(acc3, p3, h);
             i32x16 acc4[M4];
             layer_mma<M4, M3, SPLIT>(A4, p3, acc4);
             cls = argmax_rows<M4>(acc4, h, n_classes);
-            if (logits_out) emit_logits(acc4);
+            if (logits_out && img < n) store_logits<M4>(acc4, logits_out + img * n_classes, h, n_classes);
         } else {
             cls = argmax_rows<M3>(acc3, h, n_classes);
-            if (logits_out) emit_logits(acc3);
+            if (logits_out && img < n) store_logits<M3>(acc3, logits_out + img * n_classes, h, n_classes);
         }
         if (h == 0 && img < n) cls_out[img] = cls;
     }
