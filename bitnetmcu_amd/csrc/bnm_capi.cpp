@@ -148,7 +148,15 @@ int ctx_build(bnm_ctx *c) {
         HIP_TRY(bnmk_unpack_rows(d.packed, L.info.bits_per_weight, L.info.n_input, d.n_real, L.info.n_output, d.rows_lo,
                                  d.rows_hi, d.row_stride, s));
         all_known = all_known && bnm_codec_known(L.info.bits_per_weight);
-        any_fp130 = any_fp130 || L.info.bits_per_weight == 20;
+        if (L.info.bits_per_weight == 20) {
+            // FP1.3.0: only the code "sign 0, exponent 7" (+128) does not fit int8 and needs the second weight plane;
+            // -128 fits.  Trained models rarely contain it (mcu/BitNetMCU_model_12k_FP130.h has none), so the
+            // two-pass kernel is selected only when the packed words actually hold such a nibble.
+            const uint32_t *w = (const uint32_t *)L.weights.data();
+            for (size_t k = 0; k < L.weights.size() / 4 && !any_fp130; k++)
+                for (int nib = 0; nib < 8; nib++)
+                    if (((w[k] >> (4 * nib)) & 15u) == 7u) { any_fp130 = true; break; }
+        }
         all_tern = all_tern && L.info.bits_per_weight == 64;
         width = L.info.n_output;
         c->fc.push_back(d);
