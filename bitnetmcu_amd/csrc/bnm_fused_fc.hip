@@ -99,7 +99,7 @@ BNM_DEVICE i32x4 sdwa_shift_pack16(const int (&c)[16], int s) {
 // Rows >= n_output are zero weights => value 0: they can only raise a negative maximum to 0, in which case
 // every output is 0 either way.
 //
-// DBL = false: accumulators hold the layer sums x.   out = clamp((x + r) >> s, 0, 127), 4 VALU per value.
+// DBL = false: accumulators hold the layer sums x.   out = clamp((x + r) >> s, 0, 127), 3 VALU per value.
 // DBL = true : this layer's weight fragments were built DOUBLED, accumulators hold 2x (exact).  With
 //   s = bitlength(max(2x) >> 8) (= the reference's shift, from max(x) >> 7) and y = clamp(2x, 0, 255*2^s - 1) >> s
 //   (0..254, one v_med3 + one SDWA shift that also packs), the rounded result is
@@ -128,22 +128,19 @@ BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int 
             for (int q = 0; q < 4; q++) packed[m][q] = (int)__builtin_amdgcn_lerp((uint32_t)y[q], 0u, 0x01010101u);
         }
     } else {
+        // plain sums: out = min(127, (x + 2^(s-1)) >> s) for x >= 0, else 0 — add, v_med3 to [0, 128*2^s - 1], SDWA
+        // shift straight into the packed byte: 3 VALU per value
         uint32_t t = (uint32_t)mx >> 7;
         int sh = t ? 32 - __builtin_clz(t) : 0;
         int rnd = (1 << sh) >> 1;
+        int hi = (128 << sh) - 1;
 #pragma unroll
-        for (int m = 0; m < MT; m++)
+        for (int m = 0; m < MT; m++) {
+            int c[16];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t d = 0;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    int v = (acc[m][4 * q + b] + rnd) >> sh;
-                    v = min(max(v, 0), 127);
-                    d |= (uint32_t)v << (8 * b);
-                }
-                packed[m][q] = (int)d;
-            }
+            for (int r = 0; r < 16; r++) c[r] = clamp0_med3(acc[m][r] + rnd, hi);
+            packed[m] = sdwa_shift_pack16(c, sh);
+        }
     }
 }
 
