@@ -414,7 +414,8 @@ const FusedEntry kFused[] = {
     FUSED(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA2),
     FUSED(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA),
     FUSED(8, 2, 2, 2, 1, false, true, FUSED_DIRECT),
-    // same shape with codecs whose weights cannot be doubled in int8 (8-bit two's complement)
+    // same shape with codecs whose weights cannot be doubled in int8 (8-bit two's complement, FP1.3.0 without +128)
+    FUSED(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA2),
     FUSED(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA),
     FUSED(8, 2, 2, 2, 1, false, false, FUSED_DIRECT),
     // same shape, FP1.3.0 weights (mcu/BitNetMCU_model_12k_FP130.h): +128 split over two A passes
