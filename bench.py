@@ -122,7 +122,7 @@ def main():
     if a.path:
         ctx.set_path(a.path)
     if a.variant >= 0 or a.grid > 0:
-        ctx.set_tuning(a.variant, a.grid)      # fused kernel: 0/1/2; ternary ALU kernel: 0/1
+        ctx.set_tuning(a.variant, a.grid)
 
     # ---- resident workload: this rank's shard of the global synthetic image stream --------------------
     n = a.images

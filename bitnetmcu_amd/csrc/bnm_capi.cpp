@@ -73,7 +73,6 @@ struct bnm_ctx {
     int variant = -1, grid_blocks = 0;
     // ternary ALU path
     bool tern_ok = false;
-    int tern_variant = 0;
     int requested_path = BNM_PATH_AUTO, path = BNM_PATH_LAYERWISE_ALU;
     // scratch
     DevBuf act_a, act_b, out32, argmax, cnn_feat, stage_img, stage_cls, stage_logits;
@@ -266,7 +265,6 @@ int run_ternary(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int
     }
     a.cls = d_cls;
     a.logits = d_logits;
-    a.variant = c->tern_variant;
     HIP_TRY(bnmk_ternary_alu(a, c->grid_blocks, s));
     return BNM_OK;
 }
@@ -427,14 +425,9 @@ int bnm_ctx_get_path(const bnm_ctx *c) { return c ? c->path : BNM_EINVAL; }
 int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
     if (!c) return fail(BNM_EINVAL, "null ctx");
     if (variant >= 0) {
-        if (c->path == BNM_PATH_TERNARY_ALU) {
-            if (variant > 1) return fail(BNM_EUNSUPPORTED, "ternary ALU kernel has variants 0 and 1");
-            c->tern_variant = variant;
-        } else {
-            if (!c->fused_ok || !bnmk_fused_supported(c->shape, variant))
-                return fail(BNM_EUNSUPPORTED, "fused kernel variant not available for this model shape");
-            c->variant = variant;
-        }
+        if (!c->fused_ok || !bnmk_fused_supported(c->shape, variant))
+            return fail(BNM_EUNSUPPORTED, "fused kernel variant not available for this model shape");
+        c->variant = variant;
     }
     c->grid_blocks = grid_blocks > 0 ? grid_blocks : 0;
     return BNM_OK;

@@ -76,7 +76,6 @@ struct BnmTernArgs {
     uint32_t n_layers;
     uint32_t *cls;
     int32_t *logits;
-    int variant = 0;        // 0: scalar-load weights, 64-thread workgroups; 1: weights in LDS, 512-thread workgroups
 };
 hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s);
 

@@ -56,37 +56,18 @@ BNM_DEVICE int tern_layer(const int (&act)[KQ], const int8_t *__restrict__ rows,
     return mx;
 }
 
-// WLDS = false: 64-thread workgroups, trit rows fetched with scalar loads (12 waves per CU).
-// WLDS = true : 512-thread workgroups that first copy all unpacked trit rows (<= 48 KiB) into LDS and then read them
-//               with wave-uniform (broadcast) ds_read_b128 — the 44 KB of rows cycle through a 16 KB scalar cache in
-//               the scalar-load form and waves sit in s_waitcnt 42 % of the time (profiles/r01).
-template <int H1, int H2, int H3, bool WLDS>
-__global__ __launch_bounds__(WLDS ? 512 : 64, WLDS ? 2 : 1) void ternary_alu_kernel(
-    const int8_t *__restrict__ images, uint64_t n, const int8_t *__restrict__ g1, const int8_t *__restrict__ g2,
-    const int8_t *__restrict__ g3, const int8_t *__restrict__ g4, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4,
-    uint32_t n_classes, uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out) {
+template <int H1, int H2, int H3>
+__global__ __launch_bounds__(64) void ternary_alu_kernel(const int8_t *__restrict__ images, uint64_t n,
+                                                         const int8_t *__restrict__ r1, const int8_t *__restrict__ r2,
+                                                         const int8_t *__restrict__ r3, const int8_t *__restrict__ r4,
+                                                         uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4,
+                                                         uint32_t n_classes, uint32_t *__restrict__ cls_out,
+                                                         int32_t *__restrict__ logits_out) {
     constexpr int HM = H1 > H2 ? (H1 > H3 ? H1 : H3) : (H2 > H3 ? H2 : H3);
-    constexpr int WAVES = WLDS ? 8 : 1;
-    constexpr int WBYTES = WLDS ? (H1 * 256 + H2 * H1 + H3 * H2 + 64 * H3) : 0;   // rows are dense when stride == n_in
-    __shared__ __attribute__((aligned(16))) uint32_t s_mem[WAVES * (HM / 2 * 64) + WBYTES / 4 + 4];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    uint32_t *col = s_mem + wave * (HM / 2 * 64) + lane;
-    const int8_t *r1 = g1, *r2 = g2, *r3 = g3, *r4 = g4;
-    if constexpr (WLDS) {
-        int8_t *wl = (int8_t *)(s_mem + WAVES * (HM / 2 * 64));
-        int8_t *l1 = wl, *l2 = l1 + H1 * 256, *l3 = l2 + H2 * H1, *l4 = l3 + H3 * H2;
-        auto copy = [&](int8_t *dst, const int8_t *src, uint32_t bytes) {
-            for (uint32_t i = threadIdx.x * 16u; i < bytes; i += 512u * 16u) *(i32x4 *)(dst + i) = *(const i32x4 *)(src + i);
-        };
-        copy(l1, g1, H1 * 256);
-        copy(l2, g2, H2 * H1);
-        copy(l3, g3, H3 * H2);
-        copy(l4, g4, n_classes * H3);
-        __syncthreads();
-        r1 = l1; r2 = l2; r3 = l3; r4 = l4;
-    }
-    for (uint64_t base = ((uint64_t)blockIdx.x * WAVES + wave) * 64ull; base < n; base += (uint64_t)gridDim.x * WAVES * 64ull) {
+    __shared__ uint32_t s_col[HM / 2 * 64];
+    const int lane = threadIdx.x;
+    uint32_t *col = s_col + lane;
+    for (uint64_t base = (uint64_t)blockIdx.x * 64ull; base < n; base += (uint64_t)gridDim.x * 64ull) {
         uint64_t img = base + (uint64_t)lane;
         const bool live = img < n;
         if (!live) img = n - 1ull;
@@ -124,22 +105,12 @@ hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s
     if (a.n_layers != 4 || a.n_in[0] != 256 || a.n_out[0] != 96 || a.n_out[1] != 96 || a.n_out[2] != 96 ||
         a.n_in[1] != 96 || a.n_in[2] != 96 || a.n_in[3] != 96)
         return hipErrorInvalidValue;
-    const bool dense = a.stride[0] == 256 && a.stride[1] == 96 && a.stride[2] == 96 && a.stride[3] == 96 && a.n_out[3] <= 64;
-    if (a.variant == 1 && dense) {
-        uint64_t want = (a.n + 511ull) / 512ull;
-        uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus();
-        unsigned blocks = (unsigned)(want < cap ? want : cap);
-        ternary_alu_kernel<96, 96, 96, true><<<dim3(blocks), dim3(512), 0, s>>>(a.images, a.n, a.rows[0], a.rows[1], a.rows[2],
-                                                                                a.rows[3], a.stride[0], a.stride[1], a.stride[2],
-                                                                                a.stride[3], a.n_out[3], a.cls, a.logits);
-        return hipGetLastError();
-    }
     uint64_t want = (a.n + 63ull) / 64ull;
     uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * 12ull;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
-    ternary_alu_kernel<96, 96, 96, false><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.rows[0], a.rows[1], a.rows[2],
-                                                                              a.rows[3], a.stride[0], a.stride[1], a.stride[2],
-                                                                              a.stride[3], a.n_out[3], a.cls, a.logits);
+    ternary_alu_kernel<96, 96, 96><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.rows[0], a.rows[1], a.rows[2],
+                                                                       a.rows[3], a.stride[0], a.stride[1], a.stride[2],
+                                                                       a.stride[3], a.n_out[3], a.cls, a.logits);
     return hipGetLastError();
 }
 

@@ -30,11 +30,7 @@ def paths_for(ctx):
             pass
     try:
         ctx.set_path(b.PATH_TERNARY_ALU)
-        for v in (0, 1):
-            def tern(c, v=v):
-                c.set_path(b.PATH_TERNARY_ALU)
-                c.set_tuning(variant=v)
-            out.append((f"ternary_alu_v{v}", tern))
+        out.append(("ternary_alu", lambda c: c.set_path(b.PATH_TERNARY_ALU)))
     except b.BnmError:
         pass
     ctx.set_path(b.PATH_AUTO)
