@@ -364,7 +364,11 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
             if (next < n_tiles) direct_load(next, bnext);
         }
 
+        // raised issue priority while the 16 layer-1 MFMAs go out: the partner wave on this SIMD is usually in a VALU
+        // phase and loses nothing measurable (+0.5..1 %, profiles/r01); non-temporal DMA is worth another 2 %
+        if constexpr (TWO) __builtin_amdgcn_s_setprio(1);
         layer_mma<M1, KT0, SPLIT>(A1, b0, acc1);
+        if constexpr (TWO) __builtin_amdgcn_s_setprio(0);
         if constexpr (TWO) {
             // all 8 B fragments of this tile's buffer have been consumed (the DMA statement first retires the wave's
             // own ds_reads): refill it with the tile after next
