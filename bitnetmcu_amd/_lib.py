@@ -121,4 +121,4 @@ def load(path=None):
 
 def check(lib, rc, what=""):
     if rc != BNM_OK:
-        raise BnmError(f"{what} failed ({rc}): {lib.bnm_last_error().decode()}")
+        raise BnmError(f"{what} failed ({rc}): {lib.bnm_last_error().decode(errors='replace')}")

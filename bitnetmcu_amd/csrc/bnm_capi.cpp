@@ -48,6 +48,11 @@ struct DevBuf {
     }
 };
 
+// scope-owned device buffer (temporary allocations inside one API call)
+struct ScopedDev : DevBuf {
+    ~ScopedDev() { release(); }
+};
+
 struct FcDev {
     bnm_layer_info info{};
     uint32_t n_real = 0;      // activations actually consumed
@@ -452,7 +457,7 @@ static int infer_host_impl(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
         if (int e = c->stage_img.ensure((size_t)cn * 256)) return e;
         if (int e = c->stage_cls.ensure((size_t)cn * 4)) return e;
         if (logits) if (int e = c->stage_logits.ensure((size_t)cn * ncls * 4)) return e;
-        DevBuf tap;
+        ScopedDev tap;
         if (acts) if (int e = tap.ensure((size_t)cn * acts_stride)) return e;
         HIP_TRY(hipMemcpy(c->stage_img.p, images + off * 256, (size_t)cn * 256, hipMemcpyHostToDevice));
         int e = infer_device_locked(c, (const int8_t *)c->stage_img.p, cn, (uint32_t *)c->stage_cls.p,
@@ -467,7 +472,6 @@ static int infer_host_impl(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
             HIP_TRY(hipMemcpy(logits + off * ncls, c->stage_logits.p, (size_t)cn * ncls * 4, hipMemcpyDeviceToHost));
         if (e == BNM_OK && acts)
             HIP_TRY(hipMemcpy(acts + off * acts_stride, tap.p, (size_t)cn * acts_stride, hipMemcpyDeviceToHost));
-        tap.release();
         if (e != BNM_OK) return e;
     }
     return BNM_OK;
@@ -504,19 +508,16 @@ int bnm_unpack_layer_host(const void *weights, int32_t bpw, uint32_t n_input, ui
     uint64_t cnt = bnm_fc_weight_count(bpw, n_input, n_output);
     size_t wbytes = (size_t)cnt * (bpw == 64 ? 2 : 4);
     size_t rbytes = (size_t)n_output * row_stride;
-    void *dw = nullptr, *dlo = nullptr, *dhi = nullptr;
-    HIP_TRY(hipMalloc(&dw, wbytes ? wbytes : 16));
-    HIP_TRY(hipMalloc(&dlo, rbytes));
-    HIP_TRY(hipMalloc(&dhi, rbytes));
-    if (wbytes) HIP_TRY(hipMemcpy(dw, weights, wbytes, hipMemcpyHostToDevice));
+    ScopedDev dw, dlo, dhi;
+    if (int e = dw.ensure(wbytes ? wbytes : 16)) return e;
+    if (int e = dlo.ensure(rbytes)) return e;
+    if (int e = dhi.ensure(rbytes)) return e;
+    if (wbytes) HIP_TRY(hipMemcpy(dw.p, weights, wbytes, hipMemcpyHostToDevice));
     uint32_t n_real = n_input < row_stride ? n_input : row_stride;
-    HIP_TRY(bnmk_unpack_rows(dw, bpw, n_input, n_real, n_output, (int8_t *)dlo, (int8_t *)dhi, row_stride, nullptr));
+    HIP_TRY(bnmk_unpack_rows(dw.p, bpw, n_input, n_real, n_output, (int8_t *)dlo.p, (int8_t *)dhi.p, row_stride, nullptr));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(lo, dlo, rbytes, hipMemcpyDeviceToHost));
-    if (hi) HIP_TRY(hipMemcpy(hi, dhi, rbytes, hipMemcpyDeviceToHost));
-    (void)hipFree(dw);
-    (void)hipFree(dlo);
-    (void)hipFree(dhi);
+    HIP_TRY(hipMemcpy(lo, dlo.p, rbytes, hipMemcpyDeviceToHost));
+    if (hi) HIP_TRY(hipMemcpy(hi, dhi.p, rbytes, hipMemcpyDeviceToHost));
     return BNM_OK;
 }
 

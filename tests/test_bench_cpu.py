@@ -1,0 +1,34 @@
+"""bench.py / __graft_entry__ on a machine without a GPU: they must say so, not fall back to a CPU path."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from util import REPO
+
+
+def test_bench_refuses_to_run_without_gpu(bnm):
+    if bnm.bnm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--images", "1000", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "needs a GPU" in (out.stderr + out.stdout)
+    assert "{" not in out.stdout          # no JSON line, no fabricated number
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under bitnetmcu_amd/ or include/ may reference it."""
+    bad = []
+    for root in ("bitnetmcu_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(REPO, root)):
+            if "_build" in dirpath or "dlls" in dirpath:
+                continue
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".c")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    for needle in ("libbnm_oracle", "bitnet_oracle", "oracle/_ref", "import oracle", "from oracle", "orc_"):
+                        if needle in text:
+                            bad.append((os.path.join(dirpath, f), needle))
+    assert not bad, bad

@@ -83,3 +83,48 @@ def test_bad_blob_rejected():
     good = util.load_golden_model("mcu_1k").to_blob()
     with pytest.raises(BnmError):
         Model.from_blob(good[:100])
+
+
+def test_loader_survives_mutated_headers():
+    """Robustness of the run-time header parser: random truncations / byte flips / line drops of a valid header must
+    end in a model or in a BnmError — never in a crash (the parser runs inside the caller's process)."""
+    rng = np.random.default_rng(123)
+    base = write_header(util.load_golden_model("mcu_1k"), "exporter").encode()
+    cnn = write_header(util.load_golden_model("mcu_cnn_16small"), "exporter").encode()
+    ok = bad = 0
+    for it in range(600):
+        src = bytearray(base if it % 3 else cnn)
+        kind = it % 4
+        if kind == 0:
+            src = src[:int(rng.integers(0, len(src)))]
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 8))):
+                src[int(rng.integers(0, len(src)))] = int(rng.integers(0, 256))
+        elif kind == 2:
+            lines = bytes(src).split(b"\n")
+            del lines[int(rng.integers(0, len(lines)))]
+            src = bytearray(b"\n".join(lines))
+        else:
+            a = int(rng.integers(0, len(src)))
+            src = src[:a] + src[a:a + int(rng.integers(1, 200))] + src[a:]
+        try:
+            m = Model.from_header_text(bytes(src))
+            assert m.num_layers >= 1 and m.num_classes >= 1
+            Model.from_blob(m.to_blob())
+            ok += 1
+        except BnmError:
+            bad += 1
+    assert ok + bad == 600 and bad > 100
+
+
+def test_blob_survives_corruption():
+    rng = np.random.default_rng(5)
+    good = bytearray(util.load_golden_model("mcu_1k").to_blob())
+    for it in range(300):
+        b2 = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            b2[int(rng.integers(0, 200))] = int(rng.integers(0, 256))     # header + layer table region
+        try:
+            Model.from_blob(bytes(b2[:int(rng.integers(1, len(b2) + 1))] if it % 2 else b2))
+        except BnmError:
+            pass
