@@ -49,6 +49,12 @@ BNM_DEVICE int dot4_su_last(int w, int p, int acc) {
 // c0: first channel handled by this launch (lane -> channel c0 + lane).  FUSE: C <= 64, the whole
 // feature vector lives in one wave and ReLUNorm is fused; otherwise the int32 features are written and
 // relunorm_kernel runs afterwards.
+// two int16 lanes packed in an int, for v_dot2_i32_i16 (compiler-visible builtin: hipcc pads the DOT hazards itself)
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+BNM_DEVICE int dot2_i16(int a, int b, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, b), acc, false);
+}
+
 template <bool FUSE>
 __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                         const int8_t *__restrict__ w1, const int8_t *__restrict__ w2,
@@ -61,8 +67,9 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
     const uint32_t c = c0 + (uint32_t)lane;
     const bool live = c < C;
 
-    // conv1 weights as three packed rows (w0,w1,w2,0) for v_dot4_i32_i8; conv2/conv3 weights as 24-bit mad operands
-    int wk[3], k2[9], k3[9];
+    // conv1 weights as three packed rows (w0,w1,w2,0) for v_dot4_i32_i8; conv2 weights as int16 pairs (w0,w1), (w2,0) per
+    // kernel row for v_dot2_i32_i16 (stage-2 inputs are <= 9216, 14 bits); conv3 weights as 24-bit mad operands
+    int wk[3], k2[9], k3[9], w01[3], w2z[3];
 #pragma unroll
     for (int dy = 0; dy < 3; dy++) {
         uint32_t w = 0;
@@ -74,6 +81,11 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
     for (int t = 0; t < 9; t++) {
         k2[t] = live ? (int)w2[9u * c + t] : 0;
         k3[t] = live ? (int)w3[9u * c + t] : 0;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+        w01[dy] = (int)(((uint32_t)k2[3 * dy] & 0xFFFFu) | ((uint32_t)k2[3 * dy + 1] << 16));
+        w2z[dy] = (int)((uint32_t)k2[3 * dy + 2] & 0xFFFFu);
     }
 
     for (uint64_t img = wave0; img < n; img += nwaves) {
@@ -87,6 +99,7 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
             // first: max(a,b,c,d,0) >> n == max over the window of (max(v,0) >> n).
             int pk[3][14];      // rolling packed pixel triples of three image rows (uniform -> SGPRs)
             int r1[3][14];      // rolling conv1 rows (after ReLU and shift)
+            int pr[3][14];      // the same rows as int16 pairs (r1[x], r1[x+1]) — operands of the stage-2 dots
             int r2[2][12];      // raw conv2 sums of a row pair feeding the first pool
             int p1[6][6];       // pooled 6x6 plane
             auto load_row = [&](auto Y) {
@@ -112,14 +125,23 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
                     s = dot4_su_last(wk[2], pk[(y1 + 2) % 3][x], s);
                     r1[y1 % 3][x] = max(s, 0) >> n_shift;
                 });
+                static_for<0, 14>([&](auto X) {
+                    constexpr int x = decltype(X)::value;
+                    pr[y1 % 3][x] = x < 13 ? (int)((uint32_t)r1[y1 % 3][x] | ((uint32_t)r1[y1 % 3][x + 1] << 16)) : r1[y1 % 3][13];
+                });
                 if constexpr (y1 >= 2) {
                     constexpr int y2 = y1 - 2;
                     static_for<0, 12>([&](auto X) {
                         constexpr int x = decltype(X)::value;
-                        int s = mul24(k2[0], r1[y2 % 3][x]);
-                        static_for<1, 9>([&](auto T) {
-                            constexpr int t = decltype(T)::value;
-                            s = mad24(k2[t], r1[(y2 + t / 3) % 3][x + t % 3], s);
+                        // 3 kernel rows x { (x, x+1) . (w0, w1)  +  (x+2, x+3) . (w2, 0) }: 6 dots instead of 9 multiply-adds
+                        // (the chain starts from a plain 24-bit multiply so that hipcc's accumulate-in-place v_dot2c needs
+                        // no v_mov 0 to seed it)
+                        int s = __mul24(k2[2], r1[y2 % 3][x + 2]);
+                        s = dot2_i16(pr[y2 % 3][x], w01[0], s);
+                        static_for<1, 3>([&](auto DY) {
+                            constexpr int dy = decltype(DY)::value;
+                            s = dot2_i16(pr[(y2 + dy) % 3][x], w01[dy], s);
+                            s = dot2_i16(pr[(y2 + dy) % 3][x + 2], w2z[dy], s);
                         });
                         r2[y2 & 1][x] = s;
                     });
