@@ -39,10 +39,9 @@ BNM_DEVICE i32x16 zero16() {
 }
 
 template <int MT, int KT, bool SPLIT>
-BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 (&b)[KT], i32x16 (&acc)[MT],
-                          const i32x16 *init = nullptr) {
+BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 (&b)[KT], i32x16 (&acc)[MT]) {
 #pragma unroll
-    for (int m = 0; m < MT; m++) acc[m] = init ? init[m] : zero16();
+    for (int m = 0; m < MT; m++) acc[m] = zero16();
 #pragma unroll
     for (int s = 0; s < KT; s++)
 #pragma unroll
@@ -146,32 +145,24 @@ BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int 
 }
 
 // first strict maximum over rows < n_classes (ReLUNorm's return value, :25-37).  key = value*256 + (255 - row):
-// the largest key is the largest value and, among equals, the smallest row.  |value| < 2^22 for every layer that
-// can be last (K <= 128, |act| <= 127, |w| <= 128).  Rows >= n_classes never win: the last layer's accumulators
-// start from last_layer_init() (-2^22 in those rows, whose weights are zero), so no validity test is needed here.
-constexpr int LAST_PAD = -(1 << 22);
+// the largest key is the largest value and, among equals, the smallest row.  |value| < 2^23 for every layer that
+// can be last (K <= 128, |act| <= 127, |w| <= 128).  Registers whose rows are all >= n_classes are skipped by
+// wave-uniform branches.
 template <int MT>
-BNM_DEVICE void last_layer_init(i32x16 (&init)[MT], int h, uint32_t n_classes) {
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const uint32_t row = 32u * m + (r & 3) + 8u * (r >> 2) + 4u * h;
-            init[m][r] = row < n_classes ? 0 : LAST_PAD;
-        }
-}
-
-template <int MT>
-BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h) {
+BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h, uint32_t n_classes) {
     int best = INT_MIN;
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint32_t rowbase = 32u * m + (r & 3) + 8u * (r >> 2);   // row of the h = 0 half; h = 1: +4
-            best = max(best, (int)(((uint32_t)acc[m][r] << 8) + (255u - rowbase)));
+            if (rowbase < n_classes) {
+                int key = (int)(((uint32_t)acc[m][r] << 8) + (255u - rowbase));
+                if (rowbase + 4u >= n_classes) key = h ? INT_MIN : key;
+                best = max(best, key);
+            }
         }
-    best -= 4 * h;
+    best = best == INT_MIN ? INT_MIN : best - 4 * h;
     best = max(best, partner32(best, h));
     return 255u - ((uint32_t)best & 255u);
 }
@@ -326,9 +317,6 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
         }
     };
 
-    i32x16 last_init[M4 > 0 ? M4 : M3];
-    last_layer_init(last_init, h, n_classes);
-
     int par = 0;
     i32x4 bnext[KT0];
     auto direct_load = [&](uint64_t t, i32x4(&dst)[KT0]) {
@@ -396,7 +384,7 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
         relunorm_pack<M2, DBL>(acc2, p2, h);
 
         i32x16 acc3[M3];
-        layer_mma<M3, M2, SPLIT>(A3, p2, acc3, M4 > 0 ? nullptr : last_init);
+        layer_mma<M3, M2, SPLIT>(A3, p2, acc3);
 
         const uint64_t img = (tile << 5) + (uint64_t)j;
         uint32_t cls;
@@ -404,11 +392,11 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
             i32x4 p3[M3];
             relunorm_pack<M3, DBL>(acc3, p3, h);
             i32x16 acc4[M4];
-            layer_mma<M4, M3, SPLIT>(A4, p3, acc4, last_init);
-            cls = argmax_rows<M4>(acc4, h);
+            layer_mma<M4, M3, SPLIT>(A4, p3, acc4);
+            cls = argmax_rows<M4>(acc4, h, n_classes);
             if (logits_out && img < n) store_logits<M4>(acc4, logits_out + img * n_classes, h, n_classes);
         } else {
-            cls = argmax_rows<M3>(acc3, h);
+            cls = argmax_rows<M3>(acc3, h, n_classes);
             if (logits_out && img < n) store_logits<M3>(acc3, logits_out + img * n_classes, h, n_classes);
         }
         if (h == 0 && img < n) cls_out[img] = cls;
