@@ -321,3 +321,24 @@ def test_evaluate_binding_and_latency_numbers(gpu_ok, orc, capsys):
     xr = rng.normal(size=(20000, 256)).astype(np.float32)
     assert np.array_equal(evaluate.predict(ctx, xr), util.OracleModel(model, orc).infer(harness.quantize_input(xr)))
     ctx.close()
+
+
+def test_bench_under_torchrun_single_rank(gpu_ok):
+    """The N>1 launch contract with one rank: torch.distributed.run -> RCCL process group, model broadcast, barriers,
+    MAX-reduced time, all-reduced digest (the driver runs the same command with 2/4/8 ranks)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(util.REPO, "bench.py"), "--gpus", "1", "--steps", "2",
+                          "--warmup", "1", "--images", "1000000", "--no-cpu"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 1 and d["verified_vs_oracle"] is True and sum(d["class_histogram"]) == 1000000
