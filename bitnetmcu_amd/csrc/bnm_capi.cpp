@@ -2,6 +2,7 @@
 // Host side only: model handling, device residency, kernel selection, the reference's own symbols on top
 // of the device kernels.  There is NO CPU compute path in this file: if HIP is unusable, the reference-ABI
 // functions abort() and the bnm_* functions return BNM_EHIP.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -547,6 +548,62 @@ int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int gri
     if (mode < 0 || mode > 2) return fail(BNM_EINVAL, "mode must be 0, 1 or 2");
     HIP_TRY(bnmk_diag_stream(d_images, n, mode, grid_blocks, d_out, (hipStream_t)stream));
     return BNM_OK;
+}
+
+int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, int dist, uint64_t seed, uint64_t *digest_hist,
+                            uint32_t n_bins, double *seconds) {
+    if (!m || !digest_hist || n_bins > 64) return fail(BNM_EINVAL, "bad argument");
+    if (dist != BNM_DIST_U && dist != BNM_DIST_M) return fail(BNM_EINVAL, "dist must be 0 or 1");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(BNM_EHIP, "no HIP device visible");
+    const int G = (n_gpus <= 0 || n_gpus > ndev) ? ndev : n_gpus;
+    struct Shard {
+        bnm_ctx *ctx = nullptr;
+        ScopedDev img, cls, dig;
+        uint64_t first = 0, count = 0;
+    };
+    std::vector<Shard> sh(G);
+    auto cleanup = [&]() {
+        for (auto &x : sh) {
+            if (x.ctx) { (void)hipSetDevice(x.ctx->device); x.img.release(); x.cls.release(); x.dig.release(); bnm_ctx_destroy(x.ctx); x.ctx = nullptr; }
+        }
+    };
+    // contiguous shards differing by at most one image (same rule as bitnetmcu_amd.dist.shard_range)
+    const uint64_t base = n_total / G, rem = n_total % G;
+    for (int g = 0; g < G; g++) {
+        Shard &x = sh[g];
+        x.first = (uint64_t)g * base + ((uint64_t)g < rem ? (uint64_t)g : rem);
+        x.count = base + ((uint64_t)g < rem ? 1 : 0);
+        int e = bnm_ctx_create(m, g, &x.ctx);
+        if (e != BNM_OK) { cleanup(); return e; }
+        if ((e = x.img.ensure((size_t)(x.count ? x.count : 1) * 256)) || (e = x.cls.ensure((size_t)(x.count ? x.count : 1) * 4)) ||
+            (e = x.dig.ensure(65 * 8))) { cleanup(); return e; }
+        if (hipMemset(x.dig.p, 0, 65 * 8) != hipSuccess ||
+            bnmk_synth_fill((int8_t *)x.img.p, x.first, x.count, seed, dist, nullptr) != hipSuccess) {
+            cleanup();
+            return fail(BNM_EHIP, "shard setup failed");
+        }
+    }
+    for (int g = 0; g < G; g++) { (void)hipSetDevice(g); (void)hipDeviceSynchronize(); }
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = BNM_OK;
+    for (int g = 0; g < G && rc == BNM_OK; g++)      // launches are asynchronous: all devices run concurrently
+        rc = bnm_infer_device(sh[g].ctx, (const int8_t *)sh[g].img.p, sh[g].count, (uint32_t *)sh[g].cls.p, nullptr, nullptr);
+    for (int g = 0; g < G; g++) { (void)hipSetDevice(g); if (hipDeviceSynchronize() != hipSuccess && rc == BNM_OK) rc = fail(BNM_EHIP, "kernel execution failed"); }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    std::memset(digest_hist, 0, sizeof(uint64_t) * (1 + n_bins));
+    for (int g = 0; g < G && rc == BNM_OK; g++) {
+        uint64_t part[65] = {0};
+        (void)hipSetDevice(g);
+        if (bnmk_class_digest((const uint32_t *)sh[g].cls.p, sh[g].first, sh[g].count, (uint64_t *)sh[g].dig.p, n_bins, nullptr) != hipSuccess ||
+            hipMemcpy(part, sh[g].dig.p, sizeof(uint64_t) * (1 + n_bins), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(BNM_EHIP, "digest failed");
+        for (uint32_t k = 0; k <= n_bins; k++) digest_hist[k] += part[k];   // the all-reduce, done on the host
+    }
+    cleanup();
+    return rc == BNM_OK ? G : rc;
 }
 
 int bnm_device_malloc(void **p, size_t bytes) { HIP_TRY(hipMalloc(p, bytes)); return BNM_OK; }

@@ -185,6 +185,15 @@ BNM_API int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint6
 BNM_API int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out,
                                    void *stream);
 
+/* ---- multi-GPU, single process (C hosts; PyTorch hosts use one process per GPU, see bench.py) ------------------
+ * Shards the global synthetic image stream [0, n_total) contiguously over the first n_gpus visible devices
+ * (n_gpus <= 0: all), generates every shard on its own GPU, runs the whole-model path on all of them concurrently and
+ * returns the combined order-independent digest + class histogram (digest_hist[0], digest_hist[1..n_bins]) and the
+ * wall-clock seconds of the inference phase.  No image byte crosses a link; the model is uploaded to each device.
+ * Returns the number of GPUs used (> 0) or a negative BNM_E* code. */
+BNM_API int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, int dist, uint64_t seed,
+                                    uint64_t *digest_hist, uint32_t n_bins, double *seconds);
+
 /* ---- model binding for group A ------------------------------------------------------------ */
 /* Bind the model that Inference()/BitMnistInference() run.  A `Bitnet_inf.dll` built by
  * bitnetmcu_amd/build.py --dll <header> does this itself from the embedded header text. */

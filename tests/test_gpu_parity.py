@@ -342,3 +342,20 @@ def test_bench_under_torchrun_single_rank(gpu_ok):
     assert lines, out.stderr[-2000:]
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 1 and d["verified_vs_oracle"] is True and sum(d["class_histogram"]) == 1000000
+
+
+def test_c_abi_multi_gpu_entry_point(gpu_ok, bnm, orc):
+    """bnm_run_synth_multi_gpu on however many GPUs are visible (1 on the test box): digest + histogram equal the oracle's."""
+    import ctypes as C
+    model = util.load_golden_model("fc_4bitsym_64")
+    n = 300_001
+    out = (C.c_uint64 * 11)()
+    secs = C.c_double()
+    used = bnm.bnm_run_synth_multi_gpu(model._h, n, 0, DIST_U, b.SEED_DIST_U, out, 10, C.byref(secs))
+    assert used >= 1 and secs.value > 0
+    cls = util.OracleModel(model, orc).infer(synth.images(0, n, DIST_U))
+    assert out[0] == synth.class_digest(cls, 0)
+    assert list(out)[1:] == np.bincount(cls, minlength=10).tolist()
+    # asking for more GPUs than exist uses what is there; bad arguments are errors, not crashes
+    assert bnm.bnm_run_synth_multi_gpu(model._h, 1000, 64, DIST_U, b.SEED_DIST_U, out, 10, None) == used
+    assert bnm.bnm_run_synth_multi_gpu(model._h, 1000, 1, 7, b.SEED_DIST_U, out, 10, None) < 0
