@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Practical read ceiling of the image stream on this GPU, next to the real kernel (run on the GPU box).
-Prints GB/s (256 B/image read; the tile-loop modes also write 4 B/image like the real kernel)."""
+Prints GB/s (256 B/image read; the tile-loop modes also write 4 B/image like the real kernel).
+Modes 3/4 add a synthetic compute load of the real kernel's size to the LDS-DMA loop / to plain VGPR loads."""
 import json
 import os
 import sys
@@ -19,7 +20,7 @@ b.synth.fill_device(imgs)
 out = torch.zeros(n, dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 res = {}
-for mode, grids in ((0, (0, 8192)), (1, (0, 1024)), (2, (0, 1024))):
+for mode, grids in ((0, (0, 8192)), (1, (0,)), (2, (0,)), (3, (0,)), (4, (0,))):
     for g in grids:
         for _ in range(3):
             L.check(lib, lib.bnm_diag_stream_device(imgs.data_ptr(), n, mode, g, out.data_ptr(), s))
