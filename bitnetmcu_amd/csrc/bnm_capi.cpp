@@ -545,7 +545,11 @@ int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint64_t n, u
 
 int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out, void *stream) {
     if (n && (!d_images || !d_out)) return fail(BNM_EINVAL, "null pointer");
-    if (mode < 0 || mode > 4) return fail(BNM_EINVAL, "mode must be 0..4");
+    if (mode < 0 || mode > 7) return fail(BNM_EINVAL, "mode must be 0..7");
+    if (mode >= 5) {   // pipe-overlap probe: n = tiles per wave, no image traffic
+        HIP_TRY(bnmk_diag_pipes(mode, n, d_out, (hipStream_t)stream));
+        return BNM_OK;
+    }
     HIP_TRY(bnmk_diag_stream(d_images, n, mode, grid_blocks, d_out, (hipStream_t)stream));
     return BNM_OK;
 }

@@ -625,3 +625,44 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void diag_stream_compute_kernel(
         }
     }
 }
+
+// -------------------------------------------------------------------------------------------------
+// Diagnostics, modes 5/6/7: no memory traffic at all.  Each wave repeats a tile-sized block of 26 MFMAs (mode 5),
+// ~400 VALU (mode 6) or both (mode 7), two waves per SIMD as in the fused kernel.  T(7) ~ T(5) + T(6) means the matrix
+// pipe and the VALU of one SIMD do not overlap for this instruction mix; T(7) ~ max means they do.
+// -------------------------------------------------------------------------------------------------
+template <bool DO_MFMA, bool DO_VALU>
+__global__ __launch_bounds__(64 * FUSED_WPB, 2) void diag_pipes_kernel(uint64_t tiles_per_wave, uint32_t *__restrict__ out) {
+    __shared__ char pad[FUSED_WPB * 2 * FUSED_TILE_BYTES];   // same LDS footprint -> same residency (2 workgroups per CU)
+    const int lane = threadIdx.x & 63;
+    i32x16 acc0 = zero16(), acc1 = zero16();
+    int v0 = lane, v1 = lane * 3, v2 = lane * 5, v3 = lane * 7;
+    i32x4 fa = {lane, lane + 1, lane + 2, lane + 3}, fb = {lane * 2, 1, 2, 3};
+    for (uint64_t t = 0; t < tiles_per_wave; t++) {
+        if constexpr (DO_MFMA) {
+#pragma unroll
+            for (int i = 0; i < 13; i++) {
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb, fa, acc1, 0, 0, 0);
+            }
+        }
+        if constexpr (DO_VALU) {
+#pragma unroll
+            for (int i = 0; i < 40; i++) {     // 10 VALU per round, four chains
+                v0 = min(max(v0 + 3, 0), 0x7fffff) ^ v3;
+                v1 = min(max(v1 + 5, 0), 0x7fffff) ^ v0;
+                v2 = (v2 >> 1) + v1;
+                v3 = (v3 << 1) ^ v2;
+            }
+        }
+    }
+    if (pad[threadIdx.x] == 123 || (acc0[0] ^ acc1[1] ^ v0 ^ v1 ^ v2 ^ v3) == 0x5a5a5a5a) out[threadIdx.x] = 1;
+}
+
+hipError_t bnmk_diag_pipes(int mode, uint64_t tiles_per_wave, uint32_t *out, hipStream_t s) {
+    unsigned blocks = (unsigned)bnm_num_cus() * 2u;
+    if (mode == 5) diag_pipes_kernel<true, false><<<dim3(blocks), dim3(256), 0, s>>>(tiles_per_wave, out);
+    else if (mode == 6) diag_pipes_kernel<false, true><<<dim3(blocks), dim3(256), 0, s>>>(tiles_per_wave, out);
+    else diag_pipes_kernel<true, true><<<dim3(blocks), dim3(256), 0, s>>>(tiles_per_wave, out);
+    return hipGetLastError();
+}

@@ -84,3 +84,4 @@ hipError_t bnmk_diag_stream(const int8_t *d_images, uint64_t n, int mode, int gr
 
 // ---- input quantisation: float32 [n][256] -> int8 [n][256] (test_inference.py:140-141) --------------
 hipError_t bnmk_quantize_input(const float *d_x, uint64_t n, int8_t *d_out, hipStream_t s);
+hipError_t bnmk_diag_pipes(int mode, uint64_t tiles_per_wave, uint32_t *d_out, hipStream_t s);   // modes 5/6/7: pipe overlap probe

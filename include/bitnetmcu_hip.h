@@ -181,7 +181,8 @@ BNM_API int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint6
 
 /* Diagnostics: read the image stream without the model math.  mode 0: plain 16 B/lane loads; mode 1/2: the fused
  * kernel's own LDS-DMA tile loop (one tile ahead / two tiles in flight); mode 3/4: the stream under a synthetic
- * compute load, fed by the LDS-DMA loop / by plain loads into VGPRs.  d_out: uint32 [n].  Puts the practical read ceiling of
+ * compute load, fed by the LDS-DMA loop / by plain loads into VGPRs; mode 5/6/7: no memory traffic, n = tiles per
+ * wave of 26 MFMAs / ~400 VALU / both (do the matrix pipe and the VALU of a SIMD overlap?).  d_out: uint32 [n].  Puts the practical read ceiling of
  * this access pattern next to the real kernel (profiles/stream_ceiling.py). */
 BNM_API int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out,
                                    void *stream);
