@@ -239,7 +239,8 @@ constexpr int FUSED_WPB = 4;              // waves per workgroup; two workgroups
 
 // Kernel variants = how the image tile reaches the B operands:
 //   0  DIRECT     global -> VGPR loads in operand layout (any row length; CNN tails with 64/128/192-byte rows)
-//   1  LDSDMA     8 x 1 KiB LDS-DMA pieces into a per-wave double buffer, next tile issued at the top of the iteration
+//   1  LDSDMA     8 x 1 KiB non-temporal LDS-DMA pieces into a per-wave double buffer, next tile issued at the top of
+//                 the iteration (non-temporal: +8..12 % on the 16-wide 1k model, neutral on 64-wide ones)
 //   2  LDSDMA2    as 1 with TWO tiles in flight per wave (default where available): the refill of the buffer a tile
 //                 just vacated (tile k+2) is issued right AFTER tile k's layer-1 MFMAs, non-temporal.  With one tile
 //                 in flight the kernel is bound by per-wave memory-level parallelism (8 KiB / latency x 2048 waves);
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
         uint32_t lds = lds_wave + (uint32_t)par * FUSED_TILE_BYTES;
         uint64_t first = t << 5;
         if (first + 32ull <= n) {
-            lds_dma_tile8<TWO, TWO>(lds, base, base + 1024, base + 2048, base + 3072, base + 4096, base + 5120, base + 6144,
+            lds_dma_tile8<true, TWO>(lds, base, base + 1024, base + 2048, base + 3072, base + 4096, base + 5120, base + 6144,
                                     base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0], voff[1], voff[2], voff[3]);
         } else {
             // ragged last tile: rows past the end re-read the last valid image (never out of bounds)
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
                 uint32_t src = r < nv ? r : nv - 1u;
                 v[tt] = src * 256u + 16u * ((uint32_t)(lane & 15) ^ (r & 15u));
             }
-            lds_dma_tile8<TWO, TWO>(lds, base, base, base, base, base, base, base, base, v[0], v[1], v[2], v[3], v[4], v[5],
+            lds_dma_tile8<true, TWO>(lds, base, base, base, base, base, base, base, base, v[0], v[1], v[2], v[3], v[4], v[5],
                                     v[6], v[7]);
         }
     };
