@@ -175,6 +175,7 @@ int ctx_build(bnm_ctx *c) {
         sh.KT0 = (int)(in_width / 32u);
         for (size_t i = 0; i < 4; i++) sh.M[i] = i < nfc ? (int)((c->fc[i].info.n_output + 31u) / 32u) : 0;
         sh.split = any_fp130;
+        sh.nc8 = (int)((c->fc[nfc - 1].info.n_output + 7u) / 8u);
         // doubling needs |2w| <= 127 in every hidden layer: all codecs but 8-bit two's complement and FP1.3.0
         sh.dbl = true;
         for (size_t i = 0; i + 1 < nfc; i++)
@@ -197,8 +198,10 @@ int ctx_build(bnm_ctx *c) {
                         const int8_t *rows = (part == 0 ? d.rows_lo : d.rows_hi) + (size_t)mt * 32u * d.row_stride;
                         uint32_t rows_left = d.info.n_output > (uint32_t)mt * 32u ? d.info.n_output - (uint32_t)mt * 32u : 0u;
                         const int scale = (sh.dbl && i + 1 < nfc) ? 2 : 1;   // hidden layers only
+                        // classifier layer: padding rows weigh -128 so they can never win the argmax (first plane only)
+                        const int pad = (i + 1 == nfc && part == 0) ? -128 : 0;
                         HIP_TRY(bnmk_build_fragments(rows, d.row_stride, rows_left, d.n_real, 1, (uint32_t)kt, i == 0 ? 0 : 1, scale,
-                                                     dst + ((size_t)mt * kt * sp + (size_t)part * kt) * 1024, s));
+                                                     pad, dst + ((size_t)mt * kt * sp + (size_t)part * kt) * 1024, s));
                     }
                 }
                 dst += (size_t)sh.M[i] * kt * sp * 1024;

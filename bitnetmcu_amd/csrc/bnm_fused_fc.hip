@@ -144,25 +144,27 @@ BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int 
     }
 }
 
-// first strict maximum over rows < n_classes (ReLUNorm's return value, :25-37).  key = value*256 + (255 - row):
+// first strict maximum over the class rows (ReLUNorm's return value, :25-37).  key = value*256 + (255 - row):
 // the largest key is the largest value and, among equals, the smallest row.  |value| < 2^23 for every layer that
-// can be last (K <= 128, |act| <= 127, |w| <= 128).  Registers whose rows are all >= n_classes are skipped by
-// wave-uniform branches.
-template <int MT>
-BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h, uint32_t n_classes) {
+// can be last (K <= 128, |act| <= 127, |w| <= 128).
+// No run-time row masks: the fragment builder fills the last layer's padding rows (row >= n_classes) with weight
+// -128 on every real input column, so a padding row's sum is -128 * sum(act) <= every real row's sum (act >= 0,
+// w >= -128) and on a tie the real row, having the smaller index, wins.  NC8 > 0 states at compile time that
+// n_classes <= 8 * NC8, so accumulator registers holding only rows >= 8 * NC8 are not looked at at all
+// (10 classes: 8 of 16 registers); NC8 == 0 looks at every register.  1.5 VALU per register examined.
+template <int MT, int NC8>
+BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h) {
+    constexpr int G = NC8 > 0 ? NC8 : 4 * MT;
     int best = INT_MIN;
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
+            if (4 * m + (r >> 2) >= G) continue;
             const uint32_t rowbase = 32u * m + (r & 3) + 8u * (r >> 2);   // row of the h = 0 half; h = 1: +4
-            if (rowbase < n_classes) {
-                int key = (int)(((uint32_t)acc[m][r] << 8) + (255u - rowbase));
-                if (rowbase + 4u >= n_classes) key = h ? INT_MIN : key;
-                best = max(best, key);
-            }
+            best = max(best, (int)(((uint32_t)acc[m][r] << 8) | (255u - rowbase)));
         }
-    best = best == INT_MIN ? INT_MIN : best - 4 * h;
+    best -= 4 * h;
     best = max(best, partner32(best, h));
     return 255u - ((uint32_t)best & 255u);
 }
@@ -247,9 +249,9 @@ constexpr int FUSED_WPB = 4;              // waves per workgroup; two workgroups
 //                 issuing the second DMA in front of the MFMAs instead serialises the wave (profiles/r01).
 // Tried and dropped in round 1 (tag r01-experiments-all-variants): 8-wave workgroups with staggered halves, a
 // software-pipelined MFMA||VALU form, three waves per SIMD with weights in LDS, split half-tile refills.
-enum { FUSED_DIRECT = 0, FUSED_LDSDMA = 1, FUSED_LDSDMA2 = 2 };
+enum { FUSED_DIRECT = 0, FUSED_LDSDMA = 1, FUSED_LDSDMA2 = 2, FUSED_DUAL = 3 };
 
-template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT>
+template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT, int NC8>
 __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                      const i32x4 *__restrict__ frags, uint32_t n_classes,
                                                                      uint32_t *__restrict__ cls_out,
@@ -394,14 +396,148 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
             relunorm_pack<M3, DBL>(acc3, p3, h);
             i32x16 acc4[M4];
             layer_mma<M4, M3, SPLIT>(A4, p3, acc4);
-            cls = argmax_rows<M4>(acc4, h, n_classes);
+            cls = argmax_rows<M4, NC8>(acc4, h);
             if (logits_out && img < n) store_logits<M4>(acc4, logits_out + img * n_classes, h, n_classes);
         } else {
-            cls = argmax_rows<M3>(acc3, h, n_classes);
+            cls = argmax_rows<M3, NC8>(acc3, h);
             if (logits_out && img < n) store_logits<M3>(acc3, logits_out + img * n_classes, h, n_classes);
         }
         if (h == 0 && img < n) cls_out[img] = cls;
     }
+}
+
+// ---- variant 3, DUAL: one wave carries TWO independent tiles (A, B) per iteration -----------------
+// Same LDS budget as variant 2 (one 8 KiB buffer per tile slot, refilled right after that slot's layer-1 MFMAs), but
+// the two tiles' layer chains are independent instruction streams inside one wave, and the loop body is ONE basic
+// block (no ragged / last-iteration branches: the launcher hands this kernel whole 64-image pairs only and gives
+// the remainder to variant 2; the refill after the last pair re-reads that pair), so the scheduler can place one
+// tile's ReLUNorm VALU work between the other tile's MFMAs.  Weights stay in registers once for both tiles.
+//
+// whole 32-image tile, rows contiguous: two base pointers + instruction offsets instead of eight pointers.
+// The instruction offset of an LDS-DMA load is added to BOTH the global and the LDS address, so pieces 0..3 and
+// 4..7 need M0 set only once each.
+BNM_DEVICE void lds_dma_tile8_linear(uint32_t lds, const int8_t *lo, const int8_t *hi, uint32_t v0, uint32_t v1,
+                                     uint32_t v2, uint32_t v3) {
+    uint32_t keep;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "s_nop 4\n\t"
+                 "s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %4, %2 nt\n\t"
+                 "global_load_lds_dwordx4 %5, %2 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %6, %2 offset:2048 nt\n\t"
+                 "global_load_lds_dwordx4 %7, %2 offset:3072 nt\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %4, %3 nt\n\t"
+                 "global_load_lds_dwordx4 %5, %3 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %6, %3 offset:2048 nt\n\t"
+                 "global_load_lds_dwordx4 %7, %3 offset:3072 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds), "s"(lo), "s"(hi), "v"(v0), "v"(v1), "v"(v2), "v"(v3)
+                 : "memory", "scc");
+}
+
+template <int M1, int M2, int M3, int M4, bool DBL, int NC8>
+__global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const int8_t *__restrict__ images, uint64_t n,
+                                                                          const i32x4 *__restrict__ frags,
+                                                                          uint32_t n_classes, uint32_t *__restrict__ cls_out,
+                                                                          int32_t *__restrict__ logits_out,
+                                                                          uint64_t src_wrap) {
+    constexpr int KT0 = 8;
+    static_assert(M4 > 0, "dual-tile form is instantiated for four-layer models");
+    __shared__ __attribute__((aligned(1024))) char smem[FUSED_WPB * 2 * FUSED_TILE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    AFrags<M1, KT0> A1;
+    AFrags<M2, M1> A2;
+    AFrags<M3, M2> A3;
+    AFrags<M4, M3> A4;
+    const i32x4 *fp = frags;
+    A1.load(fp, lane);  fp += M1 * KT0 * 64;
+    A2.load(fp, lane);  fp += M2 * M1 * 64;
+    A3.load(fp, lane);  fp += M3 * M2 * 64;
+    A4.load(fp, lane);
+
+    const uint64_t n_pairs = n >> 6;            // the launcher guarantees n % 64 == 0
+    const uint64_t stride = (uint64_t)gridDim.x * FUSED_WPB;
+    uint64_t pair = (uint64_t)blockIdx.x * FUSED_WPB + wave;
+
+    uint32_t voff[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
+    const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
+    const uint32_t rd_base = (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
+
+    // slot 0 holds tile 2p, slot 1 tile 2p+1.  Diagnostics: src_wrap (a power of two here) keeps the source
+    // cache-resident; as a mask it costs one s_and and no branch.
+    const uint64_t wrap_mask = src_wrap ? src_wrap - 1ull : ~0ull;
+    auto dma_tile = [&](uint64_t t, int slot) {
+        const int8_t *base = images + (t & wrap_mask) * (uint64_t)FUSED_TILE_BYTES;
+        lds_dma_tile8_linear(lds_wave + (uint32_t)slot * FUSED_TILE_BYTES, base, base + 4096, voff[0], voff[1], voff[2], voff[3]);
+    };
+    auto read_tile = [&](int slot, i32x4(&b)[KT0]) {
+#pragma unroll
+        for (int s = 0; s < KT0; s++) b[s] = *(const i32x4 *)(smem + ((rd_base ^ (32u * s)) + (uint32_t)slot * FUSED_TILE_BYTES));
+    };
+
+    if (pair < n_pairs) {
+        dma_tile(2ull * pair, 0);
+        dma_tile(2ull * pair + 1ull, 1);
+    }
+    for (; pair < n_pairs; pair += stride) {
+        // the refill after the last pair re-reads that pair (keeps the wait counts constant and the body branch-free)
+        const uint64_t next = pair + stride < n_pairs ? pair + stride : pair;
+        // outstanding, oldest first: slot 0 (8 pieces), slot 1 (8 pieces), the previous iteration's stores.
+        // Loads retire in order among themselves, so "<= 8 left" implies slot 0 has landed.
+        bnm_wait_vmcnt<8>();
+        i32x4 bA[KT0], bB[KT0];
+        i32x16 a1A[M1], a1B[M1];
+        read_tile(0, bA);
+        layer_mma<M1, KT0, false>(A1, bA, a1A);
+        dma_tile(2ull * next, 0);
+        bnm_wait_vmcnt<8>();     // slot 1 is now the oldest load group
+        read_tile(1, bB);
+        layer_mma<M1, KT0, false>(A1, bB, a1B);
+        dma_tile(2ull * next + 1ull, 1);
+
+        i32x4 p1A[M1], p1B[M1];
+        relunorm_pack<M1, DBL>(a1A, p1A, h);
+        i32x16 a2A[M2], a2B[M2];
+        layer_mma<M2, M1, false>(A2, p1A, a2A);
+        relunorm_pack<M1, DBL>(a1B, p1B, h);
+        layer_mma<M2, M1, false>(A2, p1B, a2B);
+
+        i32x4 p2A[M2], p2B[M2];
+        relunorm_pack<M2, DBL>(a2A, p2A, h);
+        i32x16 a3A[M3], a3B[M3];
+        layer_mma<M3, M2, false>(A3, p2A, a3A);
+        relunorm_pack<M2, DBL>(a2B, p2B, h);
+        layer_mma<M3, M2, false>(A3, p2B, a3B);
+
+        i32x4 p3A[M3], p3B[M3];
+        relunorm_pack<M3, DBL>(a3A, p3A, h);
+        i32x16 a4A[M4], a4B[M4];
+        layer_mma<M4, M3, false>(A4, p3A, a4A);
+        relunorm_pack<M3, DBL>(a3B, p3B, h);
+        layer_mma<M4, M3, false>(A4, p3B, a4B);
+
+        const uint64_t imgA = (pair << 6) + (uint64_t)j, imgB = imgA + 32ull;
+        uint32_t clsA = argmax_rows<M4, NC8>(a4A, h);
+        uint32_t clsB = argmax_rows<M4, NC8>(a4B, h);
+        if (logits_out) {
+            store_logits<M4>(a4A, logits_out + imgA * n_classes, h, n_classes);
+            store_logits<M4>(a4B, logits_out + imgB * n_classes, h, n_classes);
+        }
+        // both halves of the wave hold the result: lanes 0..31 store tile A's classes, lanes 32..63 tile B's —
+        // one 256-byte store per pair
+        cls_out[h ? imgB : imgA] = h ? clsB : clsA;
+    }
+    bnm_wait_vmcnt<0>();   // LDS-DMA still in flight must not outlive the workgroup's LDS allocation
 }
 
 // ---- dispatch table: model shapes of the reference zoo (+ ternary) -----------------------------
@@ -412,40 +548,52 @@ struct FusedEntry {
     int variant;
     fused_fn fn;
 };
-#define FUSED(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR) \
-    { {KT0, {M1, M2, M3, M4}, SPLIT, DBL}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, DBL, VAR> }
+// NC8 = 0: any class count; NC8 = k: specialised for n_classes <= 8k (see argmax_rows)
+#define FUSED(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR, NC8) \
+    { {KT0, {M1, M2, M3, M4}, SPLIT, DBL, NC8}, VAR, fused_fc_kernel<KT0, M1, M2, M3, M4, SPLIT, DBL, VAR, NC8> }
+#define FUSED_ANY_AND_10(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR) \
+    FUSED(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR, 2), FUSED(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR, 0)
 const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
-    FUSED(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA2),
-    FUSED(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA),
-    FUSED(8, 2, 2, 2, 1, false, true, FUSED_DIRECT),
+    { {8, {2, 2, 2, 1}, false, true, 2}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, true, 2> },
+    { {8, {2, 2, 2, 1}, false, true, 0}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, true, 0> },
+    FUSED_ANY_AND_10(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA2),
+    FUSED_ANY_AND_10(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA),
+    FUSED(8, 2, 2, 2, 1, false, true, FUSED_DIRECT, 0),
     // same shape with codecs whose weights cannot be doubled in int8 (8-bit two's complement, FP1.3.0 without +128)
-    FUSED(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA2),
-    FUSED(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA),
-    FUSED(8, 2, 2, 2, 1, false, false, FUSED_DIRECT),
+    { {8, {2, 2, 2, 1}, false, false, 2}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, false, 2> },
+    { {8, {2, 2, 2, 1}, false, false, 0}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, false, 0> },
+    FUSED_ANY_AND_10(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA2),
+    FUSED(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA, 0),
+    FUSED(8, 2, 2, 2, 1, false, false, FUSED_DIRECT, 0),
     // same shape, FP1.3.0 weights (mcu/BitNetMCU_model_12k_FP130.h): +128 split over two A passes
-    FUSED(8, 2, 2, 2, 1, true, false, FUSED_LDSDMA),
-    FUSED(8, 2, 2, 2, 1, true, false, FUSED_DIRECT),
+    FUSED(8, 2, 2, 2, 1, true, false, FUSED_LDSDMA, 0),
+    FUSED(8, 2, 2, 2, 1, true, false, FUSED_DIRECT, 0),
     // FC 256-16-16-10 2bitsym (mcu/BitNetMCU_model_1k.h)
-    FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA2),
-    FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA),
-    FUSED(8, 1, 1, 1, 0, false, true, FUSED_DIRECT),
+    FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA2, 0),
+    FUSED_ANY_AND_10(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA),
+    FUSED(8, 1, 1, 1, 0, false, true, FUSED_DIRECT, 0),
     // ternary FC 256-96-96-96-10 through the MFMA path (optional; config 3's product path is the ALU kernel)
-    FUSED(8, 3, 3, 3, 1, false, true, FUSED_LDSDMA),
-    FUSED(8, 3, 3, 3, 1, false, true, FUSED_DIRECT),
+    FUSED(8, 3, 3, 3, 1, false, true, FUSED_LDSDMA, 0),
+    FUSED(8, 3, 3, 3, 1, false, true, FUSED_DIRECT, 0),
     // CNN FC tails: 4C-96-64-10 (cnn_64/48/32/16), 64-64-48-10 (cnn_16small), 256-96-64-37 (letters)
-    FUSED(8, 3, 2, 1, 0, false, true, FUSED_LDSDMA),
-    FUSED(8, 3, 2, 1, 0, false, true, FUSED_DIRECT),
-    FUSED(6, 3, 2, 1, 0, false, true, FUSED_DIRECT),
-    FUSED(4, 3, 2, 1, 0, false, true, FUSED_DIRECT),
-    FUSED(2, 3, 2, 1, 0, false, true, FUSED_DIRECT),
-    FUSED(2, 2, 2, 1, 0, false, true, FUSED_DIRECT),
-    FUSED(8, 3, 2, 2, 0, false, true, FUSED_LDSDMA),
-    FUSED(8, 3, 2, 2, 0, false, true, FUSED_DIRECT),
+    FUSED(8, 3, 2, 1, 0, false, true, FUSED_LDSDMA, 0),
+    FUSED(8, 3, 2, 1, 0, false, true, FUSED_DIRECT, 0),
+    FUSED(6, 3, 2, 1, 0, false, true, FUSED_DIRECT, 0),
+    FUSED(4, 3, 2, 1, 0, false, true, FUSED_DIRECT, 0),
+    FUSED(2, 3, 2, 1, 0, false, true, FUSED_DIRECT, 0),
+    FUSED(2, 2, 2, 1, 0, false, true, FUSED_DIRECT, 0),
+    FUSED(8, 3, 2, 2, 0, false, true, FUSED_LDSDMA, 0),
+    FUSED(8, 3, 2, 2, 0, false, true, FUSED_DIRECT, 0),
 };
+// exact class-count specialisation first, then the any-count instantiation of the same shape
 const FusedEntry *find_fused(const BnmFusedShape &sh, int variant) {
-    for (const FusedEntry &e : kFused)
-        if (e.sh == sh && e.variant == variant) return &e;
+    for (int pass = 0; pass < 2; pass++) {
+        BnmFusedShape want = sh;
+        if (pass) want.nc8 = 0;
+        for (const FusedEntry &e : kFused)
+            if (e.sh == want && e.variant == variant) return &e;
+    }
     return nullptr;
 }
 }  // namespace
@@ -454,6 +602,7 @@ bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fu
 // measured best first (profiles/r01): two tiles in flight pays when a tile carries real work (64-wide layers:
 // 4.65 vs 4.73 ms per 1e8 images); for the 16-wide 1k model the plain one-ahead loop is faster (4.40 vs 4.77 ms)
 int bnmk_fused_default_variant(const BnmFusedShape &sh) {
+    if (find_fused(sh, FUSED_DUAL)) return FUSED_DUAL;
     if (sh.M[0] >= 2 && find_fused(sh, FUSED_LDSDMA2)) return FUSED_LDSDMA2;
     return find_fused(sh, FUSED_LDSDMA) ? FUSED_LDSDMA : FUSED_DIRECT;
 }
@@ -462,6 +611,26 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
     const FusedEntry *e = find_fused(sh, variant);
     if (!e) return hipErrorInvalidValue;
     if (a.n == 0) return hipSuccess;
+    if (variant == FUSED_DUAL) {
+        // whole 64-image pairs go to the dual-tile kernel, the remainder (< 64 images) to variant 2
+        const uint64_t n_main = a.n & ~63ull;
+        if (n_main) {
+            uint64_t want = ((n_main >> 6) + FUSED_WPB - 1) / FUSED_WPB;
+            uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * 2ull;
+            e->fn<<<dim3((unsigned)(want < cap ? want : cap)), dim3(64 * FUSED_WPB), 0, s>>>(
+                a.images, n_main, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap);
+            hipError_t err = hipGetLastError();
+            if (err != hipSuccess) return err;
+        }
+        if (a.n == n_main) return hipSuccess;
+        BnmFusedArgs t = a;
+        t.images = a.images + n_main * 256ull;
+        t.n = a.n - n_main;
+        t.cls = a.cls + n_main;
+        t.logits = a.logits ? a.logits + n_main * a.n_classes : nullptr;
+        t.src_wrap = 0;
+        return bnmk_fused_fc(sh, FUSED_LDSDMA2, grid_blocks, t, s);
+    }
     uint64_t n_tiles = (a.n + 31ull) / 32ull;
     uint64_t want = (n_tiles + FUSED_WPB - 1) / FUSED_WPB;
     // persistent grid: 8 resident waves per CU (2 workgroups x 4 waves; VGPRs and LDS allow no more)

@@ -17,9 +17,11 @@ hipError_t bnmk_unpack_rows(const void *d_packed, int32_t bpw, uint32_t n_input,
                             hipStream_t s);
 // kmap 0: natural K order (layer fed by the raw image); 1: K order of the previous layer's packed
 // ReLUNorm output (see DESIGN.md §fragment layout).  dst: MT*KT fragments of 64 lanes x 16 B.
+// pad_row_weight: weight given to rows >= n_output on the real input columns — 0 for hidden layers (ReLUNorm must
+// see 0 there), -128 for the classifier layer (argmax_rows in bnm_fused_fc.hip relies on it).
 hipError_t bnmk_build_fragments(const int8_t *d_rows, uint32_t row_stride, uint32_t n_output,
-                                uint32_t n_real, uint32_t MT, uint32_t KT, int kmap, int scale, void *d_dst,
-                                hipStream_t s);
+                                uint32_t n_real, uint32_t MT, uint32_t KT, int kmap, int scale, int pad_row_weight,
+                                void *d_dst, hipStream_t s);
 
 // ---- fused whole-model FC kernel (int8 MFMA) -------------------------------------------------
 struct BnmFusedShape {
@@ -27,9 +29,10 @@ struct BnmFusedShape {
     int M[4];       // 32-row tiles of each FC layer's outputs; M[3] == 0 for 3-layer models
     bool split;     // FP1.3.0: two A passes per K-step
     bool dbl;       // hidden-layer weight fragments doubled (every codec except 8-bit and FP1.3.0)
+    int nc8;        // ceil(n_classes / 8); kernels specialised on it skip accumulator registers without class rows
     bool operator==(const BnmFusedShape &o) const {
         return KT0 == o.KT0 && M[0] == o.M[0] && M[1] == o.M[1] && M[2] == o.M[2] && M[3] == o.M[3] &&
-               split == o.split && dbl == o.dbl;
+               split == o.split && dbl == o.dbl && nc8 == o.nc8;
     }
 };
 struct BnmFusedArgs {
@@ -42,7 +45,7 @@ struct BnmFusedArgs {
     uint64_t src_wrap = 0;  // diagnostics: read tile (t mod src_wrap) — keeps the source cache-resident
 };
 // variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (256-byte rows only), 2 = LDS-DMA with two
-// tiles in flight per wave (default where instantiated)
+// tiles in flight per wave, 3 = two tiles computed per wave per iteration (default where instantiated)
 bool bnmk_fused_supported(const BnmFusedShape &sh, int variant);
 hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a,
                          hipStream_t s);

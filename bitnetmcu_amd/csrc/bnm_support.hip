@@ -116,7 +116,7 @@ hipError_t bnmk_unpack_rows(const void *packed, int32_t bpw, uint32_t n_input, u
 // scale: 1, or 2 for hidden layers of the "doubled" kernels (see relunorm_pack<MT, true>).
 __global__ __launch_bounds__(256) void build_fragments_kernel(const int8_t *rows, uint32_t stride, uint32_t n_output,
                                                               uint32_t n_real, uint32_t MT, uint32_t KT, int kmap,
-                                                              int scale, uint32_t *dst) {
+                                                              int scale, int pad_row_weight, uint32_t *dst) {
     uint32_t total = MT * KT * 64u * 4u;   // dwords
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         uint32_t j = i & 3u, lane = (i >> 2) & 63u, frag = i >> 8;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void build_fragments_kernel(const int8_t *rows
 #pragma unroll
         for (uint32_t b = 0; b < 4; b++) {
             uint32_t k = kmap == 0 ? 32u * s + 16u * h + 4u * j + b : 32u * s + 8u * j + 4u * h + b;
-            int w = (row < n_output && k < n_real) ? (int)rows[(size_t)row * stride + k] * scale : 0;
+            int w = k >= n_real ? 0 : row < n_output ? (int)rows[(size_t)row * stride + k] * scale : pad_row_weight;
             v |= (uint32_t)(uint8_t)(int8_t)w << (8u * b);
         }
         dst[i] = v;
@@ -134,11 +134,11 @@ __global__ __launch_bounds__(256) void build_fragments_kernel(const int8_t *rows
 }
 
 hipError_t bnmk_build_fragments(const int8_t *rows, uint32_t stride, uint32_t n_output, uint32_t n_real, uint32_t MT,
-                                uint32_t KT, int kmap, int scale, void *dst, hipStream_t s) {
+                                uint32_t KT, int kmap, int scale, int pad_row_weight, void *dst, hipStream_t s) {
     uint32_t total = MT * KT * 256u;
     if (!total) return hipSuccess;
     build_fragments_kernel<<<dim3((total + 255u) / 256u), dim3(256), 0, s>>>(rows, stride, n_output, n_real, MT, KT, kmap,
-                                                                             scale, (uint32_t *)dst);
+                                                                             scale, pad_row_weight, (uint32_t *)dst);
     return hipGetLastError();
 }
 

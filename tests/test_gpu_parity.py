@@ -19,7 +19,7 @@ def paths_for(ctx):
     """(label, setup) for every kernel path this model can run."""
     out = [("auto", lambda c: c.set_path(b.PATH_AUTO))]
     out.append(("layerwise", lambda c: c.set_path(b.PATH_LAYERWISE_ALU)))
-    for v in (0, 1, 2):
+    for v in (0, 1, 2, 3):
         def fused(c, v=v):
             c.set_path(b.PATH_FUSED_MFMA)
             c.set_tuning(variant=v)
@@ -164,9 +164,9 @@ def test_device_pointer_api_does_not_touch_neighbours(gpu_ok, orc):
     import torch
     model = util.load_golden_model("fc_4bitsym_64")
     ctx = b.Context(model)
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         ctx.set_tuning(variant=variant)
-        for n in (1, 33, 1000, 70000):
+        for n in (1, 33, 63, 64, 65, 1000, 70000):
             imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
             synth.fill_device(imgs, first=9, dist=DIST_U)
             cls = torch.full((n + 64,), -7, dtype=torch.int32, device="cuda")
