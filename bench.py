@@ -219,10 +219,11 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": {1: "fused_fc_kernel", 2: "fc_layer_bitserial_kernel+relunorm_kernel", 3: "ternary_alu_kernel"}.get(ctx.path, "?")
+                "kernel": {1: "fused_fc_dual_kernel" if ctx.variant == 3 else "fused_fc_kernel", 2: "fc_layer_bitserial_kernel+relunorm_kernel", 3: "ternary_alu_kernel"}.get(ctx.path, "?")
                           + ("+cnn_front_kernel" if model.kind == b.KIND_CNN else ""),
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": n * bpi,
+                "fused_variant": ctx.variant,
             },
             "verified_vs_oracle": verified,
             "class_histogram": hist.tolist(),

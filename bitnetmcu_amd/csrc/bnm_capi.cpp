@@ -430,6 +430,10 @@ int bnm_ctx_set_path(bnm_ctx *c, int path) {
 }
 
 int bnm_ctx_get_path(const bnm_ctx *c) { return c ? c->path : BNM_EINVAL; }
+int bnm_ctx_get_variant(const bnm_ctx *c) {
+    if (!c) return BNM_EINVAL;
+    return c->path == BNM_PATH_FUSED_MFMA && c->fused_ok ? c->variant : -1;
+}
 
 int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
     if (!c) return fail(BNM_EINVAL, "null ctx");

@@ -111,6 +111,11 @@ class Context:
     def path(self):
         return self._lib.bnm_ctx_get_path(self._h)
 
+    @property
+    def variant(self):
+        """fused-kernel variant in use (-1 when the resolved path is not the fused kernel)"""
+        return self._lib.bnm_ctx_get_variant(self._h)
+
     def set_path(self, path):
         L.check(self._lib, self._lib.bnm_ctx_set_path(self._h, path), "bnm_ctx_set_path")
 

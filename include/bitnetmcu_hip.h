@@ -132,9 +132,12 @@ BNM_API int bnm_ctx_device(const bnm_ctx *c);
 #define BNM_PATH_TERNARY_ALU 3     /* fused sign-accumulate kernel, no MFMA (ternary models) */
 BNM_API int bnm_ctx_set_path(bnm_ctx *c, int path);
 BNM_API int bnm_ctx_get_path(const bnm_ctx *c);   /* the path AUTO resolved to */
-/* Tuning knobs of the fused kernel: variant id (0 direct loads, 1 LDS-DMA, 2 LDS-DMA with two tiles in flight;
- * -1 keeps the current one) and grid size (workgroups; 0 = default). */
+/* Tuning knobs of the fused kernel: variant id (0 direct loads, 1 LDS-DMA, 2 LDS-DMA with two tiles in flight,
+ * 3 two tiles per wavefront per iteration; -1 keeps the current one) and grid size
+ * (workgroups; 0 = default).  BNM_EUNSUPPORTED if the model's shape has no such instantiation. */
 BNM_API int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks);
+/* the fused-kernel variant in use, or -1 when the resolved path is not the fused kernel */
+BNM_API int bnm_ctx_get_variant(const bnm_ctx *c);
 
 /* Whole-model batched inference, DEVICE pointers, asynchronous on `stream` (a hipStream_t;
  * NULL = default stream).  images: int8 [n][256]; cls: uint32 [n]; logits: int32
