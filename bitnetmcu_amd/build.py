@@ -40,7 +40,7 @@ def objects(force=False):
            [os.path.join(HERE, "..", "include", "bitnetmcu_hip.h")]
     out, jobs = [], []
     for src, is_hip in (("bnm_fused_fc.hip", True), ("bnm_cnn.hip", True), ("bnm_ternary.hip", True), ("bnm_layerwise.hip", True),
-                        ("bnm_support.hip", True), ("bnm_capi.cpp", False), ("bnm_model.cpp", False)):
+                        ("bnm_support.hip", True), ("bnm_qat.hip", True), ("bnm_capi.cpp", False), ("bnm_model.cpp", False)):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or newer([s] + hdrs, o):

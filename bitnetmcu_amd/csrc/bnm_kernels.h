@@ -88,3 +88,9 @@ hipError_t bnmk_diag_stream(const int8_t *d_images, uint64_t n, int mode, int gr
 // ---- input quantisation: float32 [n][256] -> int8 [n][256] (test_inference.py:140-141) --------------
 hipError_t bnmk_quantize_input(const float *d_x, uint64_t n, int8_t *d_out, hipStream_t s);
 hipError_t bnmk_diag_pipes(int mode, uint64_t tiles_per_wave, uint32_t *d_out, hipStream_t s);   // modes 5/6/7: pipe overlap probe
+
+// ---- QAT forward op (bnm_qat.hip) ---------------------------------------
+size_t bnmk_qat_workspace_bytes(uint32_t d, uint32_t k);
+hipError_t bnmk_qat_bitlinear_forward(const float *d_x, uint64_t n, uint32_t d, const float *d_w, uint32_t k,
+                                      const float *d_s, uint32_t s_count, int quant_type, int norm_type, float *d_y,
+                                      float *d_workspace, float *d_x_int_out, float *d_x_scale_out, hipStream_t s);

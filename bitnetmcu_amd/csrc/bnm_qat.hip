@@ -1,0 +1,275 @@
+// the forward pass of the reference's quantisation-aware-training layer BitLinear
+// (BitNetMCU.py:198-235: Normalize -> activation_quant -> weight_quant -> F.linear) as fused gfx950 kernels.
+// Floating point; parity is against PyTorch fp32 within a stated tolerance (tests/test_gpu_qat.py), not bit-exact.
+//
+// Formulation.  The reference multiplies x_int / x_scale by w_int / w_scale in fp32.  x_int are integers in
+// [-128, 127] and the weight levels w_int are small integers or half-integers for every QuantType except '4bit'
+// (+0.01) and 'NF4', so the products and their fp32 sums over d <= 1024 are EXACT on the fp32 matrix cores
+// (|sum| < 2^24); the two scales are applied once per output.  The result is therefore at least as accurate as
+// the reference's own fp32 GEMM, and differs from it only by that GEMM's rounding.
+//
+//   qat_weight_stats_kernel   mean|w|, mean(w) of the whole tensor (Ternary's scale, Binary's offset)
+//   qat_weight_quant_kernel   w [k][d] -> levels u, stored transposed uT [dpad][kpad] (coalesced A operands),
+//                             and the per-output scale w_scale [kpad]
+//   qat_batch_stats_kernel    per-feature mean and sqrt(var + 1e-5) over the batch (NormType BatchNorm only)
+//   qat_bitlinear_fwd_kernel  32 rows per workgroup: normalise + quantise each row into an LDS tile (one
+//                             wavefront per row), then Y^T[32 outs x 32 rows] tiles on v_mfma_f32_32x32x2_f32
+#include "bnm_device.hpp"
+#include "../../include/bitnetmcu_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int QAT_ROWS = 32;    // rows of x per workgroup (= MFMA N)
+constexpr int QAT_WAVES = 4;
+
+BNM_DEVICE float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+BNM_DEVICE float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// weight_quant's scale (BitNetMCU.py:136-148)
+BNM_DEVICE float qat_weight_scale(int qt, float s, float mean_abs) {
+    switch (qt) {
+        case BNM_QAT_NONE: return 1.0f;
+        case BNM_QAT_FP130: return __fdiv_rn(128.0f, s);
+        case BNM_QAT_NF4: return __fdiv_rn(1.0f, s);
+        case BNM_QAT_TERNARY: return __fdiv_rn(1.0f, fmaxf(mean_abs, 1e-5f));
+        case BNM_QAT_BINARY:
+        case BNM_QAT_BINARYSYM: return __fdiv_rn(1.0f, s);            // 2^(1-1) / s
+        case BNM_QAT_2BITSYM: return __fdiv_rn(2.0f, s);
+        case BNM_QAT_4BIT:
+        case BNM_QAT_4BITSYM: return __fdiv_rn(8.0f, s);
+        case BNM_QAT_5BITSYM: return __fdiv_rn(16.0f, s);
+        case BNM_QAT_8BIT: return __fdiv_rn(128.0f, s);
+    }
+    return 1.0f;
+}
+
+BNM_DEVICE float sign_of(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+// weight_quant's level for one weight (BitNetMCU.py:150-177).  Explicit __fmul_rn/__fsub_rn: the reference rounds
+// after the multiply, so the compiler must not contract w*scale - 0.5 into one fma.
+BNM_DEVICE float qat_weight_level(int qt, float w, float sc, float mean_w) {
+    const float ws = __fmul_rn(w, sc);
+    switch (qt) {
+        case BNM_QAT_NONE: return w;
+        case BNM_QAT_TERNARY: return fminf(fmaxf(rintf(ws), -1.0f), 1.0f);
+        case BNM_QAT_BINARY: return sign_of(__fsub_rn(w, mean_w));
+        case BNM_QAT_BINARYSYM: return sign_of(w);
+        case BNM_QAT_2BITSYM: return __fadd_rn(fminf(fmaxf(rintf(__fsub_rn(ws, 0.5f)), -2.0f), 1.0f), 0.5f);
+        case BNM_QAT_4BIT: return __fadd_rn(fminf(fmaxf(rintf(__fsub_rn(ws, 0.01f)), -8.0f), 7.0f), 0.01f);
+        case BNM_QAT_4BITSYM: return __fadd_rn(fminf(fmaxf(rintf(__fsub_rn(ws, 0.5f)), -8.0f), 7.0f), 0.5f);
+        case BNM_QAT_5BITSYM: return __fadd_rn(fminf(fmaxf(rintf(__fsub_rn(ws, 0.5f)), -16.0f), 15.0f), 0.5f);
+        case BNM_QAT_8BIT: return fminf(fmaxf(rintf(ws), -128.0f), 127.0f);
+        case BNM_QAT_FP130: {
+            // e = floor(log2|w*scale|) clamped to [0,7]; log2(0) = -inf clamps to 0 and sign(0) = 0 gives level 0
+            float e = fminf(fmaxf(floorf(log2f(fabsf(ws))), 0.0f), 7.0f);
+            return sign_of(w) * exp2f(e);
+        }
+        case BNM_QAT_NF4: {
+            const float lv[16] = {-1.0f, -0.6962f, -0.5251f, -0.3949f, -0.2844f, -0.1848f, -0.0911f, 0.0f,
+                                  0.0796f, 0.1609f, 0.2461f, 0.3379f, 0.4407f, 0.5626f, 0.723f, 1.0f};
+            int best = 0;
+            float bd = fabsf(__fsub_rn(ws, lv[0]));
+#pragma unroll
+            for (int i = 1; i < 16; i++) {
+                float dd = fabsf(__fsub_rn(ws, lv[i]));
+                if (dd < bd) { bd = dd; best = i; }   // argmin keeps the first minimum
+            }
+            return lv[best];
+        }
+    }
+    return 0.0f;
+}
+}  // namespace
+
+// stats[0] = mean|w|, stats[1] = mean(w); one workgroup, fixed reduction order (deterministic)
+__global__ __launch_bounds__(1024) void qat_weight_stats_kernel(const float *__restrict__ w, uint64_t count,
+                                                                float *__restrict__ stats) {
+    __shared__ double sa[16], sw[16];
+    double a = 0.0, b = 0.0;
+    for (uint64_t i = threadIdx.x; i < count; i += 1024) {
+        float v = w[i];
+        a += fabsf(v);
+        b += v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+    }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sw[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int i = 0; i < 16; i++) { ta += sa[i]; tb += sw[i]; }
+        stats[0] = (float)(ta / (double)count);
+        stats[1] = (float)(tb / (double)count);
+    }
+}
+
+// one thread per weight; uT and w_scale are zero-filled by the launcher first (padding rows/columns stay 0)
+__global__ __launch_bounds__(256) void qat_weight_quant_kernel(const float *__restrict__ w, uint32_t k, uint32_t d,
+                                                               const float *__restrict__ s, uint32_t s_count, int qt,
+                                                               const float *__restrict__ stats, uint32_t kpad,
+                                                               float *__restrict__ uT, float *__restrict__ w_scale) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (uint64_t)k * d) return;
+    const uint32_t row = (uint32_t)(idx / d), col = (uint32_t)(idx % d);
+    const float sc = qat_weight_scale(qt, s[s_count > 1 ? row : 0], stats[0]);
+    uT[(uint64_t)col * kpad + row] = qat_weight_level(qt, w[idx], sc, stats[1]);
+    if (col == 0) w_scale[row] = sc;
+}
+
+// BatchNorm statistics over the batch dimension (BitNetMCU.py:247-250): one thread per feature, rows are walked in
+// order so a wavefront reads 256 contiguous bytes per row
+__global__ __launch_bounds__(256) void qat_batch_stats_kernel(const float *__restrict__ x, uint64_t n, uint32_t d,
+                                                              float *__restrict__ mean, float *__restrict__ den) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= d) return;
+    double sum = 0.0;
+    for (uint64_t r = 0; r < n; r++) sum += x[r * d + c];
+    const float m = (float)(sum / (double)n);
+    double var = 0.0;
+    for (uint64_t r = 0; r < n; r++) {
+        double t = (double)x[r * d + c] - (double)m;
+        var += t * t;
+    }
+    mean[c] = m;
+    den[c] = sqrtf((float)(var / (double)n) + 1e-5f);
+}
+
+// dynamic LDS: q tile [32][dpad + 1] floats (odd row stride: conflict-free column reads) + 32 row scales
+__global__ __launch_bounds__(64 * QAT_WAVES) void qat_bitlinear_fwd_kernel(
+    const float *__restrict__ x, uint64_t n, uint32_t d, uint32_t dpad, const float *__restrict__ uT,
+    const float *__restrict__ w_scale, uint32_t k, uint32_t kpad, int qt, int nt, const float *__restrict__ bn_mean,
+    const float *__restrict__ bn_den, float *__restrict__ y, float *__restrict__ x_int_out,
+    float *__restrict__ x_scale_out) {
+    extern __shared__ float lds[];
+    const uint32_t rs = dpad + 1u;
+    float *q = lds;
+    float *xs = lds + QAT_ROWS * rs;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t row0 = (uint64_t)blockIdx.x * QAT_ROWS;
+
+    // ---- phase 1: Normalize (:237-262) + activation_quant (:119-128), one wavefront per row ------------------
+    for (int r = wave; r < QAT_ROWS; r += QAT_WAVES) {
+        float *qr = q + r * rs;
+        const uint64_t row = row0 + (uint64_t)r;
+        if (row >= n) {
+            for (uint32_t c = lane; c < rs; c += 64) qr[c] = 0.0f;
+            if (lane == 0) xs[r] = 1.0f;
+            continue;
+        }
+        const float *xr = x + row * d;
+        float a = 0.0f, b = 0.0f;
+        for (uint32_t c = lane; c < d; c += 64) {
+            float v = xr[c];
+            qr[c] = v;
+            a += nt == BNM_QAT_NORM_RMS ? v * v : (nt == BNM_QAT_NORM_LIN ? fabsf(v) : v);
+        }
+        if (lane == 0 && (d & 1u)) qr[d] = 0.0f;       // K padding to an even length
+        a = wave_sum(a);
+        float sub = 0.0f, den = 1.0f;
+        if (nt == BNM_QAT_NORM_RMS) den = sqrtf(a / (float)d);
+        else if (nt == BNM_QAT_NORM_LIN) den = a / (float)d;
+        else if (nt == BNM_QAT_NORM_LAYERNORM) {
+            sub = a / (float)d;
+            for (uint32_t c = lane; c < d; c += 64) {
+                float t = qr[c] - sub;
+                b += t * t;
+            }
+            den = sqrtf(wave_sum(b) / (float)d + 1e-5f);
+        }
+        float mx = 0.0f;
+        for (uint32_t c = lane; c < d; c += 64) {
+            float v = qr[c];
+            if (nt == BNM_QAT_NORM_BATCHNORM) v = __fdiv_rn(__fsub_rn(v, bn_mean[c]), bn_den[c]);
+            else if (nt == BNM_QAT_NORM_LAYERNORM) v = __fdiv_rn(__fsub_rn(v, sub), den);
+            else if (nt != BNM_QAT_NORM_NONE) v = __fdiv_rn(v, den);
+            qr[c] = v;
+            mx = fmaxf(mx, fabsf(v));
+        }
+        if (qt == BNM_QAT_NONE) {
+            if (lane == 0) xs[r] = 1.0f;
+            continue;
+        }
+        mx = wave_max(mx);
+        const float sc = __fdiv_rn(127.0f, fmaxf(mx, 1e-5f));
+        for (uint32_t c = lane; c < d; c += 64) {
+            float v = fminf(fmaxf(rintf(__fmul_rn(qr[c], sc)), -128.0f), 127.0f);
+            qr[c] = v;
+            if (x_int_out) x_int_out[row * d + c] = v;
+        }
+        if (lane == 0) {
+            xs[r] = sc;
+            if (x_scale_out) x_scale_out[row] = sc;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: Y^T tile = U[32 outs x K] * Q^T[K x 32 rows] on the fp32 matrix cores ----------------------
+    const int i = lane & 31, h = lane >> 5;
+    const uint32_t mtiles = kpad / 32u;
+    for (uint32_t m = wave; m < mtiles; m += QAT_WAVES) {
+        f32x16 acc = {0};
+        const float *ap = uT + (uint64_t)h * kpad + 32u * m + i;   // A[out i][k = 2*s + h]
+        const float *bp = q + i * rs + h;                          // B[k = 2*s + h][row i]
+        for (uint32_t s2 = 0; s2 < dpad / 2u; s2++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(uint64_t)2u * s2 * kpad], bp[2u * s2], acc, 0, 0, 0);
+        const uint64_t row = row0 + (uint64_t)i;
+        if (row >= n) continue;
+        const float xsc = xs[i];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t out = 32u * m + (r & 3) + 8u * (r >> 2) + 4u * h;
+            if (out < k) {
+                float v = acc[r];
+                if (qt != BNM_QAT_NONE) v = __fdiv_rn(__fdiv_rn(v, xsc), w_scale[out]);
+                y[row * k + out] = v;
+            }
+        }
+    }
+}
+
+size_t bnmk_qat_workspace_bytes(uint32_t d, uint32_t k) {
+    const size_t dpad = (d + 1u) & ~1u, kpad = (k + 31u) & ~31u;
+    return (dpad * kpad + kpad + 4u + 2u * (size_t)d) * sizeof(float);
+}
+
+hipError_t bnmk_qat_bitlinear_forward(const float *x, uint64_t n, uint32_t d, const float *w, uint32_t k, const float *s,
+                                      uint32_t s_count, int qt, int nt, float *y, float *workspace, float *x_int_out,
+                                      float *x_scale_out, hipStream_t st) {
+    const uint32_t dpad = (d + 1u) & ~1u, kpad = (k + 31u) & ~31u;
+    float *uT = workspace;
+    float *w_scale = uT + (size_t)dpad * kpad;
+    float *stats = w_scale + kpad;
+    float *bn_mean = stats + 4, *bn_den = bn_mean + d;
+    hipError_t e = hipMemsetAsync(workspace, 0, ((size_t)dpad * kpad + kpad + 4u) * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    if (n == 0) return hipSuccess;
+    if (qt == BNM_QAT_TERNARY || qt == BNM_QAT_BINARY)
+        qat_weight_stats_kernel<<<dim3(1), dim3(1024), 0, st>>>(w, (uint64_t)k * d, stats);
+    const uint64_t cnt = (uint64_t)k * d;
+    qat_weight_quant_kernel<<<dim3((unsigned)((cnt + 255u) / 256u)), dim3(256), 0, st>>>(w, k, d, s, s_count, qt, stats, kpad, uT,
+                                                                                   w_scale);
+    if (nt == BNM_QAT_NORM_BATCHNORM)
+        qat_batch_stats_kernel<<<dim3((d + 255u) / 256u), dim3(256), 0, st>>>(x, n, d, bn_mean, bn_den);
+    const size_t lds_bytes = ((size_t)QAT_ROWS * (dpad + 1u) + QAT_ROWS) * sizeof(float);
+    if (lds_bytes > 64u * 1024u) {
+        e = hipFuncSetAttribute((const void *)qat_bitlinear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const uint64_t blocks = (n + QAT_ROWS - 1) / QAT_ROWS;
+    qat_bitlinear_fwd_kernel<<<dim3((unsigned)blocks), dim3(64 * QAT_WAVES), lds_bytes, st>>>(
+        x, n, d, dpad, uT, w_scale, k, kpad, qt, nt, bn_mean, bn_den, y, x_int_out, x_scale_out);
+    return hipGetLastError();
+}

@@ -1,0 +1,211 @@
+"""QAT forward op — SURVEY.md §8(f) row 4.
+
+The reference trains with `BitLinear` (BitNetMCU.py:198-262): Normalize -> activation_quant -> weight_quant ->
+F.linear, with the straight-through estimator written as `x + (q(x) - x).detach()`.  Here the forward pass is the
+fused gfx950 op `bnm_qat_bitlinear_forward_device` (csrc/bnm_qat.hip); `BitLinear` below mirrors the reference
+layer's constructor, attributes and `update_clipping_scalar` so it can stand in for it in `BitNetMCU.py`'s models.
+
+What is and is not native:
+  * forward on CUDA tensors: native, one weight-quant launch + one fused normalise/quantise/GEMM launch;
+  * backward: the straight-through gradient is obtained by re-running `ste_formula` (the reference's expression,
+    restated below) under autograd — plain PyTorch ops, not a HIP kernel (training is minutes-long on MNIST; row 4 is
+    the lowest-ranked "next" item);
+  * CPU tensors: refused.  There is no CPU implementation of the op in the product path.
+  * `BitConv2d` (BitNetMCU.py:264-322) is not built.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+
+QUANT_TYPES = {"None": 0, "Binary": 1, "BinarySym": 2, "Ternary": 3, "2bitsym": 4, "4bit": 5, "4bitsym": 6, "FP130": 7,
+               "NF4": 8, "5bitsym": 9, "8bit": 10}
+NORM_TYPES = {"RMS": 0, "Lin": 1, "BatchNorm": 2, "LayerNorm": 3, "None": 4}
+# bits per weight as BitQuant.__init__ assigns them (BitNetMCU.py:53-66)
+BPW = {"Binary": 1, "BinarySym": 1, "2bitsym": 2, "Ternary": 1.6, "4bit": 4, "4bitsym": 4, "FP130": 4, "NF4": 4,
+       "5bitsym": 5, "8bit": 8}
+NF4_LEVELS = [-1.0, -0.6962, -0.5251, -0.3949, -0.2844, -0.1848, -0.0911, 0.0, 0.0796, 0.1609, 0.2461, 0.3379, 0.4407,
+              0.5626, 0.723, 1.0]
+
+_workspaces = {}
+
+
+def _workspace(device, d, k):
+    key = (device.index, d, k)
+    ws = _workspaces.get(key)
+    if ws is None:
+        nbytes = int(L.load().bnm_qat_workspace_bytes(d, k))
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def bitlinear_forward(x, w, s, quant_type, norm_type, return_int=False):
+    """y = F.linear(act_quant(Normalize(x)), weight_quant(w)) on the GPU.
+    x [n,d], w [k,d], s scalar or [k]/[k,1] (the layer's clipping scalar), all float32 CUDA tensors.
+    return_int: also return activation_quant's integers [n,d] and scales [n]."""
+    if not (x.is_cuda and w.is_cuda):
+        raise RuntimeError("bitlinear_forward is a GPU op: x and w must be CUDA tensors (there is no CPU path)")
+    lib = L.load()
+    qt, nt = QUANT_TYPES[quant_type], NORM_TYPES[norm_type]
+    x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+    w2 = w.contiguous().float()
+    s2 = torch.as_tensor(s, dtype=torch.float32, device=x.device).reshape(-1).contiguous()
+    n, d = x2.shape
+    k = w2.shape[0]
+    if w2.shape[1] != d:
+        raise ValueError("w must be [k, d]")
+    y = torch.empty((n, k), dtype=torch.float32, device=x.device)
+    xi = torch.empty((n, d), dtype=torch.float32, device=x.device) if return_int else None
+    xsc = torch.empty((n,), dtype=torch.float32, device=x.device) if return_int else None
+    ws = _workspace(x.device, d, k)
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        L.check(lib, lib.bnm_qat_bitlinear_forward_device(
+            C.c_void_p(x2.data_ptr()), n, d, C.c_void_p(w2.data_ptr()), k, C.c_void_p(s2.data_ptr()), s2.numel(), qt, nt,
+            C.c_void_p(y.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel() * 4,
+            C.c_void_p(xi.data_ptr()) if return_int else None, C.c_void_p(xsc.data_ptr()) if return_int else None,
+            C.c_void_p(stream)), "bnm_qat_bitlinear_forward_device")
+    y = y.reshape(*x.shape[:-1], k)
+    return (y, xi, xsc) if return_int else y
+
+
+# ---- the reference's expression, restated (used for the straight-through backward and pinned by
+# ---- tests/test_qat_cpu.py against fixtures generated from the reference module itself) -------------------------
+def normalize(x, norm_type):
+    """BitLinear.Normalize (BitNetMCU.py:237-262)."""
+    if norm_type == "RMS":
+        return x / torch.sqrt(torch.mean(x ** 2, dim=-1, keepdim=True))
+    if norm_type == "Lin":
+        return x / torch.mean(torch.abs(x), dim=-1, keepdim=True)
+    if norm_type == "BatchNorm":
+        return (x - torch.mean(x, dim=0, keepdim=True)) / torch.sqrt(torch.var(x, dim=0, keepdim=True, unbiased=False) + 1e-5)
+    if norm_type == "LayerNorm":
+        return (x - torch.mean(x, dim=-1, keepdim=True)) / torch.sqrt(torch.var(x, dim=-1, keepdim=True, unbiased=False) + 1e-5)
+    if norm_type == "None":
+        return x
+    raise AssertionError(f"Invalid NormType: {norm_type}")
+
+
+def activation_quant(x):
+    """BitQuant.activation_quant (BitNetMCU.py:119-128): per-row 8-bit absmax."""
+    scale = 127.0 / x.abs().max(dim=-1, keepdim=True).values.clamp(min=1e-5)
+    return (x * scale).round().clamp(-128, 127), scale
+
+
+def weight_quant(w, s, quant_type):
+    """BitQuant.weight_quant (BitNetMCU.py:130-177): levels u and scale."""
+    if quant_type == "FP130":
+        scale = 128.0 / s
+    elif quant_type == "NF4":
+        scale = 1.0 / s
+    elif quant_type == "Ternary":
+        scale = 1.0 / w.abs().mean().clamp(min=1e-5)
+    else:
+        scale = (2.0 ** (BPW[quant_type] - 1)) / s
+    if quant_type == "Ternary":
+        u = (w * scale).round().clamp(-1, 1)
+    elif quant_type == "Binary":
+        u = (w - w.mean()).sign()
+    elif quant_type == "BinarySym":
+        u = w.sign()
+    elif quant_type == "2bitsym":
+        u = (w * scale - 0.5).round().clamp(-2, 1) + 0.5
+    elif quant_type == "4bit":
+        u = (w * scale - 0.01).round().clamp(-8, 7) + 0.01
+    elif quant_type == "4bitsym":
+        u = (w * scale - 0.5).round().clamp(-8, 7) + 0.5
+    elif quant_type == "5bitsym":
+        u = (w * scale - 0.5).round().clamp(-16, 15) + 0.5
+    elif quant_type == "8bit":
+        u = (w * scale).round().clamp(-128, 127)
+    elif quant_type == "FP130":
+        e = (w * scale).abs().log2().floor().clamp(0, 7)
+        u = w.sign() * e.exp2()
+    elif quant_type == "NF4":
+        levels = torch.tensor(NF4_LEVELS, device=w.device)
+        u = levels[torch.argmin(torch.abs((w * scale).unsqueeze(-1) - levels), dim=-1)]
+    else:
+        raise AssertionError(f"Invalid QuantType: {quant_type}")
+    return u, scale
+
+
+def ste_formula(x, w, s, quant_type, norm_type):
+    """BitLinear.forward (BitNetMCU.py:214-235) as differentiable PyTorch ops (straight-through estimator)."""
+    x_norm = normalize(x, norm_type)
+    if quant_type == "None":
+        return F.linear(x_norm, w)
+    if torch.is_tensor(s) and s.numel() > 1:
+        s = s.reshape(-1, 1)          # PerOutput: one clipping scalar per weight row
+    x_int, x_scale = activation_quant(x_norm)
+    x_quant = x_norm + (x_int / x_scale - x_norm).detach()
+    w_int, w_scale = weight_quant(w, s, quant_type)
+    w_quant = w + (w_int / w_scale - w).detach()
+    return F.linear(x_quant, w_quant)
+
+
+class _BitLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, s, quant_type, norm_type):
+        ctx.save_for_backward(x, w, s)
+        ctx.qn = (quant_type, norm_type)
+        return bitlinear_forward(x, w, s, quant_type, norm_type)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, s = ctx.saved_tensors
+        with torch.enable_grad():
+            xr = x.detach().requires_grad_(True)
+            wr = w.detach().requires_grad_(True)
+            y = ste_formula(xr, wr, s.detach(), *ctx.qn)
+            gx, gw = torch.autograd.grad(y, (xr, wr), gy)
+        return gx, gw, None, None, None
+
+
+class BitLinear(nn.Linear):
+    """Stand-in for the reference's BitLinear (BitNetMCU.py:198-262): same constructor, `weight`, `s`, `bpw`,
+    `QuantType`, `WScale`, `NormType`, `update_clipping_scalar`; forward runs the fused HIP op on CUDA inputs."""
+
+    def __init__(self, in_features, out_features, bias=False, QuantType="Binary", WScale="PerTensor", NormType="RMS"):
+        super().__init__(in_features, out_features, bias=False)
+        if QuantType != "None" and QuantType not in BPW:
+            raise AssertionError(f"Invalid QuantType: {QuantType}")
+        if WScale not in ("PerOutput", "PerTensor"):
+            raise AssertionError(f"Invalid WScale: {WScale}. Expected one of: 'PerTensor', 'PerOutput'")
+        if NormType not in ("RMS", "Lin", "BatchNorm", "LayerNorm"):
+            raise AssertionError(f"Invalid NormType: {NormType}. Expected one of: 'RMS', 'Lin', 'BatchNorm', 'LayerNorm'")
+        self.QuantType, self.WScale, self.NormType = QuantType, WScale, NormType
+        self.bpw = BPW.get(QuantType, 0)
+        self.s = nn.Parameter(torch.tensor(1.0), requires_grad=False)
+
+    def forward(self, x):
+        return _BitLinearFn.apply(x, self.weight, self.s, self.QuantType, self.NormType)
+
+    def octav(self, tensor, num_iterations=10, s=-1):
+        """Optimum clipping scalar by Newton iteration (BitNetMCU.py:71-83; C. Sakr et al. 2022)."""
+        if s < 0:
+            s = tensor.abs().mean().clamp(min=1e-5) * 0.25
+        a = tensor.abs()
+        for _ in range(num_iterations):
+            inside = (a <= s).float()
+            outside = (a > s).float()
+            s = torch.sum(a * outside) / ((4 ** -self.bpw / 3) * torch.sum(inside) + torch.sum(outside))
+        return s
+
+    def update_clipping_scalar(self, w, algorithm="octav", quantscale=0.25):
+        """BitQuant.update_clipping_scalar (BitNetMCU.py:85-117)."""
+        s = self.s
+        if algorithm == "octav":
+            s = torch.stack([self.octav(row, 10) for row in w]) if self.WScale == "PerOutput" else self.octav(w, 10, s)
+        elif algorithm == "prop":
+            if self.WScale == "PerOutput":
+                s = w.abs().max(dim=-1, keepdim=True)[0].clamp(min=1e-5) / quantscale
+            else:
+                s = w.abs().mean().clamp(min=1e-5) / quantscale
+        else:
+            raise AssertionError(f"Invalid algorithm: {algorithm}. Expected one of: 'octav', 'prop'")
+        self.s = nn.Parameter(s.detach(), requires_grad=False)
+        return s

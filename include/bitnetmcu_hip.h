@@ -169,6 +169,36 @@ BNM_API int bnm_unpack_layer_host(const void *weights, int32_t bits_per_weight, 
  * d_x: float32 [n][256], d_out: int8 [n][256]; bit-identical to the numpy float32 formula. */
 BNM_API int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_out, void *stream);
 
+/* ---- QAT forward op ------------------------------------------------------
+ * The forward pass of the reference's training layer BitLinear (BitNetMCU.py:198-235):
+ *   y = F.linear(act_quant(Normalize(x)), weight_quant(w))        x [n][d], w [k][d], y [n][k], float32
+ * quant_type / norm_type name the reference's QuantType / NormType strings.  s: the layer's clipping scalar
+ * `self.s` (BitNetMCU.py:51; s_count 1 = PerTensor, k = PerOutput).  Floating point: parity with PyTorch is
+ * within tolerance (integer sums are exact on the fp32 matrix cores; see csrc/bnm_qat.hip), not bit-exact.
+ * x_int_out [n][d] / x_scale_out [n] (optional) return activation_quant's integers and scales.
+ * All pointers are DEVICE pointers; workspace must hold bnm_qat_workspace_bytes(d, k) bytes; d <= 1024. */
+#define BNM_QAT_NONE 0        /* 'None': no fake quantisation, plain linear on the normalised input */
+#define BNM_QAT_BINARY 1      /* 'Binary' */
+#define BNM_QAT_BINARYSYM 2   /* 'BinarySym' */
+#define BNM_QAT_TERNARY 3     /* 'Ternary' */
+#define BNM_QAT_2BITSYM 4     /* '2bitsym' */
+#define BNM_QAT_4BIT 5        /* '4bit' */
+#define BNM_QAT_4BITSYM 6     /* '4bitsym' */
+#define BNM_QAT_FP130 7       /* 'FP130' */
+#define BNM_QAT_NF4 8         /* 'NF4' */
+#define BNM_QAT_5BITSYM 9     /* '5bitsym' */
+#define BNM_QAT_8BIT 10       /* '8bit' */
+#define BNM_QAT_NORM_RMS 0        /* 'RMS' */
+#define BNM_QAT_NORM_LIN 1        /* 'Lin' */
+#define BNM_QAT_NORM_BATCHNORM 2  /* 'BatchNorm' */
+#define BNM_QAT_NORM_LAYERNORM 3  /* 'LayerNorm' */
+#define BNM_QAT_NORM_NONE 4       /* no normalisation (BitConv2d's 'None') */
+BNM_API uint64_t bnm_qat_workspace_bytes(uint32_t d, uint32_t k);
+BNM_API int bnm_qat_bitlinear_forward_device(const float *d_x, uint64_t n, uint32_t d, const float *d_w, uint32_t k,
+                                             const float *d_s, uint32_t s_count, int quant_type, int norm_type,
+                                             float *d_y, void *d_workspace, uint64_t workspace_bytes,
+                                             float *d_x_int_out, float *d_x_scale_out, void *stream);
+
 /* ---- synthetic workload + digests ---------------------------------------- */
 #define BNM_DIST_U 0
 #define BNM_DIST_M 1

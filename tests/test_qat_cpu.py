@@ -1,0 +1,77 @@
+"""QAT forward op, CPU side: the PyTorch restatement that provides the straight-through
+backward (bitnetmcu_amd/qat.py) is pinned against fixtures generated from the reference's own BitLinear
+(tests/golden/make_qat_golden.py), and the product op refuses CPU tensors instead of falling back."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from bitnetmcu_amd import qat
+from util import GOLDEN
+
+G = np.load(os.path.join(GOLDEN, "qat_bitlinear.npz"))
+QUANTS = ["Binary", "BinarySym", "Ternary", "2bitsym", "4bit", "4bitsym", "FP130", "NF4", "5bitsym", "8bit"]
+NORMS = ["RMS", "Lin", "BatchNorm", "LayerNorm"]
+
+
+def t(name):
+    return torch.from_numpy(G[name])
+
+
+@pytest.mark.parametrize("nt", NORMS)
+def test_normalize_and_activation_quant_equal_reference(nt):
+    x = t("a/x")
+    xn = qat.normalize(x, nt)
+    assert torch.equal(xn, t(f"a/{nt}/x_norm"))
+    xi, xs = qat.activation_quant(xn)
+    assert torch.equal(xi, t(f"a/{nt}/x_int")) and torch.equal(xs.reshape(-1), t(f"a/{nt}/x_scale"))
+
+
+@pytest.mark.parametrize("qt", QUANTS)
+def test_weight_quant_and_forward_equal_reference(qt):
+    x, w = t("a/x"), t("a/w")
+    for nt in NORMS:
+        s = t(f"a/{qt}/{nt}/s")
+        s = s[0] if s.numel() == 1 else s
+        u, sc = qat.weight_quant(w, s, qt)
+        assert torch.equal(u, t(f"a/{qt}/{nt}/w_int"))
+        assert torch.equal(torch.as_tensor(sc).reshape(-1), t(f"a/{qt}/{nt}/w_scale"))
+        assert torch.equal(qat.ste_formula(x, w, s, qt, nt), t(f"a/{qt}/{nt}/y"))
+
+
+def test_per_output_scale_and_odd_width():
+    for tag, qts in (("perout", ["4bitsym", "2bitsym"]), ("odd", ["4bitsym", "8bit"])):
+        x, w = t(f"{tag}/x"), t(f"{tag}/w")
+        for qt in qts:
+            s = t(f"{tag}/{qt}/RMS/s")
+            s = s[0] if s.numel() == 1 else s
+            assert torch.equal(qat.ste_formula(x, w, s, qt, "RMS"), t(f"{tag}/{qt}/RMS/y"))
+
+
+@pytest.mark.parametrize("qt,nt", [("4bitsym", "RMS"), ("Ternary", "Lin"), ("FP130", "LayerNorm"), ("2bitsym", "BatchNorm")])
+def test_straight_through_gradients_equal_reference(qt, nt):
+    x = t("a/x").clone().requires_grad_(True)
+    w = t("a/w").clone().requires_grad_(True)
+    y = qat.ste_formula(x, w, t(f"a/{qt}/{nt}/s")[0], qt, nt)
+    gx, gw = torch.autograd.grad(y, (x, w), t("a/gy"))
+    assert torch.equal(gx, t(f"a/{qt}/{nt}/gx")) and torch.equal(gw, t(f"a/{qt}/{nt}/gw"))
+
+
+def test_module_mirrors_reference_constructor_and_clipping_scalar():
+    layer = qat.BitLinear(202, 24, QuantType="4bitsym", NormType="RMS")
+    assert layer.bias is None and layer.bpw == 4 and layer.weight.shape == (24, 202) and not layer.s.requires_grad
+    with torch.no_grad():
+        layer.weight.copy_(t("a/w"))
+    s = layer.update_clipping_scalar(layer.weight.data, "prop", 0.25)
+    assert torch.equal(s.reshape(-1), t("a/4bitsym/RMS/s")) and torch.equal(layer.s.data.reshape(-1), t("a/4bitsym/RMS/s"))
+    assert float(layer.update_clipping_scalar(layer.weight.data, "octav")) > 0
+    for bad in (dict(QuantType="3bit"), dict(WScale="PerRow"), dict(NormType="Group")):
+        with pytest.raises(AssertionError):
+            qat.BitLinear(8, 8, **bad)
+
+
+def test_cpu_tensors_are_refused_not_emulated():
+    layer = qat.BitLinear(16, 4, QuantType="4bitsym")
+    with pytest.raises(RuntimeError, match="GPU op"):
+        layer(torch.randn(3, 16))
