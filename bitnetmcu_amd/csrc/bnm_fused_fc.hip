@@ -447,7 +447,6 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
                                                                           int32_t *__restrict__ logits_out,
                                                                           uint64_t src_wrap) {
     constexpr int KT0 = 8;
-    static_assert(M4 > 0, "dual-tile form is instantiated for four-layer models");
     __shared__ __attribute__((aligned(1024))) char smem[FUSED_WPB * 2 * FUSED_TILE_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -456,12 +455,12 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
     AFrags<M1, KT0> A1;
     AFrags<M2, M1> A2;
     AFrags<M3, M2> A3;
-    AFrags<M4, M3> A4;
+    AFrags<(M4 > 0 ? M4 : 1), M3> A4;
     const i32x4 *fp = frags;
     A1.load(fp, lane);  fp += M1 * KT0 * 64;
     A2.load(fp, lane);  fp += M2 * M1 * 64;
     A3.load(fp, lane);  fp += M3 * M2 * 64;
-    A4.load(fp, lane);
+    if constexpr (M4 > 0) A4.load(fp, lane);
 
     const uint64_t n_pairs = n >> 6;            // the launcher guarantees n % 64 == 0
     const uint64_t stride = (uint64_t)gridDim.x * FUSED_WPB;
@@ -519,19 +518,28 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
         relunorm_pack<M2, DBL>(a2B, p2B, h);
         layer_mma<M3, M2, false>(A3, p2B, a3B);
 
-        i32x4 p3A[M3], p3B[M3];
-        relunorm_pack<M3, DBL>(a3A, p3A, h);
-        i32x16 a4A[M4], a4B[M4];
-        layer_mma<M4, M3, false>(A4, p3A, a4A);
-        relunorm_pack<M3, DBL>(a3B, p3B, h);
-        layer_mma<M4, M3, false>(A4, p3B, a4B);
-
         const uint64_t imgA = (pair << 6) + (uint64_t)j, imgB = imgA + 32ull;
-        uint32_t clsA = argmax_rows<M4, NC8>(a4A, h);
-        uint32_t clsB = argmax_rows<M4, NC8>(a4B, h);
-        if (logits_out) {
-            store_logits<M4>(a4A, logits_out + imgA * n_classes, h, n_classes);
-            store_logits<M4>(a4B, logits_out + imgB * n_classes, h, n_classes);
+        uint32_t clsA, clsB;
+        if constexpr (M4 > 0) {
+            i32x4 p3A[M3], p3B[M3];
+            relunorm_pack<M3, DBL>(a3A, p3A, h);
+            i32x16 a4A[M4], a4B[M4];
+            layer_mma<M4, M3, false>(A4, p3A, a4A);
+            relunorm_pack<M3, DBL>(a3B, p3B, h);
+            layer_mma<M4, M3, false>(A4, p3B, a4B);
+            clsA = argmax_rows<M4, NC8>(a4A, h);
+            clsB = argmax_rows<M4, NC8>(a4B, h);
+            if (logits_out) {
+                store_logits<M4>(a4A, logits_out + imgA * n_classes, h, n_classes);
+                store_logits<M4>(a4B, logits_out + imgB * n_classes, h, n_classes);
+            }
+        } else {
+            clsA = argmax_rows<M3, NC8>(a3A, h);
+            clsB = argmax_rows<M3, NC8>(a3B, h);
+            if (logits_out) {
+                store_logits<M3>(a3A, logits_out + imgA * n_classes, h, n_classes);
+                store_logits<M3>(a3B, logits_out + imgB * n_classes, h, n_classes);
+            }
         }
         // both halves of the wave hold the result: lanes 0..31 store tile A's classes, lanes 32..63 tile B's —
         // one 256-byte store per pair
@@ -570,6 +578,7 @@ const FusedEntry kFused[] = {
     FUSED(8, 2, 2, 2, 1, true, false, FUSED_LDSDMA, 0),
     FUSED(8, 2, 2, 2, 1, true, false, FUSED_DIRECT, 0),
     // FC 256-16-16-10 2bitsym (mcu/BitNetMCU_model_1k.h)
+    { {8, {1, 1, 1, 0}, false, true, 2}, FUSED_DUAL, fused_fc_dual_kernel<1, 1, 1, 0, true, 2> },
     FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA2, 0),
     FUSED_ANY_AND_10(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA),
     FUSED(8, 1, 1, 1, 0, false, true, FUSED_DIRECT, 0),
@@ -602,7 +611,7 @@ bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fu
 // measured best first (profiles/r01): two tiles in flight pays when a tile carries real work (64-wide layers:
 // 4.65 vs 4.73 ms per 1e8 images); for the 16-wide 1k model the plain one-ahead loop is faster (4.40 vs 4.77 ms)
 int bnmk_fused_default_variant(const BnmFusedShape &sh) {
-    if (find_fused(sh, FUSED_DUAL)) return FUSED_DUAL;
+    if (sh.M[0] >= 2 && find_fused(sh, FUSED_DUAL)) return FUSED_DUAL;
     if (sh.M[0] >= 2 && find_fused(sh, FUSED_LDSDMA2)) return FUSED_LDSDMA2;
     return find_fused(sh, FUSED_LDSDMA) ? FUSED_LDSDMA : FUSED_DIRECT;
 }

@@ -11,7 +11,9 @@ What is and is not native:
     restated below) under autograd — plain PyTorch ops, not a HIP kernel (training is minutes-long on MNIST; row 4 is
     the lowest-ranked "next" item);
   * CPU tensors: refused.  There is no CPU implementation of the op in the product path.
-  * `BitConv2d` (BitNetMCU.py:264-322) is not built.
+  * `BitConv2d` (BitNetMCU.py:264-322): forward native for the configuration the reference's CNN uses
+    (models.py:111-116: stride 1, one input channel per group — single-channel input or depthwise); other group
+    structures are refused.
 """
 import ctypes as C
 
@@ -71,6 +73,41 @@ def bitlinear_forward(x, w, s, quant_type, norm_type, return_int=False):
             C.c_void_p(stream)), "bnm_qat_bitlinear_forward_device")
     y = y.reshape(*x.shape[:-1], k)
     return (y, xi, xsc) if return_int else y
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def bitconv2d_forward(x, w, s, quant_type, norm_type, stride=1, padding=0, groups=1):
+    """y = F.conv2d(act_quant(Normalize(x)), weight_quant(w)) on the GPU for stride 1 and one input channel per group.
+    x [n,cin,h,w], w [cout,1,kh,kw], s the PerTensor clipping scalar; float32 CUDA tensors."""
+    if not (x.is_cuda and w.is_cuda):
+        raise RuntimeError("bitconv2d_forward is a GPU op: x and w must be CUDA tensors (there is no CPU path)")
+    if _pair(stride) != (1, 1):
+        raise NotImplementedError("bitconv2d_forward: stride 1 only")
+    ph, pw = _pair(padding)
+    if ph != pw:
+        raise NotImplementedError("bitconv2d_forward: symmetric padding only")
+    lib = L.load()
+    x4 = x.contiguous().float()
+    w4 = w.contiguous().float()
+    n, cin, h, wd = x4.shape
+    cout, cpg, kh, kw = w4.shape
+    if cpg != 1:
+        raise NotImplementedError("bitconv2d_forward: one input channel per group only")
+    s2 = torch.as_tensor(s, dtype=torch.float32, device=x.device).reshape(-1).contiguous()
+    if s2.numel() != 1:
+        raise NotImplementedError("bitconv2d_forward: PerTensor clipping scalar only")
+    y = torch.empty((n, cout, h + 2 * ph - kh + 1, wd + 2 * ph - kw + 1), dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device, kh * kw, cout)
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        L.check(lib, lib.bnm_qat_bitconv2d_forward_device(
+            C.c_void_p(x4.data_ptr()), n, cin, h, wd, C.c_void_p(w4.data_ptr()), cout, kh, kw, ph, groups,
+            C.c_void_p(s2.data_ptr()), QUANT_TYPES[quant_type], NORM_TYPES[norm_type], C.c_void_p(y.data_ptr()),
+            C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.c_void_p(stream)), "bnm_qat_bitconv2d_forward_device")
+    return y
 
 
 # ---- the reference's expression, restated (used for the straight-through backward and pinned by
@@ -147,6 +184,41 @@ def ste_formula(x, w, s, quant_type, norm_type):
     return F.linear(x_quant, w_quant)
 
 
+def ste_conv_formula(x, w, s, quant_type, norm_type, stride=1, padding=0, groups=1):
+    """BitConv2d.forward (BitNetMCU.py:284-305) as differentiable PyTorch ops."""
+    if norm_type == "RMS":
+        x_norm = x / torch.sqrt(torch.mean(x ** 2, dim=(-2, -1), keepdim=True))     # :306-308, per plane
+    elif norm_type == "None":
+        x_norm = x
+    else:
+        raise AssertionError(f"Invalid NormType: {norm_type}. Expected one of: 'RMS', 'None'")
+    if quant_type == "None":
+        return F.conv2d(x_norm, w, stride=stride, padding=padding, groups=groups)
+    x_int, x_scale = activation_quant(x_norm)                                        # per image row (last dimension)
+    x_quant = x_norm + (x_int / x_scale - x_norm).detach()
+    w_int, w_scale = weight_quant(w, s, quant_type)
+    w_quant = w + (w_int / w_scale - w).detach()
+    return F.conv2d(x_quant, w_quant, groups=groups, stride=stride, padding=padding, bias=None)
+
+
+class _BitConv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, s, quant_type, norm_type, stride, padding, groups):
+        ctx.save_for_backward(x, w, s)
+        ctx.cfg = (quant_type, norm_type, stride, padding, groups)
+        return bitconv2d_forward(x, w, s, quant_type, norm_type, stride, padding, groups)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, s = ctx.saved_tensors
+        with torch.enable_grad():
+            xr = x.detach().requires_grad_(True)
+            wr = w.detach().requires_grad_(True)
+            y = ste_conv_formula(xr, wr, s.detach(), *ctx.cfg)
+            gx, gw = torch.autograd.grad(y, (xr, wr), gy)
+        return gx, gw, None, None, None, None, None, None
+
+
 class _BitLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, s, quant_type, norm_type):
@@ -184,6 +256,18 @@ class BitLinear(nn.Linear):
     def forward(self, x):
         return _BitLinearFn.apply(x, self.weight, self.s, self.QuantType, self.NormType)
 
+    # the pieces the reference's exporter and QuantizedModel call on a layer (BitNetMCU.py:351-418 uses weight_quant)
+    def Normalize(self, x):
+        return normalize(x, self.NormType)
+
+    def activation_quant(self, x):
+        return activation_quant(x)
+
+    def weight_quant(self, w):
+        s = self.s.reshape(-1, 1) if self.s.numel() > 1 else self.s
+        u, scale = weight_quant(w, s, self.QuantType)
+        return u, scale, self.bpw
+
     def octav(self, tensor, num_iterations=10, s=-1):
         """Optimum clipping scalar by Newton iteration (BitNetMCU.py:71-83; C. Sakr et al. 2022)."""
         if s < 0:
@@ -209,3 +293,36 @@ class BitLinear(nn.Linear):
             raise AssertionError(f"Invalid algorithm: {algorithm}. Expected one of: 'octav', 'prop'")
         self.s = nn.Parameter(s.detach(), requires_grad=False)
         return s
+
+
+class BitConv2d(nn.Conv2d):
+    """Stand-in for the reference's BitConv2d (BitNetMCU.py:264-322): same constructor and attributes; forward runs
+    the fused HIP op on CUDA inputs (stride 1, one input channel per group)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, groups=1, QuantType="4bitsym",
+                 WScale="PerTensor", NormType="RMS"):
+        super().__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding, groups=groups,
+                         bias=False)
+        if QuantType != "None" and QuantType not in BPW:
+            raise AssertionError(f"Invalid QuantType: {QuantType}")
+        if WScale not in ("PerOutput", "PerTensor"):
+            raise AssertionError(f"Invalid WScale: {WScale}. Expected one of: 'PerTensor', 'PerOutput'")
+        if NormType not in ("RMS", "None"):
+            raise AssertionError(f"Invalid NormType: {NormType}. Expected one of: 'RMS', 'None'")
+        self.QuantType, self.WScale, self.NormType = QuantType, WScale, NormType
+        self.bpw = BPW.get(QuantType, 0)
+        self.s = nn.Parameter(torch.tensor(1.0), requires_grad=False)
+
+    def forward(self, x):
+        return _BitConv2dFn.apply(x, self.weight, self.s, self.QuantType, self.NormType, self.stride, self.padding,
+                                  self.groups)
+
+    def weight_quant(self, w):
+        u, scale = weight_quant(w, self.s, self.QuantType)
+        return u, scale, self.bpw
+
+    def activation_quant(self, x):
+        return activation_quant(x)
+
+    octav = BitLinear.octav
+    update_clipping_scalar = BitLinear.update_clipping_scalar

@@ -48,7 +48,7 @@ def check_case(tag, qt, nt):
     x, w = dev(f"{tag}/x"), dev(f"{tag}/w")
     n, d = x.shape
     k = w.shape[0]
-    s = dev(f"{tag}/{qt}/{nt}/s")
+    s = dev(f"{tag}/{qt}/s")
     y, xi, xs = qat.bitlinear_forward(x, w, s, qt, nt, return_int=True)
     torch.cuda.synchronize()
     y, xi, xs = y.cpu().numpy(), xi.cpu().numpy().astype(np.float64), xs.cpu().numpy().astype(np.float64)
@@ -67,7 +67,7 @@ def check_case(tag, qt, nt):
     else:
         clean_rows = np.ones(n, bool)
     # weight side
-    ref_u, ref_ws = G[f"{tag}/{qt}/{nt}/w_int"].astype(np.float64), G[f"{tag}/{qt}/{nt}/w_scale"].astype(np.float64)
+    ref_u, ref_ws = G[f"{tag}/{qt}/w_int"].astype(np.float64), G[f"{tag}/{qt}/w_scale"].astype(np.float64)
     wbad = np.abs(u - ref_u) > 1e-6
     if wbad.any():
         assert wbad.mean() < 2e-3, (qt, nt, wbad.mean())
@@ -110,7 +110,7 @@ def test_quant_type_none_is_a_plain_linear_on_the_normalised_input(gpu_ok):
 
 def test_shapes_empty_batch_large_batch_and_leading_dims(gpu_ok):
     w = dev("a/w")
-    s = dev("a/4bitsym/RMS/s")
+    s = dev("a/4bitsym/s")
     assert qat.bitlinear_forward(torch.empty(0, 202, device="cuda"), w, s, "4bitsym", "RMS").shape == (0, 24)
     x = torch.randn(3, 700, 202, device="cuda")
     y = qat.bitlinear_forward(x, w, s, "4bitsym", "RMS")
@@ -147,3 +147,41 @@ def test_module_forward_backward(qt, nt, gpu_ok):
     assert (rel < 2e-4).mean() > 0.9 and rel.max() < 2e-2
     assert np.abs(x.grad.cpu().numpy() - ref_gx).max() <= 1e-3 * np.abs(ref_gx).max()
     assert np.abs(layer.weight.grad.cpu().numpy() - ref_gw).max() <= 1e-3 * np.abs(ref_gw).max()
+
+
+# ---- BitConv2d forward: y within 2e-5 of the reference's y relative to max|y| on >= 99.5 % of the outputs; the rest
+# ---- may carry one activation tie flip (one quantisation step of one image row: < 2e-2).
+CONV_CASES = [("conv1", (1, 16, 1, "8bit", "None", 0)), ("convdw", (16, 16, 16, "8bit", "None", 0)),
+              ("convdw_rms", (8, 16, 8, "4bitsym", "RMS", 1)), ("conv1_tern", (1, 12, 1, "Ternary", "RMS", 0))]
+
+
+@pytest.mark.parametrize("tag,cfg", CONV_CASES)
+def test_bitconv2d_forward(tag, cfg, gpu_ok):
+    cin, cout, groups, qt, nt, pad = cfg
+    y = qat.bitconv2d_forward(dev(f"{tag}/x"), dev(f"{tag}/w"), dev(f"{tag}/s"), qt, nt, 1, (pad, pad), groups)
+    ref = G[f"{tag}/y"]
+    assert tuple(y.shape) == ref.shape
+    rel = np.abs(y.cpu().numpy() - ref) / np.abs(ref).max()
+    assert (rel < 2e-5).mean() > 0.995 and rel.max() < 2e-2, (tag, rel.max(), (rel < 2e-5).mean())
+
+
+def test_bitconv2d_module_forward_backward_and_refusals(gpu_ok):
+    for tag, (cin, cout, groups, qt, nt, pad) in (CONV_CASES[0], CONV_CASES[2]):
+        layer = qat.BitConv2d(cin, cout, kernel_size=3, stride=1, padding=(pad, pad), groups=groups, QuantType=qt, NormType=nt).cuda()
+        with torch.no_grad():
+            layer.weight.copy_(dev(f"{tag}/w"))
+        layer.update_clipping_scalar(layer.weight.data, "prop", 0.25)
+        assert np.allclose(layer.s.detach().cpu().numpy().reshape(-1), G[f"{tag}/s"], rtol=1e-6)
+        x = dev(f"{tag}/x").requires_grad_(True)
+        y = layer(x)
+        (y * dev(f"{tag}/gy")).sum().backward()
+        rel = np.abs(y.detach().cpu().numpy() - G[f"{tag}/y"]) / np.abs(G[f"{tag}/y"]).max()
+        assert (rel < 2e-5).mean() > 0.995 and rel.max() < 2e-2
+        assert np.abs(x.grad.cpu().numpy() - G[f"{tag}/gx"]).max() <= 1e-3 * np.abs(G[f"{tag}/gx"]).max()
+        assert np.abs(layer.weight.grad.cpu().numpy() - G[f"{tag}/gw"]).max() <= 1e-3 * np.abs(G[f"{tag}/gw"]).max()
+    x = torch.randn(2, 4, 8, 8, device="cuda")
+    with pytest.raises(NotImplementedError):
+        qat.bitconv2d_forward(x, torch.randn(8, 2, 3, 3, device="cuda"), torch.ones(1), "8bit", "None", 1, 0, 2)
+    with pytest.raises(NotImplementedError):
+        qat.bitconv2d_forward(x, torch.randn(4, 1, 3, 3, device="cuda"), torch.ones(1), "8bit", "None", 2, 0, 4)
+    assert qat.bitconv2d_forward(x[:0], torch.randn(4, 1, 3, 3, device="cuda"), torch.ones(1), "8bit", "None", 1, 0, 4).shape == (0, 4, 6, 6)

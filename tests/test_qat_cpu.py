@@ -32,11 +32,11 @@ def test_normalize_and_activation_quant_equal_reference(nt):
 def test_weight_quant_and_forward_equal_reference(qt):
     x, w = t("a/x"), t("a/w")
     for nt in NORMS:
-        s = t(f"a/{qt}/{nt}/s")
+        s = t(f"a/{qt}/s")
         s = s[0] if s.numel() == 1 else s
         u, sc = qat.weight_quant(w, s, qt)
-        assert torch.equal(u, t(f"a/{qt}/{nt}/w_int"))
-        assert torch.equal(torch.as_tensor(sc).reshape(-1), t(f"a/{qt}/{nt}/w_scale"))
+        assert torch.equal(u, t(f"a/{qt}/w_int"))
+        assert torch.equal(torch.as_tensor(sc).reshape(-1), t(f"a/{qt}/w_scale"))
         assert torch.equal(qat.ste_formula(x, w, s, qt, nt), t(f"a/{qt}/{nt}/y"))
 
 
@@ -44,7 +44,7 @@ def test_per_output_scale_and_odd_width():
     for tag, qts in (("perout", ["4bitsym", "2bitsym"]), ("odd", ["4bitsym", "8bit"])):
         x, w = t(f"{tag}/x"), t(f"{tag}/w")
         for qt in qts:
-            s = t(f"{tag}/{qt}/RMS/s")
+            s = t(f"{tag}/{qt}/s")
             s = s[0] if s.numel() == 1 else s
             assert torch.equal(qat.ste_formula(x, w, s, qt, "RMS"), t(f"{tag}/{qt}/RMS/y"))
 
@@ -53,7 +53,7 @@ def test_per_output_scale_and_odd_width():
 def test_straight_through_gradients_equal_reference(qt, nt):
     x = t("a/x").clone().requires_grad_(True)
     w = t("a/w").clone().requires_grad_(True)
-    y = qat.ste_formula(x, w, t(f"a/{qt}/{nt}/s")[0], qt, nt)
+    y = qat.ste_formula(x, w, t(f"a/{qt}/s")[0], qt, nt)
     gx, gw = torch.autograd.grad(y, (x, w), t("a/gy"))
     assert torch.equal(gx, t(f"a/{qt}/{nt}/gx")) and torch.equal(gw, t(f"a/{qt}/{nt}/gw"))
 
@@ -64,7 +64,7 @@ def test_module_mirrors_reference_constructor_and_clipping_scalar():
     with torch.no_grad():
         layer.weight.copy_(t("a/w"))
     s = layer.update_clipping_scalar(layer.weight.data, "prop", 0.25)
-    assert torch.equal(s.reshape(-1), t("a/4bitsym/RMS/s")) and torch.equal(layer.s.data.reshape(-1), t("a/4bitsym/RMS/s"))
+    assert torch.equal(s.reshape(-1), t("a/4bitsym/s")) and torch.equal(layer.s.data.reshape(-1), t("a/4bitsym/s"))
     assert float(layer.update_clipping_scalar(layer.weight.data, "octav")) > 0
     for bad in (dict(QuantType="3bit"), dict(WScale="PerRow"), dict(NormType="Group")):
         with pytest.raises(AssertionError):
@@ -75,3 +75,37 @@ def test_cpu_tensors_are_refused_not_emulated():
     layer = qat.BitLinear(16, 4, QuantType="4bitsym")
     with pytest.raises(RuntimeError, match="GPU op"):
         layer(torch.randn(3, 16))
+
+
+def test_module_exposes_the_quantiser_pieces_the_exporter_calls():
+    layer = qat.BitLinear(202, 24, QuantType="FP130", NormType="Lin")
+    with torch.no_grad():
+        layer.weight.copy_(t("a/w"))
+    layer.update_clipping_scalar(layer.weight.data, "prop", 0.25)
+    u, scale, bpw = layer.weight_quant(layer.weight.data)
+    assert bpw == 4 and torch.equal(u, t("a/FP130/w_int")) and torch.equal(scale.reshape(-1), t("a/FP130/w_scale"))
+    xi, xs = layer.activation_quant(layer.Normalize(t("a/x")))
+    assert torch.equal(xi, t("a/Lin/x_int"))
+
+
+@pytest.mark.parametrize("tag,cfg", [("conv1", (1, 16, 1, "8bit", "None", 0)), ("convdw", (16, 16, 16, "8bit", "None", 0)),
+                                     ("convdw_rms", (8, 16, 8, "4bitsym", "RMS", 1)), ("conv1_tern", (1, 12, 1, "Ternary", "RMS", 0))])
+def test_conv_formula_equals_reference(tag, cfg):
+    cin, cout, groups, qt, nt, pad = cfg
+    x = t(f"{tag}/x").clone().requires_grad_(True)
+    w = t(f"{tag}/w").clone().requires_grad_(True)
+    y = qat.ste_conv_formula(x, w, t(f"{tag}/s")[0], qt, nt, 1, (pad, pad), groups)
+    assert torch.equal(y, t(f"{tag}/y"))
+    if f"{tag}/gx" in G:
+        gx, gw = torch.autograd.grad(y, (x, w), t(f"{tag}/gy"))
+        assert torch.equal(gx, t(f"{tag}/gx")) and torch.equal(gw, t(f"{tag}/gw"))
+
+
+def test_conv_module_mirrors_reference_constructor():
+    layer = qat.BitConv2d(16, 16, kernel_size=3, stride=1, padding=(0, 0), groups=16, QuantType="8bit", NormType="None")
+    assert layer.weight.shape == (16, 1, 3, 3) and layer.bias is None and layer.bpw == 8 and not layer.s.requires_grad
+    assert float(layer.update_clipping_scalar(layer.weight.data, "prop", 0.25)) > 0
+    with pytest.raises(AssertionError):
+        qat.BitConv2d(1, 4, 3, 1, 0, NormType="LayerNorm")
+    with pytest.raises(RuntimeError, match="GPU op"):
+        layer(torch.randn(2, 16, 14, 14))
