@@ -608,10 +608,11 @@ const FusedEntry *find_fused(const BnmFusedShape &sh, int variant) {
 }  // namespace
 
 bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fused(sh, variant) != nullptr; }
-// measured best first (profiles/r01): two tiles in flight pays when a tile carries real work (64-wide layers:
-// 4.65 vs 4.73 ms per 1e8 images); for the 16-wide 1k model the plain one-ahead loop is faster (4.40 vs 4.77 ms)
+// measured best first (profiles/r01): the dual-tile kernel wherever it is instantiated (64-wide four-layer shapes:
+// 4.40-4.55 vs 4.63-4.70 ms per 1e8 images; the 16-wide 1k model: 4.29 vs 4.33 ms), then two tiles in flight for
+// shapes whose tiles carry real work, else the plain one-ahead loop
 int bnmk_fused_default_variant(const BnmFusedShape &sh) {
-    if (sh.M[0] >= 2 && find_fused(sh, FUSED_DUAL)) return FUSED_DUAL;
+    if (find_fused(sh, FUSED_DUAL)) return FUSED_DUAL;
     if (sh.M[0] >= 2 && find_fused(sh, FUSED_LDSDMA2)) return FUSED_LDSDMA2;
     return find_fused(sh, FUSED_LDSDMA) ? FUSED_LDSDMA : FUSED_DIRECT;
 }
