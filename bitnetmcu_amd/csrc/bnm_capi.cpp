@@ -540,7 +540,8 @@ uint64_t bnm_qat_workspace_bytes(uint32_t d, uint32_t k) { return bnmk_qat_works
 
 int bnm_qat_bitlinear_forward_device(const float *d_x, uint64_t n, uint32_t d, const float *d_w, uint32_t k, const float *d_s,
                                      uint32_t s_count, int quant_type, int norm_type, float *d_y, void *d_workspace,
-                                     uint64_t workspace_bytes, float *d_x_int_out, float *d_x_scale_out, void *stream) {
+                                     uint64_t workspace_bytes, float *d_x_int_out, float *d_x_scale_out, float *d_w_deq_out,
+                                     void *stream) {
     if (!d_w || !d_s || !d_workspace || (n && (!d_x || !d_y))) return fail(BNM_EINVAL, "null pointer");
     if (d == 0 || k == 0 || d > 1024u) return fail(BNM_EINVAL, "need 1 <= d <= 1024 and k >= 1");
     if (s_count != 1u && s_count != k) return fail(BNM_EINVAL, "s_count must be 1 (PerTensor) or k (PerOutput)");
@@ -549,7 +550,7 @@ int bnm_qat_bitlinear_forward_device(const float *d_x, uint64_t n, uint32_t d, c
     if (workspace_bytes < bnmk_qat_workspace_bytes(d, k)) return fail(BNM_EINVAL, "workspace too small (bnm_qat_workspace_bytes)");
     if ((uintptr_t)d_workspace & 3u) return fail(BNM_EINVAL, "workspace must be 4-byte aligned");
     HIP_TRY(bnmk_qat_bitlinear_forward(d_x, n, d, d_w, k, d_s, s_count, quant_type, norm_type, d_y, (float *)d_workspace,
-                                       d_x_int_out, d_x_scale_out, (hipStream_t)stream));
+                                       d_x_int_out, d_x_scale_out, d_w_deq_out, (hipStream_t)stream));
     return BNM_OK;
 }
 

@@ -93,7 +93,8 @@ hipError_t bnmk_diag_pipes(int mode, uint64_t tiles_per_wave, uint32_t *d_out, h
 size_t bnmk_qat_workspace_bytes(uint32_t d, uint32_t k);
 hipError_t bnmk_qat_bitlinear_forward(const float *d_x, uint64_t n, uint32_t d, const float *d_w, uint32_t k,
                                       const float *d_s, uint32_t s_count, int quant_type, int norm_type, float *d_y,
-                                      float *d_workspace, float *d_x_int_out, float *d_x_scale_out, hipStream_t s);
+                                      float *d_workspace, float *d_x_int_out, float *d_x_scale_out, float *d_w_deq_out,
+                                      hipStream_t s);
 // BitConv2d forward: stride 1, one input channel per group (cin == 1 with groups == 1, or depthwise), zero padding `pad`.
 // workspace: bnmk_qat_workspace_bytes(kh * kw, cout) bytes.
 hipError_t bnmk_qat_bitconv2d_forward(const float *d_x, uint64_t n, uint32_t cin, uint32_t h, uint32_t w, const float *d_w,

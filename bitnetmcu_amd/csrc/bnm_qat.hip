@@ -120,12 +120,15 @@ __global__ __launch_bounds__(1024) void qat_weight_stats_kernel(const float *__r
 __global__ __launch_bounds__(256) void qat_weight_quant_kernel(const float *__restrict__ w, uint32_t k, uint32_t d,
                                                                const float *__restrict__ s, uint32_t s_count, int qt,
                                                                const float *__restrict__ stats, uint32_t kpad,
-                                                               float *__restrict__ uT, float *__restrict__ w_scale) {
+                                                               float *__restrict__ uT, float *__restrict__ w_scale,
+                                                               float *__restrict__ w_deq_out) {
     const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (idx >= (uint64_t)k * d) return;
     const uint32_t row = (uint32_t)(idx / d), col = (uint32_t)(idx % d);
     const float sc = qat_weight_scale(qt, s[s_count > 1 ? row : 0], stats[0]);
-    uT[(uint64_t)col * kpad + row] = qat_weight_level(qt, w[idx], sc, stats[1]);
+    const float u = qat_weight_level(qt, w[idx], sc, stats[1]);
+    uT[(uint64_t)col * kpad + row] = u;
+    if (w_deq_out) w_deq_out[idx] = qt == BNM_QAT_NONE ? u : __fdiv_rn(u, sc);   // w_int / w_scale, the STE forward value
     if (col == 0) w_scale[row] = sc;
 }
 
@@ -320,7 +323,7 @@ hipError_t bnmk_qat_bitconv2d_forward(const float *x, uint64_t n, uint32_t cin, 
     const uint64_t cnt = (uint64_t)cout * d;
     if (qt == BNM_QAT_TERNARY || qt == BNM_QAT_BINARY) qat_weight_stats_kernel<<<dim3(1), dim3(1024), 0, st>>>(w, cnt, stats);
     qat_weight_quant_kernel<<<dim3((unsigned)((cnt + 255u) / 256u)), dim3(256), 0, st>>>(w, cout, d, s, 1u, qt, stats, kpad, uT,
-                                                                                   w_scale);
+                                                                                   w_scale, nullptr);
     const size_t lds_bytes = ((size_t)(h + 2u * pad) * (wd + 2u * pad) + (size_t)(cout / cin) * d) * sizeof(float);
     qat_bitconv2d_fwd_kernel<<<dim3((unsigned)(n * cin)), dim3(256), lds_bytes, st>>>(x, cin, h, wd, uT, w_scale, cout, kpad, kh, kw,
                                                                                      pad, qt, nt, y);
@@ -334,7 +337,7 @@ size_t bnmk_qat_workspace_bytes(uint32_t d, uint32_t k) {
 
 hipError_t bnmk_qat_bitlinear_forward(const float *x, uint64_t n, uint32_t d, const float *w, uint32_t k, const float *s,
                                       uint32_t s_count, int qt, int nt, float *y, float *workspace, float *x_int_out,
-                                      float *x_scale_out, hipStream_t st) {
+                                      float *x_scale_out, float *w_deq_out, hipStream_t st) {
     const uint32_t dpad = (d + 1u) & ~1u, kpad = (k + 31u) & ~31u;
     float *uT = workspace;
     float *w_scale = uT + (size_t)dpad * kpad;
@@ -347,7 +350,7 @@ hipError_t bnmk_qat_bitlinear_forward(const float *x, uint64_t n, uint32_t d, co
         qat_weight_stats_kernel<<<dim3(1), dim3(1024), 0, st>>>(w, (uint64_t)k * d, stats);
     const uint64_t cnt = (uint64_t)k * d;
     qat_weight_quant_kernel<<<dim3((unsigned)((cnt + 255u) / 256u)), dim3(256), 0, st>>>(w, k, d, s, s_count, qt, stats, kpad, uT,
-                                                                                   w_scale);
+                                                                                   w_scale, w_deq_out);
     if (nt == BNM_QAT_NORM_BATCHNORM)
         qat_batch_stats_kernel<<<dim3((d + 255u) / 256u), dim3(256), 0, st>>>(x, n, d, bn_mean, bn_den);
     const size_t lds_bytes = ((size_t)QAT_ROWS * (dpad + 1u) + QAT_ROWS) * sizeof(float);

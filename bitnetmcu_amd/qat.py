@@ -7,9 +7,10 @@ layer's constructor, attributes and `update_clipping_scalar` so it can stand in 
 
 What is and is not native:
   * forward on CUDA tensors: native, one weight-quant launch + one fused normalise/quantise/GEMM launch;
-  * backward: the straight-through gradient is obtained by re-running `ste_formula` (the reference's expression,
-    restated below) under autograd — plain PyTorch ops, not a HIP kernel (training is minutes-long on MNIST; row 4 is
-    the lowest-ranked "next" item);
+  * backward (BitLinear): no forward recompute — the op hands back x_int, x_scale and w_int / w_scale, and the
+    straight-through gradient is two library GEMMs against them plus Normalize's own backward through autograd
+    (`ste_backward`); BitConv2d's backward re-runs the restated expression `ste_conv_formula` under autograd.  Neither
+    is a hand-written HIP kernel (training is minutes-long on MNIST; row 4 is the lowest-ranked "next" item);
   * CPU tensors: refused.  There is no CPU implementation of the op in the product path.
   * `BitConv2d` (BitNetMCU.py:264-322): forward native for the configuration the reference's CNN uses
     (models.py:111-116: stride 1, one input channel per group — single-channel input or depthwise); other group
@@ -45,10 +46,11 @@ def _workspace(device, d, k):
     return ws
 
 
-def bitlinear_forward(x, w, s, quant_type, norm_type, return_int=False):
+def bitlinear_forward(x, w, s, quant_type, norm_type, return_int=False, return_w_deq=False):
     """y = F.linear(act_quant(Normalize(x)), weight_quant(w)) on the GPU.
     x [n,d], w [k,d], s scalar or [k]/[k,1] (the layer's clipping scalar), all float32 CUDA tensors.
-    return_int: also return activation_quant's integers [n,d] and scales [n]."""
+    return_int: also return activation_quant's integers [n,d] and scales [n]; return_w_deq: also the fake-quantised
+    weights w_int / w_scale [k,d]."""
     if not (x.is_cuda and w.is_cuda):
         raise RuntimeError("bitlinear_forward is a GPU op: x and w must be CUDA tensors (there is no CPU path)")
     lib = L.load()
@@ -63,6 +65,7 @@ def bitlinear_forward(x, w, s, quant_type, norm_type, return_int=False):
     y = torch.empty((n, k), dtype=torch.float32, device=x.device)
     xi = torch.empty((n, d), dtype=torch.float32, device=x.device) if return_int else None
     xsc = torch.empty((n,), dtype=torch.float32, device=x.device) if return_int else None
+    wdq = torch.empty((k, d), dtype=torch.float32, device=x.device) if return_w_deq else None
     ws = _workspace(x.device, d, k)
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream().cuda_stream
@@ -70,9 +73,10 @@ def bitlinear_forward(x, w, s, quant_type, norm_type, return_int=False):
             C.c_void_p(x2.data_ptr()), n, d, C.c_void_p(w2.data_ptr()), k, C.c_void_p(s2.data_ptr()), s2.numel(), qt, nt,
             C.c_void_p(y.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel() * 4,
             C.c_void_p(xi.data_ptr()) if return_int else None, C.c_void_p(xsc.data_ptr()) if return_int else None,
-            C.c_void_p(stream)), "bnm_qat_bitlinear_forward_device")
+            C.c_void_p(wdq.data_ptr()) if return_w_deq else None, C.c_void_p(stream)), "bnm_qat_bitlinear_forward_device")
     y = y.reshape(*x.shape[:-1], k)
-    return (y, xi, xsc) if return_int else y
+    extra = ((xi, xsc) if return_int else ()) + ((wdq,) if return_w_deq else ())
+    return (y,) + extra if extra else y
 
 
 def _pair(v):
@@ -219,21 +223,46 @@ class _BitConv2dFn(torch.autograd.Function):
         return gx, gw, None, None, None, None, None, None
 
 
+def ste_backward(x, gy, norm_type, x_q, w_q):
+    """Gradients of BitLinear's straight-through forward given its quantised operands: x_q = x_int / x_scale (or the
+    normalised input when QuantType is 'None'; pass None to use it), w_q = w_int / w_scale (or w)."""
+    g2 = gy.reshape(-1, gy.shape[-1])
+    with torch.enable_grad():
+        xr = x.detach().requires_grad_(True)
+        xn = normalize(xr, norm_type)
+    if x_q is None:
+        x_q = xn.detach().reshape(-1, x.shape[-1])
+    gw = g2.t() @ x_q
+    (gx,) = torch.autograd.grad(xn, xr, (g2 @ w_q).reshape(x.shape))
+    return gx, gw
+
+
 class _BitLinearFn(torch.autograd.Function):
+    """Forward: the fused HIP op, which also hands back what the straight-through estimator differentiates against
+    (x_int, x_scale, w_int / w_scale).  Backward: dy/dx_norm = w_quant and dy/dw = x_quant (BitNetMCU.py:228-234: the
+    detach() terms carry no gradient), i.e. two library GEMMs, then the Normalize step's own backward via autograd."""
+
     @staticmethod
     def forward(ctx, x, w, s, quant_type, norm_type):
-        ctx.save_for_backward(x, w, s)
+        if quant_type == "None":
+            y = bitlinear_forward(x, w, s, quant_type, norm_type)
+            ctx.save_for_backward(x, w)
+        else:
+            y, xi, xs, wq = bitlinear_forward(x, w, s, quant_type, norm_type, return_int=True, return_w_deq=True)
+            ctx.save_for_backward(x, xi, xs, wq)
         ctx.qn = (quant_type, norm_type)
-        return bitlinear_forward(x, w, s, quant_type, norm_type)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, s = ctx.saved_tensors
-        with torch.enable_grad():
-            xr = x.detach().requires_grad_(True)
-            wr = w.detach().requires_grad_(True)
-            y = ste_formula(xr, wr, s.detach(), *ctx.qn)
-            gx, gw = torch.autograd.grad(y, (xr, wr), gy)
+        quant_type, norm_type = ctx.qn
+        if quant_type == "None":
+            x, w_q = ctx.saved_tensors
+            x_q = None
+        else:
+            x, xi, xs, w_q = ctx.saved_tensors
+            x_q = xi / xs[:, None]
+        gx, gw = ste_backward(x, gy, norm_type, x_q, w_q)
         return gx, gw, None, None, None
 
 

@@ -175,7 +175,8 @@ BNM_API int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_ou
  * quant_type / norm_type name the reference's QuantType / NormType strings.  s: the layer's clipping scalar
  * `self.s` (BitNetMCU.py:51; s_count 1 = PerTensor, k = PerOutput).  Floating point: parity with PyTorch is
  * within tolerance (integer sums are exact on the fp32 matrix cores; see csrc/bnm_qat.hip), not bit-exact.
- * x_int_out [n][d] / x_scale_out [n] (optional) return activation_quant's integers and scales.
+ * x_int_out [n][d] / x_scale_out [n] (optional) return activation_quant's integers and scales, w_deq_out [k][d]
+ * (optional) the fake-quantised weights w_int / w_scale — what a straight-through backward pass multiplies by.
  * All pointers are DEVICE pointers; workspace must hold bnm_qat_workspace_bytes(d, k) bytes; d <= 1024. */
 #define BNM_QAT_NONE 0        /* 'None': no fake quantisation, plain linear on the normalised input */
 #define BNM_QAT_BINARY 1      /* 'Binary' */
@@ -197,7 +198,8 @@ BNM_API uint64_t bnm_qat_workspace_bytes(uint32_t d, uint32_t k);
 BNM_API int bnm_qat_bitlinear_forward_device(const float *d_x, uint64_t n, uint32_t d, const float *d_w, uint32_t k,
                                              const float *d_s, uint32_t s_count, int quant_type, int norm_type,
                                              float *d_y, void *d_workspace, uint64_t workspace_bytes,
-                                             float *d_x_int_out, float *d_x_scale_out, void *stream);
+                                             float *d_x_int_out, float *d_x_scale_out, float *d_w_deq_out,
+                                             void *stream);
 
 /* BitConv2d forward (BitNetMCU.py:264-322) in the configuration the reference's CNN uses (models.py:111-116):
  * stride 1, ONE input channel per group — either in_channels == 1 with groups == 1, or depthwise

@@ -109,3 +109,16 @@ def test_conv_module_mirrors_reference_constructor():
         qat.BitConv2d(1, 4, 3, 1, 0, NormType="LayerNorm")
     with pytest.raises(RuntimeError, match="GPU op"):
         layer(torch.randn(2, 16, 14, 14))
+
+
+@pytest.mark.parametrize("qt,nt", [("4bitsym", "RMS"), ("Ternary", "Lin"), ("FP130", "LayerNorm"), ("2bitsym", "BatchNorm")])
+def test_backward_from_quantised_operands_equals_reference_gradients(qt, nt):
+    """The module's backward does not re-run the forward: it multiplies by the quantised operands the forward op
+    returns.  Same algebra as the reference's autograd graph; only the fp32 rounding of the two GEMMs may differ."""
+    x, w = t("a/x"), t("a/w")
+    xi, xs = qat.activation_quant(qat.normalize(x, nt))
+    u, sc = qat.weight_quant(w, t(f"a/{qt}/s")[0], qt)
+    gx, gw = qat.ste_backward(x, t("a/gy"), nt, xi / xs, u / sc)
+    ref_gx, ref_gw = t(f"a/{qt}/{nt}/gx"), t(f"a/{qt}/{nt}/gw")
+    assert (gx - ref_gx).abs().max() <= 1e-5 * ref_gx.abs().max()
+    assert (gw - ref_gw).abs().max() <= 1e-5 * ref_gw.abs().max()
