@@ -55,10 +55,11 @@ BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 
     }
 }
 
-// value of the partner lane (lane ^ 32)
-BNM_DEVICE int partner32(int x, int h) {
+// max(x, x of lane ^ 32): swapping the upper half of one copy with the lower half of another leaves
+// {x_lo, x_lo} and {x_hi, x_hi}, whose maximum is the answer in every lane — no select on the half index
+BNM_DEVICE int max_with_partner32(int x) {
     auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-    return h ? r[0] : r[1];
+    return max((int)r[0], (int)r[1]);
 }
 
 // clamp to [0, hi] in ONE instruction.  hipcc only forms v_med3_i32 from min(max(x, lo), hi) when it can prove
@@ -112,11 +113,10 @@ BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int 
     for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) mx = max(mx, acc[m][r]);
-    mx = max(mx, partner32(mx, h));
-    mx = max(mx, 0);
+    mx = max(max_with_partner32(mx), 0);
     if constexpr (DBL) {
-        uint32_t t = (uint32_t)mx >> 8;
-        int sh = t ? 32 - __builtin_clz(t) : 0;
+        // shift = bitlength(mx >> 8) = bitlength(mx | 255) - 8: no zero test needed (mx >= 0)
+        int sh = 24 - __builtin_clz((uint32_t)mx | 255u);
         int hi = (255 << sh) - 1;
 #pragma unroll
         for (int m = 0; m < MT; m++) {
@@ -130,8 +130,7 @@ BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int 
     } else {
         // plain sums: out = min(127, (x + 2^(s-1)) >> s) for x >= 0, else 0 — add, v_med3 to [0, 128*2^s - 1], SDWA
         // shift straight into the packed byte: 3 VALU per value
-        uint32_t t = (uint32_t)mx >> 7;
-        int sh = t ? 32 - __builtin_clz(t) : 0;
+        int sh = 25 - __builtin_clz((uint32_t)mx | 127u);     // bitlength(mx >> 7)
         int rnd = (1 << sh) >> 1;
         int hi = (128 << sh) - 1;
 #pragma unroll
@@ -164,8 +163,7 @@ BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h) {
             const uint32_t rowbase = 32u * m + (r & 3) + 8u * (r >> 2);   // row of the h = 0 half; h = 1: +4
             best = max(best, (int)(((uint32_t)acc[m][r] << 8) | (255u - rowbase)));
         }
-    best -= 4 * h;
-    best = max(best, partner32(best, h));
+    best = max_with_partner32(best - 4 * h);
     return 255u - ((uint32_t)best & 255u);
 }
 
