@@ -414,28 +414,32 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
 // whole 32-image tile, rows contiguous: two base pointers + instruction offsets instead of eight pointers.
 // The instruction offset of an LDS-DMA load is added to BOTH the global and the LDS address, so pieces 0..3 and
 // 4..7 need M0 set only once each.
+#define BNM_DMA8_LINEAR(POL)                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                        \
+                 "s_nop 4\n\t"                                                                      \
+                 "s_mov_b32 %0, m0\n\t"                                                             \
+                 "s_mov_b32 m0, %1\n\t"                                                             \
+                 "s_nop 0\n\t"                                                                      \
+                 "global_load_lds_dwordx4 %4, %2" POL "\n\t"                                        \
+                 "global_load_lds_dwordx4 %5, %2 offset:1024" POL "\n\t"                            \
+                 "global_load_lds_dwordx4 %6, %2 offset:2048" POL "\n\t"                            \
+                 "global_load_lds_dwordx4 %7, %2 offset:3072" POL "\n\t"                            \
+                 "s_add_u32 m0, m0, 0x1000\n\t"                                                     \
+                 "s_nop 0\n\t"                                                                      \
+                 "global_load_lds_dwordx4 %4, %3" POL "\n\t"                                        \
+                 "global_load_lds_dwordx4 %5, %3 offset:1024" POL "\n\t"                            \
+                 "global_load_lds_dwordx4 %6, %3 offset:2048" POL "\n\t"                            \
+                 "global_load_lds_dwordx4 %7, %3 offset:3072" POL "\n\t"                            \
+                 "s_mov_b32 m0, %0"                                                                  \
+                 : "=&s"(keep)                                                                       \
+                 : "s"(lds), "s"(lo), "s"(hi), "v"(v0), "v"(v1), "v"(v2), "v"(v3)                    \
+                 : "memory", "scc")
+// Cache policy: nt (non-temporal).  Round 1 also measured sc1 nt, sc0 sc1 nt, sc1 and no hint on the same box
+// (profiles/r01/r01n_cache_policy_experiment.log): all within the run-to-run spread, none better than nt.
 BNM_DEVICE void lds_dma_tile8_linear(uint32_t lds, const int8_t *lo, const int8_t *hi, uint32_t v0, uint32_t v1,
                                      uint32_t v2, uint32_t v3) {
     uint32_t keep;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 "s_nop 4\n\t"
-                 "s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %1\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %4, %2 nt\n\t"
-                 "global_load_lds_dwordx4 %5, %2 offset:1024 nt\n\t"
-                 "global_load_lds_dwordx4 %6, %2 offset:2048 nt\n\t"
-                 "global_load_lds_dwordx4 %7, %2 offset:3072 nt\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %4, %3 nt\n\t"
-                 "global_load_lds_dwordx4 %5, %3 offset:1024 nt\n\t"
-                 "global_load_lds_dwordx4 %6, %3 offset:2048 nt\n\t"
-                 "global_load_lds_dwordx4 %7, %3 offset:3072 nt\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(lds), "s"(lo), "s"(hi), "v"(v0), "v"(v1), "v"(v2), "v"(v3)
-                 : "memory", "scc");
+    BNM_DMA8_LINEAR(" nt");
 }
 
 template <int M1, int M2, int M3, int M4, bool DBL, int NC8>
