@@ -486,14 +486,24 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
         for (int s = 0; s < KT0; s++) b[s] = *(const i32x4 *)(smem + ((rd_base ^ (32u * s)) + (uint32_t)slot * FUSED_TILE_BYTES));
     };
 
-    if (pair < n_pairs) {
+    const bool any = pair < n_pairs;
+    if (any) {
         dma_tile(2ull * pair, 0);
         dma_tile(2ull * pair + 1ull, 1);
     }
+    // Class ids are stored HALF AN ITERATION LATE (after the next pair's second wait).  vmcnt counts stores too, and
+    // "<= 8 outstanding" retires everything older than the newest 8 operations: a store issued at the end of the
+    // body would sit between the two refills and the next pair's second wait would stall on its write
+    // acknowledgement (~1000 cycles per iteration while HBM is streaming; profiles/r01/conly_r01p...).  Deferred, the
+    // only store either wait can cover is a whole iteration old.  The first iteration's deferred store writes a
+    // placeholder to the wave's own first slot, which the real value overwrites later (same wave, same address,
+    // program order).
+    uint64_t img_prev = (pair << 6) + (uint64_t)lane;
+    uint32_t cls_prev = 0;
     for (; pair < n_pairs; pair += stride) {
         // the refill after the last pair re-reads that pair (keeps the wait counts constant and the body branch-free)
         const uint64_t next = pair + stride < n_pairs ? pair + stride : pair;
-        // outstanding, oldest first: slot 0 (8 pieces), slot 1 (8 pieces), the previous iteration's stores.
+        // outstanding, oldest first: slot 0 (8 pieces), [the deferred store], slot 1 (8 pieces).
         // Loads retire in order among themselves, so "<= 8 left" implies slot 0 has landed.
         bnm_wait_vmcnt<8>();
         i32x4 bA[KT0], bB[KT0];
@@ -502,6 +512,7 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
         layer_mma<M1, KT0, false>(A1, bA, a1A);
         dma_tile(2ull * next, 0);
         bnm_wait_vmcnt<8>();     // slot 1 is now the oldest load group
+        cls_out[img_prev] = cls_prev;
         read_tile(1, bB);
         layer_mma<M1, KT0, false>(A1, bB, a1B);
         dma_tile(2ull * next + 1ull, 1);
@@ -543,10 +554,12 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
                 store_logits<M3>(a3B, logits_out + imgB * n_classes, h, n_classes);
             }
         }
-        // both halves of the wave hold the result: lanes 0..31 store tile A's classes, lanes 32..63 tile B's —
-        // one 256-byte store per pair
-        cls_out[h ? imgB : imgA] = h ? clsB : clsA;
+        // both halves of the wave hold the result: lanes 0..31 keep tile A's classes, lanes 32..63 tile B's —
+        // one 256-byte store per pair, issued in the next iteration (or after the loop)
+        img_prev = h ? imgB : imgA;
+        cls_prev = h ? clsB : clsA;
     }
+    if (any) cls_out[img_prev] = cls_prev;
     bnm_wait_vmcnt<0>();   // LDS-DMA still in flight must not outlive the workgroup's LDS allocation
 }
 
