@@ -51,3 +51,28 @@ def test_no_gpu_means_error_not_fallback(bnm):
     with pytest.raises(bitnetmcu_amd.BnmError) as e:
         bitnetmcu_amd.Context(m)
     assert "(-4)" in str(e.value)
+
+
+def test_qat_entry_points_validate_arguments_before_touching_the_device(bnm):
+    """Argument errors of the QAT ops are reported as such on any machine (no GPU needed, no compute happens)."""
+    import ctypes as C
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+    ws = bnm.bnm_qat_workspace_bytes(256, 64)
+    assert ws >= (256 * 64 + 64) * 4
+    lin = bnm.bnm_qat_bitlinear_forward_device
+    EINVAL, EUNSUP = -1, -3
+    assert lin(p, 1, 0, p, 4, p, 1, 6, 0, p, p, ws, None, None, None, None) == EINVAL          # d == 0
+    assert lin(p, 1, 2000, p, 4, p, 1, 6, 0, p, p, 1 << 30, None, None, None, None) == EINVAL  # d > 1024
+    assert lin(p, 1, 8, p, 4, p, 3, 6, 0, p, p, ws, None, None, None, None) == EINVAL          # s_count not 1 or k
+    assert lin(p, 1, 8, p, 4, p, 1, 99, 0, p, p, ws, None, None, None, None) == EINVAL         # unknown QuantType
+    assert lin(p, 1, 8, p, 4, p, 1, 6, 9, p, p, ws, None, None, None, None) == EINVAL          # unknown NormType
+    assert lin(p, 1, 8, p, 4, p, 1, 6, 0, p, p, 16, None, None, None, None) == EINVAL          # workspace too small
+    assert lin(None, 1, 8, p, 4, p, 1, 6, 0, p, p, ws, None, None, None, None) == EINVAL       # null x with n > 0
+    assert b"workspace" in bnm.bnm_last_error() or b"null" in bnm.bnm_last_error()
+    conv = bnm.bnm_qat_bitconv2d_forward_device
+    wsc = bnm.bnm_qat_workspace_bytes(9, 8)
+    assert conv(p, 1, 4, 8, 8, p, 8, 3, 3, 0, 2, p, 10, 4, p, p, wsc, None) == EUNSUP           # two channels per group
+    assert conv(p, 1, 1, 2, 2, p, 8, 3, 3, 0, 1, p, 10, 4, p, p, wsc, None) == EINVAL           # kernel larger than the plane
+    assert conv(p, 1, 1, 8, 8, p, 8, 3, 3, 0, 1, p, 10, 3, p, p, wsc, None) == EINVAL           # LayerNorm is not a conv NormType
+    assert conv(p, 1, 1, 300, 300, p, 8, 3, 3, 0, 1, p, 10, 4, p, p, wsc, None) == EUNSUP       # plane exceeds the LDS tile
