@@ -442,11 +442,7 @@ BNM_DEVICE void lds_dma_tile8_linear(uint32_t lds, const int8_t *lo, const int8_
     BNM_DMA8_LINEAR(" nt");
 }
 
-// TOUCH (round-1 experiment, variant 4, not a default): one extra 4-byte-per-lane load per refill that touches every
-// 128-byte line of the tile AFTER next, so that the later LDS-DMA of that tile finds it in L2 / MALL instead of
-// waiting on HBM.  The loaded value is never used; its register stays reserved for the whole loop because the
-// load completes asynchronously.  Two more operations per group => the waits become "<= 10 outstanding".
-template <int M1, int M2, int M3, int M4, bool DBL, int NC8, bool TOUCH = false>
+template <int M1, int M2, int M3, int M4, bool DBL, int NC8>
 __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                           const i32x4 *__restrict__ frags,
                                                                           uint32_t n_classes, uint32_t *__restrict__ cls_out,
@@ -485,13 +481,6 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
         const int8_t *base = images + (t & wrap_mask) * (uint64_t)FUSED_TILE_BYTES;
         lds_dma_tile8_linear(lds_wave + (uint32_t)slot * FUSED_TILE_BYTES, base, base + 4096, voff[0], voff[1], voff[2], voff[3]);
     };
-    uint32_t sink0 = 0, sink1 = 0;
-    const uint32_t line_off = (uint32_t)lane * 128u;
-    auto touch_tile = [&](uint64_t t, uint32_t &sink) {
-        const int8_t *base = images + (t & wrap_mask) * (uint64_t)FUSED_TILE_BYTES;
-        asm volatile("global_load_dword %0, %1, %2" : "+v"(sink) : "v"(line_off), "s"(base) : "memory");
-    };
-    constexpr int WAITN = TOUCH ? 10 : 8;
     auto read_tile = [&](int slot, i32x4(&b)[KT0]) {
 #pragma unroll
         for (int s = 0; s < KT0; s++) b[s] = *(const i32x4 *)(smem + ((rd_base ^ (32u * s)) + (uint32_t)slot * FUSED_TILE_BYTES));
@@ -501,11 +490,6 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
     if (any) {
         dma_tile(2ull * pair, 0);
         dma_tile(2ull * pair + 1ull, 1);
-        if constexpr (TOUCH) {
-            const uint64_t nx = pair + stride < n_pairs ? pair + stride : pair;
-            touch_tile(2ull * nx, sink0);
-            touch_tile(2ull * nx + 1ull, sink1);
-        }
     }
     // Class ids are stored HALF AN ITERATION LATE (after the next pair's second wait).  vmcnt counts stores too, and
     // "<= 8 outstanding" retires everything older than the newest 8 operations: a store issued at the end of the
@@ -521,20 +505,17 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
         const uint64_t next = pair + stride < n_pairs ? pair + stride : pair;
         // outstanding, oldest first: slot 0 (8 pieces), [the deferred store], slot 1 (8 pieces).
         // Loads retire in order among themselves, so "<= 8 left" implies slot 0 has landed.
-        const uint64_t next2 = next + stride < n_pairs ? next + stride : next;
-        bnm_wait_vmcnt<WAITN>();
+        bnm_wait_vmcnt<8>();
         i32x4 bA[KT0], bB[KT0];
         i32x16 a1A[M1], a1B[M1];
         read_tile(0, bA);
         layer_mma<M1, KT0, false>(A1, bA, a1A);
         dma_tile(2ull * next, 0);
-        if constexpr (TOUCH) touch_tile(2ull * next2, sink0);
-        bnm_wait_vmcnt<WAITN>();     // slot 1 is now the oldest load group
+        bnm_wait_vmcnt<8>();     // slot 1 is now the oldest load group
         cls_out[img_prev] = cls_prev;
         read_tile(1, bB);
         layer_mma<M1, KT0, false>(A1, bB, a1B);
         dma_tile(2ull * next + 1ull, 1);
-        if constexpr (TOUCH) touch_tile(2ull * next2 + 1ull, sink1);
 
         i32x4 p1A[M1], p1B[M1];
         relunorm_pack<M1, DBL>(a1A, p1A, h);
@@ -580,7 +561,6 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
     }
     if (any) cls_out[img_prev] = cls_prev;
     bnm_wait_vmcnt<0>();   // LDS-DMA still in flight must not outlive the workgroup's LDS allocation
-    if constexpr (TOUCH) asm volatile("" ::"v"(sink0), "v"(sink1));   // the sinks stay reserved until here
 }
 
 // ---- dispatch table: model shapes of the reference zoo (+ ternary) -----------------------------
@@ -600,7 +580,6 @@ const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
     { {8, {2, 2, 2, 1}, false, true, 2}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, true, 2> },
     { {8, {2, 2, 2, 1}, false, true, 0}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, true, 0> },
-    { {8, {2, 2, 2, 1}, false, true, 2}, FUSED_DUAL + 1, fused_fc_dual_kernel<2, 2, 2, 1, true, 2, true> },
     FUSED_ANY_AND_10(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA2),
     FUSED_ANY_AND_10(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA),
     FUSED(8, 2, 2, 2, 1, false, true, FUSED_DIRECT, 0),
@@ -657,7 +636,7 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
     const FusedEntry *e = find_fused(sh, variant);
     if (!e) return hipErrorInvalidValue;
     if (a.n == 0) return hipSuccess;
-    if (variant >= FUSED_DUAL) {
+    if (variant == FUSED_DUAL) {
         // whole 64-image pairs go to the dual-tile kernel, the remainder (< 64 images) to variant 2
         const uint64_t n_main = a.n & ~63ull;
         if (n_main) {
