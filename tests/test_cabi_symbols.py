@@ -76,3 +76,22 @@ def test_qat_entry_points_validate_arguments_before_touching_the_device(bnm):
     assert conv(p, 1, 1, 2, 2, p, 8, 3, 3, 0, 1, p, 10, 4, p, p, wsc, None) == EINVAL           # kernel larger than the plane
     assert conv(p, 1, 1, 8, 8, p, 8, 3, 3, 0, 1, p, 10, 3, p, p, wsc, None) == EINVAL           # LayerNorm is not a conv NormType
     assert conv(p, 1, 1, 300, 300, p, 8, 3, 3, 0, 1, p, 10, 4, p, p, wsc, None) == EUNSUP       # plane exceeds the LDS tile
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/bitnetmcu_hip.h is the drop-in boundary: plain C99 (and C++) with no torch / HIP types, and a C host
+    links against the library with nothing but gcc."""
+    hdr = os.path.join(REPO, "include")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "bitnetmcu_hip.h"\nint main(void) { return sizeof(bnm_layer_info) ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", hdr, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", hdr, str(src)])
+    text = open(os.path.join(hdr, "bitnetmcu_hip.h")).read()
+    assert "torch" not in text and "hip/hip_runtime" not in text
+    exe = tmp_path / "batch_infer"
+    libdir = os.path.join(REPO, "bitnetmcu_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", hdr,
+                           os.path.join(REPO, "examples", "batch_infer.c"), "-L", libdir, "-lbitnetmcu_hip",
+                           f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
