@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbitnetmcu_hip.so")
+# BNM_LIBRARY: load another build of the same library instead (diagnostic builds, see build.py --diag-timing)
+LIB_PATH = os.environ.get("BNM_LIBRARY") or os.path.join(HERE, "libbitnetmcu_hip.so")
 
 BNM_OK = 0
 KIND_FC, KIND_CNN = 0, 1

@@ -34,17 +34,18 @@ def newer(src_list, out):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def objects(force=False):
-    os.makedirs(OBJ, exist_ok=True)
+def objects(force=False, extra_flags=(), obj_dir=None):
+    obj_dir = obj_dir or OBJ
+    os.makedirs(obj_dir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in ("bnm_kernels.h", "bnm_model.hpp", "bnm_device.hpp")] + \
            [os.path.join(HERE, "..", "include", "bitnetmcu_hip.h")]
     out, jobs = [], []
     for src, is_hip in (("bnm_fused_fc.hip", True), ("bnm_cnn.hip", True), ("bnm_ternary.hip", True), ("bnm_layerwise.hip", True),
                         ("bnm_support.hip", True), ("bnm_qat.hip", True), ("bnm_capi.cpp", False), ("bnm_model.cpp", False)):
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        o = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         if force or newer([s] + hdrs, o):
-            cmd = [HIPCC, f"--offload-arch={ARCH}"] + CXXFLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC, f"--offload-arch={ARCH}"] + CXXFLAGS + list(extra_flags) + ["-c", s, "-o", o]
             if not is_hip:
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")
@@ -62,6 +63,15 @@ def build_lib(force=False):
     if force or newer(objs, LIB):
         run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", LIB] + objs)
     return LIB
+
+
+def build_diag_timing():
+    """Diagnostic library: the dual-tile kernel stamps the shader clock around its two vmcnt waits and writes the
+    per-wave sums into the logits buffer (profiles/wait_timing.py).  Never used by the product or the tests."""
+    lib = os.path.join(HERE, "libbitnetmcu_hip_timing.so")
+    objs = objects(extra_flags=["-DBNM_DIAG_TIMING"], obj_dir=os.path.join(HERE, "_build_timing"))
+    run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", lib] + objs)
+    return lib
 
 
 def build_dll(header, outdir):
@@ -82,8 +92,11 @@ def main():
     ap.add_argument("--dll", metavar="MODEL_H", help="build a model-bound Bitnet_inf.dll from this header")
     ap.add_argument("-o", "--outdir", default=".")
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--diag-timing", action="store_true", help="build libbitnetmcu_hip_timing.so (diagnostics only)")
     a = ap.parse_args()
-    if a.dll:
+    if a.diag_timing:
+        print(build_diag_timing())
+    elif a.dll:
         print(build_dll(a.dll, a.outdir))
     else:
         print(build_lib(a.force))

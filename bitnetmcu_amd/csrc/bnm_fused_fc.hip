@@ -500,18 +500,36 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
     // program order).
     uint64_t img_prev = (pair << 6) + (uint64_t)lane;
     uint32_t cls_prev = 0;
+#ifdef BNM_DIAG_TIMING
+    // diagnostic build only (build.py --diag-timing; profiles/wait_timing.py): shader-clock stamps around the two waits
+    uint64_t t_wait_a = 0, t_wait_b = 0, t_iters = 0;
+    const uint64_t t_start = __builtin_readcyclecounter();
+#endif
     for (; pair < n_pairs; pair += stride) {
         // the refill after the last pair re-reads that pair (keeps the wait counts constant and the body branch-free)
         const uint64_t next = pair + stride < n_pairs ? pair + stride : pair;
         // outstanding, oldest first: slot 0 (8 pieces), [the deferred store], slot 1 (8 pieces).
         // Loads retire in order among themselves, so "<= 8 left" implies slot 0 has landed.
+#ifdef BNM_DIAG_TIMING
+        const uint64_t t0 = __builtin_readcyclecounter();
+#endif
         bnm_wait_vmcnt<8>();
+#ifdef BNM_DIAG_TIMING
+        t_wait_a += __builtin_readcyclecounter() - t0;
+        t_iters++;
+#endif
         i32x4 bA[KT0], bB[KT0];
         i32x16 a1A[M1], a1B[M1];
         read_tile(0, bA);
         layer_mma<M1, KT0, false>(A1, bA, a1A);
         dma_tile(2ull * next, 0);
+#ifdef BNM_DIAG_TIMING
+        const uint64_t t2 = __builtin_readcyclecounter();
+#endif
         bnm_wait_vmcnt<8>();     // slot 1 is now the oldest load group
+#ifdef BNM_DIAG_TIMING
+        t_wait_b += __builtin_readcyclecounter() - t2;
+#endif
         cls_out[img_prev] = cls_prev;
         read_tile(1, bB);
         layer_mma<M1, KT0, false>(A1, bB, a1B);
@@ -542,17 +560,21 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
             layer_mma<M4, M3, false>(A4, p3B, a4B);
             clsA = argmax_rows<M4, NC8>(a4A, h);
             clsB = argmax_rows<M4, NC8>(a4B, h);
+#ifndef BNM_DIAG_TIMING
             if (logits_out) {
                 store_logits<M4>(a4A, logits_out + imgA * n_classes, h, n_classes);
                 store_logits<M4>(a4B, logits_out + imgB * n_classes, h, n_classes);
             }
+#endif
         } else {
             clsA = argmax_rows<M3, NC8>(a3A, h);
             clsB = argmax_rows<M3, NC8>(a3B, h);
+#ifndef BNM_DIAG_TIMING
             if (logits_out) {
                 store_logits<M3>(a3A, logits_out + imgA * n_classes, h, n_classes);
                 store_logits<M3>(a3B, logits_out + imgB * n_classes, h, n_classes);
             }
+#endif
         }
         // both halves of the wave hold the result: lanes 0..31 keep tile A's classes, lanes 32..63 tile B's —
         // one 256-byte store per pair, issued in the next iteration (or after the loop)
@@ -561,6 +583,16 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
     }
     if (any) cls_out[img_prev] = cls_prev;
     bnm_wait_vmcnt<0>();   // LDS-DMA still in flight must not outlive the workgroup's LDS allocation
+#ifdef BNM_DIAG_TIMING
+    // the logits buffer is reused as the record array: 4 x uint64 per wave {loop cycles, wait A, wait B, iterations}
+    if (logits_out && lane == 0) {
+        uint64_t *rec = (uint64_t *)logits_out + 4ull * ((uint64_t)blockIdx.x * FUSED_WPB + (uint64_t)wave);
+        rec[0] = __builtin_readcyclecounter() - t_start;
+        rec[1] = t_wait_a;
+        rec[2] = t_wait_b;
+        rec[3] = t_iters;
+    }
+#endif
 }
 
 // ---- dispatch table: model shapes of the reference zoo (+ ternary) -----------------------------
