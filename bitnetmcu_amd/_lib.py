@@ -71,7 +71,6 @@ PROTOTYPES = {
                                                    C.c_int, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "bnm_synth_fill_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "bnm_class_digest_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, _vp]),
-    "bnm_diag_stream_device": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, _vp, _vp]),
     "bnm_run_synth_multi_gpu": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, C.c_uint64, _vp, C.c_uint32, C.POINTER(C.c_double)]),
     "bnm_bind_default_model": (C.c_int, [_vp]),
     "bnm_device_count": (C.c_int, []),
@@ -80,6 +79,13 @@ PROTOTYPES = {
     "bnm_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "bnm_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "bnm_device_synchronize": (C.c_int, []),
+}
+
+
+# diagnostic library only (bitnetmcu_amd/build.py --diag, csrc/bnm_diag.h): bound when present, never required
+DIAG_PROTOTYPES = {
+    "bnm_diag_stream_device": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, _vp, _vp]),
+    "bnm_diag_set_src_wrap": (C.c_int, [_vp, C.c_uint64]),
 }
 
 
@@ -100,6 +106,9 @@ def bind(lib, strict=True):
         fn.argtypes = args
     if missing and strict:
         raise BnmError(f"{lib._name} does not export: {missing}")
+    for name, (res, args) in DIAG_PROTOTYPES.items():
+        if hasattr(lib, name):
+            getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
     return lib
 
 

@@ -34,14 +34,23 @@ def newer(src_list, out):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def objects(force=False, extra_flags=(), obj_dir=None):
+SOURCES = (("bnm_fused_fc.hip", True), ("bnm_fused_generic.hip", True), ("bnm_fused_generic_m2.hip", True),
+           ("bnm_fused_generic_m4.hip", True), ("bnm_fused_generic_m8.hip", True), ("bnm_cnn.hip", True), ("bnm_ternary.hip", True),
+           ("bnm_layerwise.hip", True), ("bnm_support.hip", True), ("bnm_qat.hip", True), ("bnm_capi.cpp", False),
+           ("bnm_model.cpp", False))
+DIAG_SOURCES = (("bnm_diag.hip", True),)      # diagnostic library only (--diag / --diag-timing)
+
+
+def objects(force=False, extra_flags=(), obj_dir=None, sources=SOURCES):
+    """Compile what is out of date; prints one 'build: compiled|reused <object>' line per translation unit so that a
+    build log shows whether the compiler actually ran (BNM_FORCE_BUILD=1 or --force recompiles everything)."""
     obj_dir = obj_dir or OBJ
+    force = force or os.environ.get("BNM_FORCE_BUILD") == "1"
     os.makedirs(obj_dir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in ("bnm_kernels.h", "bnm_model.hpp", "bnm_device.hpp")] + \
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".hpp"))] + \
            [os.path.join(HERE, "..", "include", "bitnetmcu_hip.h")]
     out, jobs = [], []
-    for src, is_hip in (("bnm_fused_fc.hip", True), ("bnm_cnn.hip", True), ("bnm_ternary.hip", True), ("bnm_layerwise.hip", True),
-                        ("bnm_support.hip", True), ("bnm_qat.hip", True), ("bnm_capi.cpp", False), ("bnm_model.cpp", False)):
+    for src, is_hip in sources:
         s = os.path.join(CSRC, src)
         o = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         if force or newer([s] + hdrs, o):
@@ -50,6 +59,9 @@ def objects(force=False, extra_flags=(), obj_dir=None):
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")
             jobs.append(cmd)
+            print("build: compiled", os.path.relpath(o, HERE), flush=True)
+        else:
+            print("build: reused  ", os.path.relpath(o, HERE), flush=True)
         out.append(o)
     if jobs:   # translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
@@ -65,11 +77,15 @@ def build_lib(force=False):
     return LIB
 
 
-def build_diag_timing():
-    """Diagnostic library: the dual-tile kernel stamps the shader clock around its two vmcnt waits and writes the
-    per-wave sums into the logits buffer (profiles/wait_timing.py).  Never used by the product or the tests."""
-    lib = os.path.join(HERE, "libbitnetmcu_hip_timing.so")
-    objs = objects(extra_flags=["-DBNM_DIAG_TIMING"], obj_dir=os.path.join(HERE, "_build_timing"))
+def build_diag(timing=False):
+    """Diagnostic library (never used by the product, the tests or bench.py's default run): the product sources compiled
+    with -DBNM_DIAG — the fused kernels honour bnm_diag_set_src_wrap (cache-resident source) — plus bnm_diag.hip's
+    stream / pipe-overlap probes (csrc/bnm_diag.h).  timing=True additionally stamps the shader clock around the dual
+    kernel's two vmcnt waits and writes the per-wave sums into the logits buffer (profiles/wait_timing.py)."""
+    lib = os.path.join(HERE, "libbitnetmcu_hip_timing.so" if timing else "libbitnetmcu_hip_diag.so")
+    flags = ["-DBNM_DIAG"] + (["-DBNM_DIAG_TIMING"] if timing else [])
+    objs = objects(extra_flags=flags, obj_dir=os.path.join(HERE, "_build_timing" if timing else "_build_diag"),
+                   sources=SOURCES + DIAG_SOURCES)
     run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", lib] + objs)
     return lib
 
@@ -92,10 +108,11 @@ def main():
     ap.add_argument("--dll", metavar="MODEL_H", help="build a model-bound Bitnet_inf.dll from this header")
     ap.add_argument("-o", "--outdir", default=".")
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--diag", action="store_true", help="build libbitnetmcu_hip_diag.so (diagnostics only, csrc/bnm_diag.h)")
     ap.add_argument("--diag-timing", action="store_true", help="build libbitnetmcu_hip_timing.so (diagnostics only)")
     a = ap.parse_args()
-    if a.diag_timing:
-        print(build_diag_timing())
+    if a.diag or a.diag_timing:
+        print(build_diag(timing=a.diag_timing))
     elif a.dll:
         print(build_dll(a.dll, a.outdir))
     else:

@@ -11,6 +11,9 @@
 #include <vector>
 #include "bnm_kernels.h"
 #include "bnm_model.hpp"
+#ifdef BNM_DIAG
+#include "bnm_diag.h"
+#endif
 
 namespace {
 
@@ -72,14 +75,23 @@ struct bnm_ctx {
     // CNN front end
     uint32_t channels = 0;
     int8_t *w_conv[3] = {nullptr, nullptr, nullptr};
-    // fused MFMA path
-    bool fused_ok = false;
+    // fused MFMA path: shape-specialised kernels (register-resident weights, bnm_fused_fc.hip) and / or the generic
+    // kernel (run-time widths, weights in LDS, bnm_fused_generic.hip; variant id BNM_FUSED_GENERIC)
+    bool fused_ok = false;      // at least one of the two can run this model
+    bool table_ok = false, generic_ok = false;
     BnmFusedShape shape{};
-    void *frags = nullptr;
+    BnmGenericDesc gdesc{};
+    void *frags = nullptr, *gfrags = nullptr;
+    uint32_t in_width = 256;    // bytes of one input row of the FC stack (256, or 4*C behind the CNN front end)
     int variant = -1, grid_blocks = 0;
     // ternary ALU path
     bool tern_ok = false;
     int requested_path = BNM_PATH_AUTO, path = BNM_PATH_LAYERWISE_ALU;
+    bool warned_layerwise = false;
+    std::string fused_reason = "unknown";   // why fused_ok is false
+#ifdef BNM_DIAG
+    uint64_t diag_src_wrap = 0;
+#endif
     // scratch
     DevBuf act_a, act_b, out32, argmax, cnn_feat, stage_img, stage_cls, stage_logits;
     std::vector<void *> owned;
@@ -97,7 +109,15 @@ int resolve_path(bnm_ctx *c) {
     if (want == BNM_PATH_AUTO) {
         if (c->model.kind == BNM_KIND_FC && all_tern && c->tern_ok) want = BNM_PATH_TERNARY_ALU;
         else if (c->fused_ok) want = BNM_PATH_FUSED_MFMA;
-        else want = BNM_PATH_LAYERWISE_ALU;
+        else {
+            want = BNM_PATH_LAYERWISE_ALU;
+            // no silent cliffs: this path is orders of magnitude slower than the fused kernels
+            if (!c->warned_layerwise && !std::getenv("BNM_QUIET")) {
+                std::fprintf(stderr, "bitnetmcu_hip: model is outside the fused MFMA kernels (%s); using the layer-wise ALU "
+                                     "path, which is about 500x slower\n", c->fused_reason.c_str());
+                c->warned_layerwise = true;
+            }
+        }
     }
     if (want == BNM_PATH_FUSED_MFMA && !c->fused_ok)
         return fail(BNM_EUNSUPPORTED, "model shape/codec is outside the fused MFMA kernel table");
@@ -168,11 +188,17 @@ int ctx_build(bnm_ctx *c) {
         c->fc.push_back(d);
     }
 
-    // ---- fused MFMA path: shape + fragment buffer --------------------------------------------------
+    // ---- fused MFMA path: shape + fragment buffers ------------------------------------------------------
     const size_t nfc = c->fc.size();
-    if (all_known && (nfc == 3 || nfc == 4) && in_width % 32u == 0) {
+    c->in_width = in_width;
+    uint32_t max_width = 0;
+    for (auto &l : c->fc) max_width = l.info.n_output > max_width ? l.info.n_output : max_width;
+    if (!all_known) c->fused_reason = "a layer uses a codec the C engine does not decode";
+    else if (nfc != 3 && nfc != 4) c->fused_reason = "the reference wrapper's FC stack has 3 or 4 layers";
+    else if (max_width > 256) c->fused_reason = "a layer is wider than 256 outputs";
+    else if (in_width > 512) c->fused_reason = "input rows longer than 512 bytes";
+    else {
         BnmFusedShape sh{};
-        sh.KT0 = (int)(in_width / 32u);
         for (size_t i = 0; i < 4; i++) sh.M[i] = i < nfc ? (int)((c->fc[i].info.n_output + 31u) / 32u) : 0;
         sh.split = any_fp130;
         sh.nc8 = (int)((c->fc[nfc - 1].info.n_output + 7u) / 8u);
@@ -180,37 +206,69 @@ int ctx_build(bnm_ctx *c) {
         sh.dbl = true;
         for (size_t i = 0; i + 1 < nfc; i++)
             if (c->fc[i].info.bits_per_weight == 16 || c->fc[i].info.bits_per_weight == 20) sh.dbl = false;
-        int var = bnmk_fused_default_variant(sh);
-        if (bnmk_fused_supported(sh, var)) {
-            const int sp = sh.split ? 2 : 1;
-            size_t frag_count = 0;
-            int kt = sh.KT0;
-            for (size_t i = 0; i < nfc; i++) { frag_count += (size_t)sh.M[i] * kt * sp; kt = sh.M[i]; }
-            if (int e = dev_alloc(c, &c->frags, frag_count * 1024)) return e;
-            char *dst = (char *)c->frags;
-            kt = sh.KT0;
+        const int sp = sh.split ? 2 : 1;
+        // fragment image for input rows of kt0 K-steps: per layer, per 32-row tile m: [KT lo fragments][KT hi fragments]
+        // fragment image: per layer, per 32-row tile m: [ktp lo fragments][ktp hi fragments]; mt[i] tiles (>= the real
+        // count: surplus tiles and K-steps hold zero weights), ktp[i] K-steps; layer i starts at layer_off[i]
+        auto build_frags = [&](const uint32_t *mt, const uint32_t *ktp, const uint32_t *layer_off, uint32_t total, void **out) -> int {
+            if (int e = dev_alloc(c, out, total)) return e;
+            HIP_TRY(hipMemsetAsync(*out, 0, total, s));
             for (size_t i = 0; i < nfc; i++) {
                 const FcDev &d = c->fc[i];
-                // per M-tile the kernel expects [KT lo fragments][KT hi fragments]; the builder emits
-                // [m][s], so lo and hi are built per m into the interleaved place
-                for (int mt = 0; mt < sh.M[i]; mt++) {
+                char *dst = (char *)*out + layer_off[i];
+                const uint32_t kt = ktp[i];
+                const uint32_t real_tiles = (d.info.n_output + 31u) / 32u;
+                for (uint32_t m = 0; m < mt[i]; m++) {
                     for (int part = 0; part < sp; part++) {
-                        const int8_t *rows = (part == 0 ? d.rows_lo : d.rows_hi) + (size_t)mt * 32u * d.row_stride;
-                        uint32_t rows_left = d.info.n_output > (uint32_t)mt * 32u ? d.info.n_output - (uint32_t)mt * 32u : 0u;
+                        const bool past = m >= real_tiles;      // surplus tile: no rows to read
+                        const int8_t *rows = (part == 0 ? d.rows_lo : d.rows_hi) + (past ? 0 : (size_t)m * 32u * d.row_stride);
+                        const uint32_t rows_left = past ? 0u : d.info.n_output - m * 32u;
                         const int scale = (sh.dbl && i + 1 < nfc) ? 2 : 1;   // hidden layers only
                         // classifier layer: padding rows weigh -128 so they can never win the argmax (first plane only)
                         const int pad = (i + 1 == nfc && part == 0) ? -128 : 0;
-                        HIP_TRY(bnmk_build_fragments(rows, d.row_stride, rows_left, d.n_real, 1, (uint32_t)kt, i == 0 ? 0 : 1, scale,
-                                                     pad, dst + ((size_t)mt * kt * sp + (size_t)part * kt) * 1024, s));
+                        HIP_TRY(bnmk_build_fragments(rows, d.row_stride, rows_left, d.n_real, 1, kt, i == 0 ? 0 : 1, scale, pad,
+                                                     dst + ((size_t)m * kt * sp + (size_t)part * kt) * 1024, s));
                     }
                 }
-                dst += (size_t)sh.M[i] * kt * sp * 1024;
-                kt = sh.M[i];
             }
-            c->shape = sh;
-            c->variant = var;
-            c->fused_ok = true;
+            return BNM_OK;
+        };
+        // (1) shape-specialised kernels: the reference zoo's shapes
+        if (in_width % 32u == 0) {
+            sh.KT0 = (int)(in_width / 32u);
+            int var = bnmk_fused_default_variant(sh);
+            if (bnmk_fused_supported(sh, var)) {
+                uint32_t mt[4], ktp[4], off[4], bytes = 0, kt = (uint32_t)sh.KT0;
+                for (size_t i = 0; i < nfc; i++) {
+                    mt[i] = (uint32_t)sh.M[i]; ktp[i] = kt; off[i] = bytes;
+                    bytes += mt[i] * kt * (uint32_t)sp * 1024u;
+                    kt = mt[i];
+                }
+                if (int e = build_frags(mt, ktp, off, bytes, &c->frags)) return e;
+                c->table_ok = true;
+                c->variant = var;
+            }
         }
+        c->shape = sh;
+        // (2) generic kernel: any widths; input rows padded to 64 / 128 / 256 / 512 bytes (the CNN front end writes
+        // its act rows with that stride; the fragment builder gives the padding columns weight 0)
+        BnmGenericDesc gd{};
+        uint32_t row = 64;
+        while (row < in_width) row *= 2;
+        gd.KT0 = row / 32u;
+        gd.sp = (uint32_t)sp;
+        gd.n_classes = c->fc[nfc - 1].info.n_output;
+        uint32_t m_real[4];
+        for (size_t i = 0; i < 4; i++) m_real[i] = (uint32_t)sh.M[i];
+        if (bnmk_generic_plan(gd, m_real) && bnmk_generic_supported(gd, sh.dbl)) {
+            if (int e = build_frags(gd.M, gd.KTP, gd.frag_off, gd.w_bytes, &c->gfrags)) return e;
+            c->gdesc = gd;
+            c->generic_ok = true;
+            if (!c->table_ok) c->variant = BNM_FUSED_GENERIC;
+        } else if (!c->table_ok) {
+            c->fused_reason = "the weight fragments do not fit beside the image tiles in 160 KiB of LDS";
+        }
+        c->fused_ok = c->table_ok || c->generic_ok;
     }
     // ---- ternary ALU path ------------------------------------------------------------------------------
     if (m.kind == BNM_KIND_FC && all_tern && nfc == 4 && c->fc[0].n_real == 256 && c->fc[0].info.n_output == 96 &&
@@ -222,6 +280,10 @@ int ctx_build(bnm_ctx *c) {
 
 // ---- whole-model launches on device data -----------------------------------------------------------
 int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32_t *d_logits, hipStream_t s) {
+    if (c->variant == BNM_FUSED_GENERIC) {
+        HIP_TRY(bnmk_fused_generic(c->gdesc, c->shape.dbl, c->grid_blocks, d_in, n, c->gfrags, d_cls, d_logits, s));
+        return BNM_OK;
+    }
     BnmFusedArgs a{};
     a.images = d_in;
     a.n = n;
@@ -229,7 +291,9 @@ int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32
     a.n_classes = c->model.num_classes();
     a.cls = d_cls;
     a.logits = d_logits;
-    if (const char *w = std::getenv("BNM_DIAG_SRC_WRAP")) a.src_wrap = std::strtoull(w, nullptr, 10);   // diagnostics only
+#ifdef BNM_DIAG
+    a.src_wrap = c->diag_src_wrap;   // diagnostic library only (bnm_diag_set_src_wrap)
+#endif
     HIP_TRY(bnmk_fused_fc(c->shape, c->variant, c->grid_blocks, a, s));
     return BNM_OK;
 }
@@ -298,17 +362,19 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
     }
     // CNN: front end (conv/pool/ReLUNorm fused) -> int8 [n][4C] -> FC tail
     const uint32_t W = c->channels * 4u;
+    // act rows: 4*C bytes, padded to the generic kernel's row length when that kernel runs the FC tail
+    const uint32_t AS = (path == BNM_PATH_FUSED_MFMA && c->variant == BNM_FUSED_GENERIC) ? c->gdesc.KT0 * 32u : W;
     for (uint64_t off = 0; off < n; off += kChunk) {
         uint64_t cn = n - off < kChunk ? n - off : kChunk;
         // the FC tail reads act rows with 16-byte vector loads: keep the buffer padded
-        if (int e = c->cnn_feat.ensure((size_t)cn * W * 4 + (size_t)cn * W + 64)) return e;
+        if (int e = c->cnn_feat.ensure((size_t)cn * W * 4 + (size_t)cn * AS + 64)) return e;
         int32_t *feat = (c->channels > 64 || d_acts_tap) ? (int32_t *)c->cnn_feat.p : nullptr;
         int8_t *acts = (int8_t *)c->cnn_feat.p + (size_t)cn * W * 4;
-        HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->channels, 4, acts, feat, s));
+        HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->channels, 4, acts, AS, feat, s));
         uint32_t *cls = d_cls + off;
         int32_t *lg = d_logits ? d_logits + off * ncls : nullptr;
         if (d_acts_tap)
-            HIP_TRY(hipMemcpy2DAsync(d_acts_tap + off * tap_stride, tap_stride, acts, W, W, cn, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpy2DAsync(d_acts_tap + off * tap_stride, tap_stride, acts, AS, W, cn, hipMemcpyDeviceToDevice, s));
         if (path == BNM_PATH_FUSED_MFMA) {
             if (int e = run_fused(c, acts, cn, cls, lg, s)) return e;
         } else {
@@ -438,8 +504,8 @@ int bnm_ctx_get_variant(const bnm_ctx *c) {
 int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
     if (!c) return fail(BNM_EINVAL, "null ctx");
     if (variant >= 0) {
-        if (!c->fused_ok || !bnmk_fused_supported(c->shape, variant))
-            return fail(BNM_EUNSUPPORTED, "fused kernel variant not available for this model shape");
+        const bool ok = variant == BNM_FUSED_GENERIC ? c->generic_ok : (c->table_ok && bnmk_fused_supported(c->shape, variant));
+        if (!ok) return fail(BNM_EUNSUPPORTED, "fused kernel variant not available for this model shape");
         c->variant = variant;
     }
     c->grid_blocks = grid_blocks > 0 ? grid_blocks : 0;
@@ -588,6 +654,8 @@ int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint64_t n, u
     return BNM_OK;
 }
 
+#ifdef BNM_DIAG
+// ---- diagnostic library only (bitnetmcu_amd/build.py --diag; declared in csrc/bnm_diag.h, not in the public header) ----
 int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out, void *stream) {
     if (n && (!d_images || !d_out)) return fail(BNM_EINVAL, "null pointer");
     if (mode < 0 || mode > 7) return fail(BNM_EINVAL, "mode must be 0..7");
@@ -598,6 +666,13 @@ int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int gri
     HIP_TRY(bnmk_diag_stream(d_images, n, mode, grid_blocks, d_out, (hipStream_t)stream));
     return BNM_OK;
 }
+// the fused kernels read tile (t mod wrap) instead of tile t: WRONG class ids by design, timing only
+int bnm_diag_set_src_wrap(bnm_ctx *c, uint64_t wrap) {
+    if (!c) return fail(BNM_EINVAL, "null ctx");
+    c->diag_src_wrap = wrap;
+    return BNM_OK;
+}
+#endif
 
 int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, int dist, uint64_t seed, uint64_t *digest_hist,
                             uint32_t n_bins, double *seconds) {

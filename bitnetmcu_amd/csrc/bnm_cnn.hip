@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
                                                         const int8_t *__restrict__ w1, const int8_t *__restrict__ w2,
                                                         const int8_t *__restrict__ w3, uint32_t C, uint32_t c0,
                                                         uint32_t n_shift, int8_t *__restrict__ acts,
-                                                        int32_t *__restrict__ feat) {
+                                                        uint32_t acts_stride, int32_t *__restrict__ feat) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = (uint64_t)blockIdx.x * 4u + (uint64_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4u;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
                 uint32_t d = 0;
 #pragma unroll
                 for (int t = 0; t < 4; t++) d |= (uint32_t)min((f[t] + rnd) >> sh, 127) << (8 * t);
-                *(uint32_t *)(acts + img * (4ull * C) + 4ull * c) = d;
+                *(uint32_t *)(acts + img * (uint64_t)acts_stride + 4ull * c) = d;
             }
         }
     }
@@ -199,23 +199,23 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
 // acts: int8 [n][4C] (always produced).  feat: int32 [n][4C]; optional when C <= 64, REQUIRED scratch when
 // C > 64 (several channel groups: ReLUNorm then runs as its own kernel over the complete vector).
 hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, const int8_t *w2, const int8_t *w3,
-                          uint32_t C, uint32_t n_shift, int8_t *acts, int32_t *feat, hipStream_t s) {
+                          uint32_t C, uint32_t n_shift, int8_t *acts, uint32_t acts_stride, int32_t *feat, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (C == 0 || C > 256 || n_shift < 4 || n_shift > 31) return hipErrorInvalidValue;
+    if (C == 0 || C > 256 || n_shift < 4 || n_shift > 31 || acts_stride < 4u * C || (acts_stride & 3u)) return hipErrorInvalidValue;
     uint64_t blocks = (n + 3) / 4;
     uint64_t cap = (uint64_t)bnm_num_cus() * 4ull;
     if (blocks > cap) blocks = cap;
     dim3 g((unsigned)blocks), b(256);
     if (C <= 64) {
-        cnn_front_kernel<true><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, 0, n_shift, acts, feat);
+        cnn_front_kernel<true><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, 0, n_shift, acts, acts_stride, feat);
         return hipGetLastError();
     }
     if (!feat) return hipErrorInvalidValue;
     for (uint32_t c0 = 0; c0 < C; c0 += 64) {
-        cnn_front_kernel<false><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, c0, n_shift, acts, feat);
+        cnn_front_kernel<false><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, c0, n_shift, acts, acts_stride, feat);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    return bnmk_relunorm(feat, 4u * C, acts, 4u * C, nullptr, n, s);
+    return bnmk_relunorm(feat, 4u * C, acts, acts_stride, nullptr, n, s);
 }
 

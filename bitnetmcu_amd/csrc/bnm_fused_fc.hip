@@ -1,8 +1,9 @@
-// Fused whole-model FC kernel (int8 MFMA) + the stream-only diagnostics that share its tile loop.
+// Fused whole-model FC kernels (int8 MFMA), register-resident weights, specialised per model shape.
 // gfx950 (CDNA4 / MI355X) only; see DESIGN.md for layouts and rooflines.  Reference semantics:
 // BitNetMCU_inference.c:23-72 (ReLUNorm), :88-208 (processfclayer), :238-277 (conv), :300-322 (pool);
 // schedule BitNetMCU_MNIST_dll.c:48-121.
-#include "bnm_device.hpp"
+#include "bnm_fused_tile.hpp"
+#include "bnm_fused_math.hpp"
 
 // =================================================================================================
 // Fused whole-model FC kernel.
@@ -31,13 +32,6 @@ struct AFrags {
     }
 };
 
-BNM_DEVICE i32x16 zero16() {
-    i32x16 z;
-#pragma unroll
-    for (int i = 0; i < 16; i++) z[i] = 0;
-    return z;
-}
-
 template <int MT, int KT, bool SPLIT>
 BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 (&b)[KT], i32x16 (&acc)[MT]) {
 #pragma unroll
@@ -54,188 +48,6 @@ BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 
                 acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A.a[m][KT + s], b[s], acc[m], 0, 0, 0);
     }
 }
-
-// max(x, x of lane ^ 32): swapping the upper half of one copy with the lower half of another leaves
-// {x_lo, x_lo} and {x_hi, x_hi}, whose maximum is the answer in every lane — no select on the half index
-BNM_DEVICE int max_with_partner32(int x) {
-    auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-    return max((int)r[0], (int)r[1]);
-}
-
-// clamp to [0, hi] in ONE instruction.  hipcc only forms v_med3_i32 from min(max(x, lo), hi) when it can prove
-// lo <= hi (constants); with a run-time hi it emits v_max + v_min.
-BNM_DEVICE int clamp0_med3(int x, int hi) {
-    int r;
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
-    return r;
-}
-
-// 16 clamped values -> 4 dwords, byte b of dword q = c[4q+b] >> s.  One SDWA shift per value writes its result
-// byte straight into place (dst_sel:BYTE_b, dst_unused:UNUSED_PRESERVE), so no separate pack instructions.
-// Same-register writes are 4 instructions apart and a trailing s_nop covers the dst_sel forwarding hazard that
-// hipcc cannot see inside an asm statement.
-BNM_DEVICE i32x4 sdwa_shift_pack16(const int (&c)[16], int s) {
-    int d0, d1, d2, d3;
-#define SD(dst, src, sel, unused) \
-    "v_lshrrev_b32_sdwa " dst ", %4, " src " dst_sel:" sel " dst_unused:" unused " src0_sel:DWORD src1_sel:DWORD\n\t"
-    asm(SD("%0", "%5", "BYTE_0", "UNUSED_PAD") SD("%1", "%9", "BYTE_0", "UNUSED_PAD")
-        SD("%2", "%13", "BYTE_0", "UNUSED_PAD") SD("%3", "%17", "BYTE_0", "UNUSED_PAD")
-        SD("%0", "%6", "BYTE_1", "UNUSED_PRESERVE") SD("%1", "%10", "BYTE_1", "UNUSED_PRESERVE")
-        SD("%2", "%14", "BYTE_1", "UNUSED_PRESERVE") SD("%3", "%18", "BYTE_1", "UNUSED_PRESERVE")
-        SD("%0", "%7", "BYTE_2", "UNUSED_PRESERVE") SD("%1", "%11", "BYTE_2", "UNUSED_PRESERVE")
-        SD("%2", "%15", "BYTE_2", "UNUSED_PRESERVE") SD("%3", "%19", "BYTE_2", "UNUSED_PRESERVE")
-        SD("%0", "%8", "BYTE_3", "UNUSED_PRESERVE") SD("%1", "%12", "BYTE_3", "UNUSED_PRESERVE")
-        SD("%2", "%16", "BYTE_3", "UNUSED_PRESERVE") SD("%3", "%20", "BYTE_3", "UNUSED_PRESERVE")
-        "s_nop 0"
-        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
-        : "v"(s), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]),
-          "v"(c[9]), "v"(c[10]), "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
-#undef SD
-    i32x4 r = {d0, d1, d2, d3};
-    return r;
-}
-
-// ReLUNorm (BitNetMCU_inference.c:23-72) on MT x 16 accumulator values per lane (+ the partner lane's),
-// result packed as the next layer's B operand: packed[m][q] byte b = row 32m + 8q + 4h + b.
-// Rows >= n_output are zero weights => value 0: they can only raise a negative maximum to 0, in which case
-// every output is 0 either way.
-//
-// DBL = false: accumulators hold the layer sums x.   out = clamp((x + r) >> s, 0, 127), 3 VALU per value.
-// DBL = true : this layer's weight fragments were built DOUBLED, accumulators hold 2x (exact).  With
-//   s = bitlength(max(2x) >> 8) (= the reference's shift, from max(x) >> 7) and y = clamp(2x, 0, 255*2^s - 1) >> s
-//   (0..254, one v_med3 + one SDWA shift that also packs), the rounded result is
-//   (x + 2^(s-1)) >> s = (2x + 2^s) >> (s+1) = (y + 1) >> 1, which v_lerp_u8 computes for 4 bytes at once;
-//   y <= 254 makes the "clip 128 to 127" case (:62-66) fall out.  2.25 VALU per value, bit-exact.
-template <int MT, bool DBL>
-BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int h) {
-    int mx = acc[0][0];
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) mx = max(mx, acc[m][r]);
-    mx = max(max_with_partner32(mx), 0);
-    if constexpr (DBL) {
-        // shift = bitlength(mx >> 8) = bitlength(mx | 255) - 8: no zero test needed (mx >= 0)
-        int sh = 24 - __builtin_clz((uint32_t)mx | 255u);
-        int hi = (255 << sh) - 1;
-#pragma unroll
-        for (int m = 0; m < MT; m++) {
-            int c[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) c[r] = clamp0_med3(acc[m][r], hi);
-            i32x4 y = sdwa_shift_pack16(c, sh);
-#pragma unroll
-            for (int q = 0; q < 4; q++) packed[m][q] = (int)__builtin_amdgcn_lerp((uint32_t)y[q], 0u, 0x01010101u);
-        }
-    } else {
-        // plain sums: out = min(127, (x + 2^(s-1)) >> s) for x >= 0, else 0 — add, v_med3 to [0, 128*2^s - 1], SDWA
-        // shift straight into the packed byte: 3 VALU per value
-        int sh = 25 - __builtin_clz((uint32_t)mx | 127u);     // bitlength(mx >> 7)
-        int rnd = (1 << sh) >> 1;
-        int hi = (128 << sh) - 1;
-#pragma unroll
-        for (int m = 0; m < MT; m++) {
-            int c[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) c[r] = clamp0_med3(acc[m][r] + rnd, hi);
-            packed[m] = sdwa_shift_pack16(c, sh);
-        }
-    }
-}
-
-// first strict maximum over the class rows (ReLUNorm's return value, :25-37).  key = value*256 + (255 - row):
-// the largest key is the largest value and, among equals, the smallest row.  |value| < 2^23 for every layer that
-// can be last (K <= 128, |act| <= 127, |w| <= 128).
-// No run-time row masks: the fragment builder fills the last layer's padding rows (row >= n_classes) with weight
-// -128 on every real input column, so a padding row's sum is -128 * sum(act) <= every real row's sum (act >= 0,
-// w >= -128) and on a tie the real row, having the smaller index, wins.  NC8 > 0 states at compile time that
-// n_classes <= 8 * NC8, so accumulator registers holding only rows >= 8 * NC8 are not looked at at all
-// (10 classes: 8 of 16 registers); NC8 == 0 looks at every register.  1.5 VALU per register examined.
-template <int MT, int NC8>
-BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h) {
-    constexpr int G = NC8 > 0 ? NC8 : 4 * MT;
-    int best = INT_MIN;
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            if (4 * m + (r >> 2) >= G) continue;
-            const uint32_t rowbase = 32u * m + (r & 3) + 8u * (r >> 2);   // row of the h = 0 half; h = 1: +4
-            best = max(best, (int)(((uint32_t)acc[m][r] << 8) | (255u - rowbase)));
-        }
-    best = max_with_partner32(best - 4 * h);
-    return 255u - ((uint32_t)best & 255u);
-}
-
-template <int MT>
-BNM_DEVICE void store_logits(const i32x16 (&acc)[MT], int32_t *dst, int h, uint32_t n_classes) {
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            uint32_t row = 32u * m + (r & 3) + 8u * (r >> 2) + 4u * h;
-            if (row < n_classes) dst[row] = acc[m][r];
-        }
-}
-
-// 8 x 1 KiB LDS-DMA pieces of one 32-image tile.  p[t] wave-uniform base pointers, v[t] per-lane byte
-// offsets, lds wave-uniform LDS byte address of the tile buffer.  The DMA destination is
-// M0 + lane*16 (lane-linear); the swizzle lives in v[].  hipcc neither counts these loads nor waits for
-// them: the caller retires them with bnm_wait_vmcnt<N>().
-// NT: non-temporal policy (the image stream is read exactly once).  WAITLDS: first retire this wave's own
-// outstanding ds_reads (s_waitcnt lgkmcnt(0)) — needed when the destination buffer was being read just before.
-#define BNM_DMA8(NTS, PRE)                                                                                           \
-    asm volatile(PRE "s_nop 4\n\t"                                                                                    \
-                 "s_mov_b32 %0, m0\n\t"                                                                                \
-                 "s_mov_b32 m0, %1\n\t"                                                                                \
-                 "s_nop 0\n\t"                                                                                         \
-                 "global_load_lds_dwordx4 %10, %2" NTS "\n\t"                                                          \
-                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
-                 "s_nop 0\n\t"                                                                                         \
-                 "global_load_lds_dwordx4 %11, %3" NTS "\n\t"                                                          \
-                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
-                 "s_nop 0\n\t"                                                                                         \
-                 "global_load_lds_dwordx4 %12, %4" NTS "\n\t"                                                          \
-                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
-                 "s_nop 0\n\t"                                                                                         \
-                 "global_load_lds_dwordx4 %13, %5" NTS "\n\t"                                                          \
-                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
-                 "s_nop 0\n\t"                                                                                         \
-                 "global_load_lds_dwordx4 %14, %6" NTS "\n\t"                                                          \
-                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
-                 "s_nop 0\n\t"                                                                                         \
-                 "global_load_lds_dwordx4 %15, %7" NTS "\n\t"                                                          \
-                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
-                 "s_nop 0\n\t"                                                                                         \
-                 "global_load_lds_dwordx4 %16, %8" NTS "\n\t"                                                          \
-                 "s_add_u32 m0, m0, 0x400\n\t"                                                                         \
-                 "s_nop 0\n\t"                                                                                         \
-                 "global_load_lds_dwordx4 %17, %9" NTS "\n\t"                                                          \
-                 "s_mov_b32 m0, %0"                                                                                    \
-                 : "=&s"(keep)                                                                                         \
-                 : "s"(lds), "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(p6), "s"(p7), "v"(v0), "v"(v1), \
-                   "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7)                                                \
-                 : "memory", "scc")
-
-template <bool NT = false, bool WAITLDS = false>
-BNM_DEVICE void lds_dma_tile8(uint32_t lds, const int8_t *p0, const int8_t *p1, const int8_t *p2, const int8_t *p3,
-                              const int8_t *p4, const int8_t *p5, const int8_t *p6, const int8_t *p7, uint32_t v0,
-                              uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t v5, uint32_t v6,
-                              uint32_t v7) {
-    uint32_t keep;
-    if constexpr (NT && WAITLDS) BNM_DMA8(" nt", "s_waitcnt lgkmcnt(0)\n\t");
-    else if constexpr (NT) BNM_DMA8(" nt", "");
-    else if constexpr (WAITLDS) BNM_DMA8("", "s_waitcnt lgkmcnt(0)\n\t");
-    else BNM_DMA8("", "");
-}
-
-template <int N>
-BNM_DEVICE void bnm_wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-constexpr int FUSED_TILE_BYTES = 8192;    // 32 images x 256 B
-constexpr int FUSED_WPB = 4;              // waves per workgroup; two workgroups per CU (LDS 64 KiB each)
 
 // Kernel variants = how the image tile reaches the B operands:
 //   0  DIRECT     global -> VGPR loads in operand layout (any row length; CNN tails with 64/128/192-byte rows)
@@ -295,9 +107,13 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
     }
 
     auto dma_tile = [&](uint64_t t, int par) {
-        // src_wrap != 0 (diagnostics only, BNM_DIAG_SRC_WRAP): read tile (t mod src_wrap) instead, so the source stays
-        // cache-resident and the kernel's compute-side time can be measured without HBM in the way
+#ifdef BNM_DIAG
+        // diagnostic library only (build.py --diag, bnm_diag_set_src_wrap): read tile (t mod src_wrap) instead, so the
+        // source stays cache-resident and the kernel's compute-side time can be measured without HBM in the way
         const int8_t *base = images + (src_wrap ? t % src_wrap : t) * (uint64_t)FUSED_TILE_BYTES;
+#else
+        const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;   // src_wrap is ignored by the product build
+#endif
         uint32_t lds = lds_wave + (uint32_t)par * FUSED_TILE_BYTES;
         uint64_t first = t << 5;
         if (first + 32ull <= n) {
@@ -411,37 +227,6 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
 // the remainder to variant 2; the refill after the last pair re-reads that pair), so the scheduler can place one
 // tile's ReLUNorm VALU work between the other tile's MFMAs.  Weights stay in registers once for both tiles.
 //
-// whole 32-image tile, rows contiguous: two base pointers + instruction offsets instead of eight pointers.
-// The instruction offset of an LDS-DMA load is added to BOTH the global and the LDS address, so pieces 0..3 and
-// 4..7 need M0 set only once each.
-#define BNM_DMA8_LINEAR(POL)                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                        \
-                 "s_nop 4\n\t"                                                                      \
-                 "s_mov_b32 %0, m0\n\t"                                                             \
-                 "s_mov_b32 m0, %1\n\t"                                                             \
-                 "s_nop 0\n\t"                                                                      \
-                 "global_load_lds_dwordx4 %4, %2" POL "\n\t"                                        \
-                 "global_load_lds_dwordx4 %5, %2 offset:1024" POL "\n\t"                            \
-                 "global_load_lds_dwordx4 %6, %2 offset:2048" POL "\n\t"                            \
-                 "global_load_lds_dwordx4 %7, %2 offset:3072" POL "\n\t"                            \
-                 "s_add_u32 m0, m0, 0x1000\n\t"                                                     \
-                 "s_nop 0\n\t"                                                                      \
-                 "global_load_lds_dwordx4 %4, %3" POL "\n\t"                                        \
-                 "global_load_lds_dwordx4 %5, %3 offset:1024" POL "\n\t"                            \
-                 "global_load_lds_dwordx4 %6, %3 offset:2048" POL "\n\t"                            \
-                 "global_load_lds_dwordx4 %7, %3 offset:3072" POL "\n\t"                            \
-                 "s_mov_b32 m0, %0"                                                                  \
-                 : "=&s"(keep)                                                                       \
-                 : "s"(lds), "s"(lo), "s"(hi), "v"(v0), "v"(v1), "v"(v2), "v"(v3)                    \
-                 : "memory", "scc")
-// Cache policy: nt (non-temporal).  Round 1 also measured sc1 nt, sc0 sc1 nt, sc1 and no hint on the same box
-// (profiles/r01/r01n_cache_policy_experiment.log): all within the run-to-run spread, none better than nt.
-BNM_DEVICE void lds_dma_tile8_linear(uint32_t lds, const int8_t *lo, const int8_t *hi, uint32_t v0, uint32_t v1,
-                                     uint32_t v2, uint32_t v3) {
-    uint32_t keep;
-    BNM_DMA8_LINEAR(" nt");
-}
-
 template <int M1, int M2, int M3, int M4, bool DBL, int NC8>
 __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                           const i32x4 *__restrict__ frags,
@@ -474,9 +259,13 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
     const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
     const uint32_t rd_base = (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ (uint32_t)(j & 15));
 
-    // slot 0 holds tile 2p, slot 1 tile 2p+1.  Diagnostics: src_wrap (a power of two here) keeps the source
-    // cache-resident; as a mask it costs one s_and and no branch.
+    // slot 0 holds tile 2p, slot 1 tile 2p+1.  Diagnostic library only: src_wrap (a power of two here) keeps the
+    // source cache-resident; as a mask it costs one s_and and no branch.  The product build ignores the argument.
+#ifdef BNM_DIAG
     const uint64_t wrap_mask = src_wrap ? src_wrap - 1ull : ~0ull;
+#else
+    constexpr uint64_t wrap_mask = ~0ull;
+#endif
     auto dma_tile = [&](uint64_t t, int slot) {
         const int8_t *base = images + (t & wrap_mask) * (uint64_t)FUSED_TILE_BYTES;
         lds_dma_tile8_linear(lds_wave + (uint32_t)slot * FUSED_TILE_BYTES, base, base + 4096, voff[0], voff[1], voff[2], voff[3]);
@@ -621,17 +410,14 @@ const FusedEntry kFused[] = {
     FUSED_ANY_AND_10(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA2),
     FUSED(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA, 0),
     FUSED(8, 2, 2, 2, 1, false, false, FUSED_DIRECT, 0),
-    // same shape, FP1.3.0 weights (mcu/BitNetMCU_model_12k_FP130.h): +128 split over two A passes
-    FUSED(8, 2, 2, 2, 1, true, false, FUSED_LDSDMA, 0),
-    FUSED(8, 2, 2, 2, 1, true, false, FUSED_DIRECT, 0),
+    // (FP1.3.0 models that really contain a +128 weight need a second weight plane: 2 x the A fragments do not fit the
+    // register file without spilling, so those go to the generic kernel, whose weights live in LDS)
     // FC 256-16-16-10 2bitsym (mcu/BitNetMCU_model_1k.h)
     { {8, {1, 1, 1, 0}, false, true, 2}, FUSED_DUAL, fused_fc_dual_kernel<1, 1, 1, 0, true, 2> },
     FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA2, 0),
     FUSED_ANY_AND_10(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA),
     FUSED(8, 1, 1, 1, 0, false, true, FUSED_DIRECT, 0),
-    // ternary FC 256-96-96-96-10 through the MFMA path (optional; config 3's product path is the ALU kernel)
-    FUSED(8, 3, 3, 3, 1, false, true, FUSED_LDSDMA, 0),
-    FUSED(8, 3, 3, 3, 1, false, true, FUSED_DIRECT, 0),
+    // (96-wide four-layer shapes, e.g. the ternary model through MFMA: 132 weight registers spill -> generic kernel)
     // CNN FC tails: 4C-96-64-10 (cnn_64/48/32/16), 64-64-48-10 (cnn_16small), 256-96-64-37 (letters)
     FUSED(8, 3, 2, 1, 0, false, true, FUSED_LDSDMA, 0),
     FUSED(8, 3, 2, 1, 0, false, true, FUSED_DIRECT, 0),
@@ -639,8 +425,7 @@ const FusedEntry kFused[] = {
     FUSED(4, 3, 2, 1, 0, false, true, FUSED_DIRECT, 0),
     FUSED(2, 3, 2, 1, 0, false, true, FUSED_DIRECT, 0),
     FUSED(2, 2, 2, 1, 0, false, true, FUSED_DIRECT, 0),
-    FUSED(8, 3, 2, 2, 0, false, true, FUSED_LDSDMA, 0),
-    FUSED(8, 3, 2, 2, 0, false, true, FUSED_DIRECT, 0),
+    // (256-96-64-37, the letters CNN's tail: spilled 3-4 registers here -> generic kernel)
 };
 // exact class-count specialisation first, then the any-count instantiation of the same shape
 const FusedEntry *find_fused(const BnmFusedShape &sh, int variant) {
@@ -697,201 +482,3 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
     return hipGetLastError();
 }
 
-// =================================================================================================
-// Diagnostics: what the image stream alone costs.  mode 0: plain 16 B/lane global loads, grid-stride;
-// mode 1 / 2: the fused kernel's own tile loop (variant LDSDMA / LDSDMA2) with the math replaced by one ds_read
-// per tile.  Both write one dword per 32 images so the result cannot be optimised away.  Used by
-// profiles/stream_ceiling.py to put the achieved GB/s of the real kernel next to the practical read ceiling.
-// =================================================================================================
-__global__ __launch_bounds__(256) void diag_stream_plain_kernel(const u32x4 *__restrict__ src, uint64_t n16,
-                                                                uint32_t *__restrict__ out) {
-    uint32_t acc = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        acc ^= a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3] ^ c[0] ^ c[1] ^ c[2] ^ c[3] ^ d[0] ^ d[1] ^ d[2] ^ d[3];
-    }
-    for (; i < n16; i += stride) {
-        u32x4 a = __builtin_nontemporal_load(src + i);
-        acc ^= a[0] ^ a[1] ^ a[2] ^ a[3];
-    }
-    if (acc == 0x12345678u) out[0] = acc;   // practically never: keeps the loads alive without a store stream
-}
-
-template <bool TWO>
-__global__ __launch_bounds__(64 * FUSED_WPB, 2) void diag_stream_tiles_kernel(const int8_t *__restrict__ images, uint64_t n,
-                                                                              uint32_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(1024))) char smem[FUSED_WPB * 2 * FUSED_TILE_BYTES];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t voff[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
-    const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
-    const uint64_t n_tiles = n >> 5;   // whole tiles only
-    const uint64_t stride = (uint64_t)gridDim.x * FUSED_WPB;
-    uint64_t tile = (uint64_t)blockIdx.x * FUSED_WPB + wave;
-    auto dma = [&](uint64_t t, int par) {
-        const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
-        lds_dma_tile8<TWO, TWO>(lds_wave + (uint32_t)par * FUSED_TILE_BYTES, base, base + 1024, base + 2048, base + 3072,
-                                base + 4096, base + 5120, base + 6144, base + 7168, voff[0], voff[1], voff[2], voff[3], voff[0],
-                                voff[1], voff[2], voff[3]);
-    };
-    int par = 0;
-    if (tile < n_tiles) dma(tile, 0);
-    if (TWO && tile + stride < n_tiles) dma(tile + stride, 1);
-    for (; tile < n_tiles; tile += stride) {
-        const uint64_t next = tile + stride;
-        if constexpr (!TWO) {
-            if (next < n_tiles) { dma(next, par ^ 1); bnm_wait_vmcnt<8>(); } else { bnm_wait_vmcnt<0>(); }
-        } else {
-            if (next < n_tiles) bnm_wait_vmcnt<8>(); else bnm_wait_vmcnt<0>();
-        }
-        uint32_t v = *(const uint32_t *)(smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)par * FUSED_TILE_BYTES + 128u * lane);
-        if (TWO && next + stride < n_tiles) dma(next + stride, par);
-        if (lane < 32) out[(tile << 5) + lane] = v;
-        par ^= 1;
-    }
-}
-
-template <bool PLAIN>
-__global__ void diag_stream_compute_kernel(const int8_t *__restrict__ images, uint64_t n, uint32_t *__restrict__ out);
-
-hipError_t bnmk_diag_stream(const int8_t *images, uint64_t n, int mode, int grid_blocks, uint32_t *out, hipStream_t s) {
-    if (!n) return hipSuccess;
-    int cus = bnm_num_cus();
-    if (mode == 0) {
-        unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 8u;
-        diag_stream_plain_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const u32x4 *)images, n * 16ull, out);
-    } else {
-        unsigned blocks = grid_blocks > 0 ? (unsigned)grid_blocks : (unsigned)cus * 2u;
-        if (mode == 1) diag_stream_tiles_kernel<false><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
-        else if (mode == 2) diag_stream_tiles_kernel<true><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
-        else if (mode == 3) diag_stream_compute_kernel<false><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
-        else diag_stream_compute_kernel<true><<<dim3(blocks), dim3(256), 0, s>>>(images, n, out);
-    }
-    return hipGetLastError();
-}
-
-
-// -------------------------------------------------------------------------------------------------
-// Diagnostics, modes 3/4: the image stream under a SYNTHETIC compute load of the real kernel's size (26 MFMAs +
-// ~400 dependent-ish VALU per 32-image tile, operands from registers), fed either by the LDS-DMA tile loop (mode 3)
-// or by plain coalesced 16 B/lane loads into double-buffered VGPRs (mode 4).  Question for the next round: does the
-// 15 % the real kernel loses against its own stream-only loop come from the LDS-DMA path under load, or from any
-// load path under load?
-// -------------------------------------------------------------------------------------------------
-BNM_DEVICE void fake_tile_compute(i32x16 &acc0, i32x16 &acc1, int &v0, int &v1, int &v2, int &v3, const i32x4 &a, const i32x4 &b) {
-#pragma unroll
-    for (int i = 0; i < 13; i++) {
-        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a, acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 50; i++) {     // 8 VALU per round, four independent chains
-        v0 = min(max(v0 + 3, 0), 0x7fffff) ^ v3;
-        v1 = min(max(v1 + 5, 0), 0x7fffff) ^ v0;
-        v2 = (v2 >> 1) + v1;
-        v3 = (v3 << 1) ^ v2;
-    }
-}
-
-template <bool PLAIN>
-__global__ __launch_bounds__(64 * FUSED_WPB, 2) void diag_stream_compute_kernel(const int8_t *__restrict__ images, uint64_t n,
-                                                                                uint32_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(1024))) char smem[PLAIN ? 16 : FUSED_WPB * 2 * FUSED_TILE_BYTES];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_tiles = n >> 5;
-    const uint64_t stride = (uint64_t)gridDim.x * FUSED_WPB;
-    uint64_t tile = (uint64_t)blockIdx.x * FUSED_WPB + wave;
-    i32x16 acc0 = zero16(), acc1 = zero16();
-    int v0 = lane, v1 = lane * 3, v2 = lane * 5, v3 = lane * 7;
-    i32x4 fa = {lane, lane + 1, lane + 2, lane + 3}, fb = {lane * 2, 1, 2, 3};
-    if constexpr (PLAIN) {
-        const i32x4 *src = (const i32x4 *)images;
-        i32x4 cur[8], nxt[8];
-        auto load = [&](uint64_t t, i32x4(&d)[8]) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) d[k] = __builtin_nontemporal_load(src + t * 512 + k * 64 + lane);
-        };
-        if (tile < n_tiles) load(tile, nxt);
-        for (; tile < n_tiles; tile += stride) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) cur[k] = nxt[k];
-            if (tile + stride < n_tiles) load(tile + stride, nxt);
-            fb[0] ^= cur[0][0] ^ cur[1][1] ^ cur[2][2] ^ cur[3][3] ^ cur[4][0] ^ cur[5][1] ^ cur[6][2] ^ cur[7][3];
-            fake_tile_compute(acc0, acc1, v0, v1, v2, v3, fa, fb);
-            if (lane < 32) out[(tile << 5) + lane] = (uint32_t)(acc0[0] ^ acc1[1] ^ v0 ^ v1 ^ v2 ^ v3);
-        }
-    } else {
-        uint32_t voff[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) voff[u] = (uint32_t)(lane >> 4) * 256u + 16u * ((uint32_t)(lane & 15) ^ (uint32_t)(lane >> 4) ^ (4u * u));
-        const uint32_t lds_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES;
-        auto dma = [&](uint64_t t, int par) {
-            const int8_t *base = images + t * (uint64_t)FUSED_TILE_BYTES;
-            lds_dma_tile8<true, true>(lds_wave + (uint32_t)par * FUSED_TILE_BYTES, base, base + 1024, base + 2048, base + 3072,
-                                      base + 4096, base + 5120, base + 6144, base + 7168, voff[0], voff[1], voff[2], voff[3],
-                                      voff[0], voff[1], voff[2], voff[3]);
-        };
-        int par = 0;
-        if (tile < n_tiles) dma(tile, 0);
-        if (tile + stride < n_tiles) dma(tile + stride, 1);
-        for (; tile < n_tiles; tile += stride) {
-            const uint64_t next = tile + stride;
-            if (next < n_tiles) bnm_wait_vmcnt<8>(); else bnm_wait_vmcnt<0>();
-            const i32x4 *rb = (const i32x4 *)(smem + (uint32_t)wave * 2u * FUSED_TILE_BYTES + (uint32_t)par * FUSED_TILE_BYTES);
-            i32x4 c0 = rb[lane], c1 = rb[64 + lane], c2 = rb[128 + lane], c3 = rb[192 + lane];
-            i32x4 c4 = rb[256 + lane], c5 = rb[320 + lane], c6 = rb[384 + lane], c7 = rb[448 + lane];
-            fb[0] ^= c0[0] ^ c1[1] ^ c2[2] ^ c3[3] ^ c4[0] ^ c5[1] ^ c6[2] ^ c7[3];
-            if (next + stride < n_tiles) dma(next + stride, par);
-            fake_tile_compute(acc0, acc1, v0, v1, v2, v3, fa, fb);
-            if (lane < 32) out[(tile << 5) + lane] = (uint32_t)(acc0[0] ^ acc1[1] ^ v0 ^ v1 ^ v2 ^ v3);
-            par ^= 1;
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Diagnostics, modes 5/6/7: no memory traffic at all.  Each wave repeats a tile-sized block of 26 MFMAs (mode 5),
-// ~400 VALU (mode 6) or both (mode 7), two waves per SIMD as in the fused kernel.  T(7) ~ T(5) + T(6) means the matrix
-// pipe and the VALU of one SIMD do not overlap for this instruction mix; T(7) ~ max means they do.
-// -------------------------------------------------------------------------------------------------
-template <bool DO_MFMA, bool DO_VALU>
-__global__ __launch_bounds__(64 * FUSED_WPB, 2) void diag_pipes_kernel(uint64_t tiles_per_wave, uint32_t *__restrict__ out) {
-    __shared__ char pad[FUSED_WPB * 2 * FUSED_TILE_BYTES];   // same LDS footprint -> same residency (2 workgroups per CU)
-    const int lane = threadIdx.x & 63;
-    i32x16 acc0 = zero16(), acc1 = zero16();
-    int v0 = lane, v1 = lane * 3, v2 = lane * 5, v3 = lane * 7;
-    i32x4 fa = {lane, lane + 1, lane + 2, lane + 3}, fb = {lane * 2, 1, 2, 3};
-    for (uint64_t t = 0; t < tiles_per_wave; t++) {
-        if constexpr (DO_MFMA) {
-#pragma unroll
-            for (int i = 0; i < 13; i++) {
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb, fa, acc1, 0, 0, 0);
-            }
-        }
-        if constexpr (DO_VALU) {
-#pragma unroll
-            for (int i = 0; i < 40; i++) {     // 10 VALU per round, four chains
-                v0 = min(max(v0 + 3, 0), 0x7fffff) ^ v3;
-                v1 = min(max(v1 + 5, 0), 0x7fffff) ^ v0;
-                v2 = (v2 >> 1) + v1;
-                v3 = (v3 << 1) ^ v2;
-            }
-        }
-    }
-    if (pad[threadIdx.x] == 123 || (acc0[0] ^ acc1[1] ^ v0 ^ v1 ^ v2 ^ v3) == 0x5a5a5a5a) out[threadIdx.x] = 1;
-}
-
-hipError_t bnmk_diag_pipes(int mode, uint64_t tiles_per_wave, uint32_t *out, hipStream_t s) {
-    unsigned blocks = (unsigned)bnm_num_cus() * 2u;
-    if (mode == 5) diag_pipes_kernel<true, false><<<dim3(blocks), dim3(256), 0, s>>>(tiles_per_wave, out);
-    else if (mode == 6) diag_pipes_kernel<false, true><<<dim3(blocks), dim3(256), 0, s>>>(tiles_per_wave, out);
-    else diag_pipes_kernel<true, true><<<dim3(blocks), dim3(256), 0, s>>>(tiles_per_wave, out);
-    return hipGetLastError();
-}

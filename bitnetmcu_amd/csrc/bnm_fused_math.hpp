@@ -1,0 +1,129 @@
+// Per-tile arithmetic shared by the fused whole-model kernels: ReLUNorm on MFMA accumulators (packed straight into the
+// next layer's B operand), first-maximum argmax, logits store.  gfx950 only.  Reference semantics:
+// BitNetMCU_inference.c:23-72 (ReLUNorm).
+#pragma once
+#include "bnm_device.hpp"
+
+// max(x, x of lane ^ 32): swapping the upper half of one copy with the lower half of another leaves
+// {x_lo, x_lo} and {x_hi, x_hi}, whose maximum is the answer in every lane — no select on the half index
+BNM_DEVICE int max_with_partner32(int x) {
+    auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return max((int)r[0], (int)r[1]);
+}
+
+// clamp to [0, hi] in ONE instruction.  hipcc only forms v_med3_i32 from min(max(x, lo), hi) when it can prove
+// lo <= hi (constants); with a run-time hi it emits v_max + v_min.
+BNM_DEVICE int clamp0_med3(int x, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
+    return r;
+}
+
+// 16 clamped values -> 4 dwords, byte b of dword q = c[4q+b] >> s.  One SDWA shift per value writes its result
+// byte straight into place (dst_sel:BYTE_b, dst_unused:UNUSED_PRESERVE), so no separate pack instructions.
+// Same-register writes are 4 instructions apart and a trailing s_nop covers the dst_sel forwarding hazard that
+// hipcc cannot see inside an asm statement.
+BNM_DEVICE i32x4 sdwa_shift_pack16(const int (&c)[16], int s) {
+    int d0, d1, d2, d3;
+#define SD(dst, src, sel, unused) \
+    "v_lshrrev_b32_sdwa " dst ", %4, " src " dst_sel:" sel " dst_unused:" unused " src0_sel:DWORD src1_sel:DWORD\n\t"
+    asm(SD("%0", "%5", "BYTE_0", "UNUSED_PAD") SD("%1", "%9", "BYTE_0", "UNUSED_PAD")
+        SD("%2", "%13", "BYTE_0", "UNUSED_PAD") SD("%3", "%17", "BYTE_0", "UNUSED_PAD")
+        SD("%0", "%6", "BYTE_1", "UNUSED_PRESERVE") SD("%1", "%10", "BYTE_1", "UNUSED_PRESERVE")
+        SD("%2", "%14", "BYTE_1", "UNUSED_PRESERVE") SD("%3", "%18", "BYTE_1", "UNUSED_PRESERVE")
+        SD("%0", "%7", "BYTE_2", "UNUSED_PRESERVE") SD("%1", "%11", "BYTE_2", "UNUSED_PRESERVE")
+        SD("%2", "%15", "BYTE_2", "UNUSED_PRESERVE") SD("%3", "%19", "BYTE_2", "UNUSED_PRESERVE")
+        SD("%0", "%8", "BYTE_3", "UNUSED_PRESERVE") SD("%1", "%12", "BYTE_3", "UNUSED_PRESERVE")
+        SD("%2", "%16", "BYTE_3", "UNUSED_PRESERVE") SD("%3", "%20", "BYTE_3", "UNUSED_PRESERVE")
+        "s_nop 0"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+        : "v"(s), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]),
+          "v"(c[9]), "v"(c[10]), "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
+#undef SD
+    i32x4 r = {d0, d1, d2, d3};
+    return r;
+}
+
+// ReLUNorm (BitNetMCU_inference.c:23-72) on MT x 16 accumulator values per lane (+ the partner lane's),
+// result packed as the next layer's B operand: packed[m][q] byte b = row 32m + 8q + 4h + b.
+// Rows >= n_output are zero weights => value 0: they can only raise a negative maximum to 0, in which case
+// every output is 0 either way.
+//
+// DBL = false: accumulators hold the layer sums x.   out = clamp((x + r) >> s, 0, 127), 3 VALU per value.
+// DBL = true : this layer's weight fragments were built DOUBLED, accumulators hold 2x (exact).  With
+//   s = bitlength(max(2x) >> 8) (= the reference's shift, from max(x) >> 7) and y = clamp(2x, 0, 255*2^s - 1) >> s
+//   (0..254, one v_med3 + one SDWA shift that also packs), the rounded result is
+//   (x + 2^(s-1)) >> s = (2x + 2^s) >> (s+1) = (y + 1) >> 1, which v_lerp_u8 computes for 4 bytes at once;
+//   y <= 254 makes the "clip 128 to 127" case (:62-66) fall out.  2.25 VALU per value, bit-exact.
+template <int MT, bool DBL>
+BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int h) {
+    int mx = acc[0][0];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = max(mx, acc[m][r]);
+    mx = max(max_with_partner32(mx), 0);
+    if constexpr (DBL) {
+        // shift = bitlength(mx >> 8) = bitlength(mx | 255) - 8: no zero test needed (mx >= 0)
+        int sh = 24 - __builtin_clz((uint32_t)mx | 255u);
+        int hi = (255 << sh) - 1;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            int c[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) c[r] = clamp0_med3(acc[m][r], hi);
+            i32x4 y = sdwa_shift_pack16(c, sh);
+#pragma unroll
+            for (int q = 0; q < 4; q++) packed[m][q] = (int)__builtin_amdgcn_lerp((uint32_t)y[q], 0u, 0x01010101u);
+        }
+    } else {
+        // plain sums: out = min(127, (x + 2^(s-1)) >> s) for x >= 0, else 0 — add, v_med3 to [0, 128*2^s - 1], SDWA
+        // shift straight into the packed byte: 3 VALU per value
+        int sh = 25 - __builtin_clz((uint32_t)mx | 127u);     // bitlength(mx >> 7)
+        int rnd = (1 << sh) >> 1;
+        int hi = (128 << sh) - 1;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            int c[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) c[r] = clamp0_med3(acc[m][r] + rnd, hi);
+            packed[m] = sdwa_shift_pack16(c, sh);
+        }
+    }
+}
+
+// first strict maximum over the class rows (ReLUNorm's return value, :25-37).  key = value*256 + (255 - row):
+// the largest key is the largest value and, among equals, the smallest row.  |value| < 2^23 for every layer that
+// can be last (K <= 128, |act| <= 127, |w| <= 128).
+// No run-time row masks: the fragment builder fills the last layer's padding rows (row >= n_classes) with weight
+// -128 on every real input column, so a padding row's sum is -128 * sum(act) <= every real row's sum (act >= 0,
+// w >= -128) and on a tie the real row, having the smaller index, wins.  NC8 > 0 states at compile time that
+// n_classes <= 8 * NC8, so accumulator registers holding only rows >= 8 * NC8 are not looked at at all
+// (10 classes: 8 of 16 registers); NC8 == 0 looks at every register.  1.5 VALU per register examined.
+template <int MT, int NC8>
+BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h) {
+    constexpr int G = NC8 > 0 ? NC8 : 4 * MT;
+    int best = INT_MIN;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if (4 * m + (r >> 2) >= G) continue;
+            const uint32_t rowbase = 32u * m + (r & 3) + 8u * (r >> 2);   // row of the h = 0 half; h = 1: +4
+            best = max(best, (int)(((uint32_t)acc[m][r] << 8) | (255u - rowbase)));
+        }
+    best = max_with_partner32(best - 4 * h);
+    return 255u - ((uint32_t)best & 255u);
+}
+
+template <int MT>
+BNM_DEVICE void store_logits(const i32x16 (&acc)[MT], int32_t *dst, int h, uint32_t n_classes) {
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            uint32_t row = 32u * m + (r & 3) + 8u * (r >> 2) + 4u * h;
+            if (row < n_classes) dst[row] = acc[m][r];
+        }
+}
+

@@ -42,7 +42,7 @@ struct BnmFusedArgs {
     uint32_t n_classes;
     uint32_t *cls;          // [n]
     int32_t *logits;        // [n][n_classes] or nullptr
-    uint64_t src_wrap = 0;  // diagnostics: read tile (t mod src_wrap) — keeps the source cache-resident
+    uint64_t src_wrap = 0;  // diagnostic library only (BNM_DIAG): read tile (t mod src_wrap); ignored by the product build
 };
 // variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (256-byte rows only), 2 = LDS-DMA with two
 // tiles in flight per wave, 3 = two tiles computed per wave per iteration (default where instantiated)
@@ -50,6 +50,28 @@ bool bnmk_fused_supported(const BnmFusedShape &sh, int variant);
 hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a,
                          hipStream_t s);
 int bnmk_fused_default_variant(const BnmFusedShape &sh);
+
+// ---- generic fused whole-model FC kernel (bnm_fused_generic.hip): run-time layer widths, weights in LDS ----------
+struct BnmGenericDesc {      // passed to the kernel by value
+    uint32_t KT0;            // input row bytes / 32: 2, 4, 8 or 16 (rows of 64 / 128 / 256 / 512 bytes)
+    uint32_t mmax;           // tile class: 2, 4 or 8 = upper bound of 32-row tiles per layer the kernel is compiled for
+    uint32_t M[4];           // 32-row output tiles per FC layer as the kernel runs them; M[3] == 0 for 3-layer models
+    uint32_t KTP[4];         // K-steps per layer in the fragment image (layer 1: KT0; deeper: padded previous tile count)
+    uint32_t frag_off[4];    // byte offset of each layer's fragments inside the fragment image
+    uint32_t w_bytes;        // size of the fragment image (a multiple of 1 KiB)
+    uint32_t sp;             // 1, or 2 when a second weight plane follows each tile's fragments (FP1.3.0's +128)
+    uint32_t n_classes;      // <= 256
+};
+// waves per SIMD an instantiation of the generic kernel is compiled for (its launch bound is 256 * this many threads)
+constexpr int bnmk_generic_wps(int mmax, int kt0, int sp) {
+    return mmax == 2 ? 4 : mmax == 4 ? ((sp == 2 || kt0 == 16) ? 2 : 3) : 1;
+}
+// variant id of the generic kernel in bnm_ctx_set_tuning / bnm_ctx_get_variant
+enum { BNM_FUSED_GENERIC = 4 };
+bool bnmk_generic_plan(BnmGenericDesc &d, const uint32_t m_real[4]);   // fills mmax, M, KTP, frag_off, w_bytes from KT0, sp
+bool bnmk_generic_supported(const BnmGenericDesc &d, bool dbl);
+hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int grid_blocks, const int8_t *d_images, uint64_t n,
+                              const void *d_frags, uint32_t *d_cls, int32_t *d_logits, hipStream_t s);
 
 // ---- layer-wise ALU kernels (bit-serial unpack + wave-shuffle reduction) ----------------------
 hipError_t bnmk_fc_layer(const int8_t *d_act, uint32_t act_stride, const void *d_packed, int32_t bpw,
@@ -64,9 +86,10 @@ hipError_t bnmk_maxpool22(const int32_t *d_in, uint32_t xy, int32_t *d_out, hipS
 // ---- CNN front end: 3 depthwise 3x3 convs + 2 pools per channel, batched ----------------------
 // images [n][256] int8 -> acts [n][4*C] int8 after the fused ReLUNorm (channel-major,
 // BitNetMCU_MNIST_dll.c:65,76,80); feat (optional) = the int32 values before ReLUNorm
+// acts_stride: bytes between consecutive images' act rows (>= 4*C; bytes past 4*C are left untouched)
 hipError_t bnmk_cnn_front(const int8_t *d_images, uint64_t n, const int8_t *d_w1, const int8_t *d_w2,
-                          const int8_t *d_w3, uint32_t C, uint32_t n_shift, int8_t *d_acts, int32_t *d_feat,
-                          hipStream_t s);
+                          const int8_t *d_w3, uint32_t C, uint32_t n_shift, int8_t *d_acts, uint32_t acts_stride,
+                          int32_t *d_feat, hipStream_t s);
 
 // ---- ternary ALU whole-model kernel (sign-accumulate, no MFMA) -------------------------------
 struct BnmTernArgs {
@@ -82,12 +105,14 @@ struct BnmTernArgs {
 };
 hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s);
 
-// ---- diagnostics: cost of the image stream alone (profiles/stream_ceiling.py) ----------------------
+// ---- diagnostics (bnm_diag.hip, diagnostic library only): cost of the image stream alone, pipe overlap ----
+#ifdef BNM_DIAG
 hipError_t bnmk_diag_stream(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out, hipStream_t s);
+hipError_t bnmk_diag_pipes(int mode, uint64_t tiles_per_wave, uint32_t *d_out, hipStream_t s);   // modes 5/6/7: pipe overlap probe
+#endif
 
 // ---- input quantisation: float32 [n][256] -> int8 [n][256] (test_inference.py:140-141) --------------
 hipError_t bnmk_quantize_input(const float *d_x, uint64_t n, int8_t *d_out, hipStream_t s);
-hipError_t bnmk_diag_pipes(int mode, uint64_t tiles_per_wave, uint32_t *d_out, hipStream_t s);   // modes 5/6/7: pipe overlap probe
 
 // ---- QAT forward op (bnm_qat.hip) ---------------------------------------
 size_t bnmk_qat_workspace_bytes(uint32_t d, uint32_t k);

@@ -263,7 +263,8 @@ bool bnm_validate_schedule(const bnm_model &m, std::string &err) {
             if (li.type == BNM_LAYER_CONV) {
                 bool first = (k == 0);
                 if (li.kernel_size != 3 || li.out_channels != C || li.in_channels != (first ? 1u : C) ||
-                    li.groups != (first ? 1u : C) || li.weight_count != 9u * C) {
+                    li.groups != (first ? 1u : C) || li.weight_count != 9u * C || li.weight_elem_bytes != 1u ||
+                    m.layers[k].weights.size() < 9u * (size_t)C) {
                     err = "CNN model: conv layer " + std::to_string(k) + " is not a 3x3 depthwise stage";
                     return false;
                 }
@@ -295,7 +296,15 @@ bool bnm_validate_schedule(const bnm_model &m, std::string &err) {
             }
             if (li.bits_per_weight == 64 && li.n_input % 10u != 0) { err = "ternary layer: incoming_weights must be a multiple of 10"; return false; }
             uint64_t need = bnm_fc_weight_count(li.bits_per_weight, li.n_input, li.n_output);
-            if (li.weight_count < need) {
+            // the kernels read `need` elements of the codec's own width (uint16 for ternary, uint32 otherwise,
+            // exportquant.py:161-174,193-207): the declared C type must be that width and the bytes must be there
+            const uint32_t want_eb = li.bits_per_weight == 64 ? 2u : 4u;
+            if (li.weight_elem_bytes != want_eb) {
+                err = "FC layer L" + std::to_string(li.order) + ": weight array declared with " + std::to_string(li.weight_elem_bytes) +
+                      "-byte elements, the codec needs " + std::to_string(want_eb);
+                return false;
+            }
+            if (li.weight_count < need || m.layers[pos].weights.size() < need * want_eb) {
                 err = "FC layer L" + std::to_string(li.order) + ": weight array too short";
                 return false;
             }

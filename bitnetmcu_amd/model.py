@@ -95,6 +95,12 @@ class Context:
         h = C.c_void_p()
         L.check(self._lib, self._lib.bnm_ctx_create(model._h, device, C.byref(h)), "bnm_ctx_create")
         self._h = h
+        # diagnostic library only (BNM_LIBRARY=.../libbitnetmcu_hip_diag.so, build.py --diag): cache-resident source for
+        # compute-side timing.  The product library does not export the symbol and ignores the variable.
+        import os
+        wrap = os.environ.get("BNM_DIAG_SRC_WRAP")
+        if wrap and hasattr(self._lib, "bnm_diag_set_src_wrap"):
+            L.check(self._lib, self._lib.bnm_diag_set_src_wrap(self._h, int(wrap)), "bnm_diag_set_src_wrap")
 
     def close(self):
         if getattr(self, "_h", None):

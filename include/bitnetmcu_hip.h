@@ -226,14 +226,6 @@ BNM_API int bnm_synth_fill_device(int8_t *d_images, uint64_t first, uint64_t cou
 BNM_API int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint64_t n,
                                     uint64_t *d_out, uint32_t n_bins, void *stream);
 
-/* Diagnostics: read the image stream without the model math.  mode 0: plain 16 B/lane loads; mode 1/2: the fused
- * kernel's own LDS-DMA tile loop (one tile ahead / two tiles in flight); mode 3/4: the stream under a synthetic
- * compute load, fed by the LDS-DMA loop / by plain loads into VGPRs; mode 5/6/7: no memory traffic, n = tiles per
- * wave of 26 MFMAs / ~400 VALU / both (do the matrix pipe and the VALU of a SIMD overlap?).  d_out: uint32 [n].  Puts the practical read ceiling of
- * this access pattern next to the real kernel (profiles/stream_ceiling.py). */
-BNM_API int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out,
-                                   void *stream);
-
 /* ---- multi-GPU, single process (C hosts; PyTorch hosts use one process per GPU, see bench.py) ------------------
  * Shards the global synthetic image stream [0, n_total) contiguously over the first n_gpus visible devices
  * (n_gpus <= 0: all), generates every shard on its own GPU, runs the whole-model path on all of them concurrently and

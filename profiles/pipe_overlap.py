@@ -7,6 +7,8 @@ sys.path.insert(0, REPO)
 import bitnetmcu_amd as b
 from bitnetmcu_amd import _lib as L
 lib = b.load()
+if not hasattr(lib, "bnm_diag_stream_device"):
+    sys.exit("needs the diagnostic library: python bitnetmcu_amd/build.py --diag; BNM_LIBRARY=bitnetmcu_amd/libbitnetmcu_hip_diag.so")
 out = torch.zeros(1024, dtype=torch.int32, device="cuda")
 dummy = torch.zeros(256, dtype=torch.int8, device="cuda")
 s = torch.cuda.current_stream().cuda_stream

@@ -15,6 +15,8 @@ from bitnetmcu_amd import _lib as L  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 lib = b.load()
+if not hasattr(lib, "bnm_diag_stream_device"):
+    sys.exit("needs the diagnostic library: python bitnetmcu_amd/build.py --diag; BNM_LIBRARY=bitnetmcu_amd/libbitnetmcu_hip_diag.so")
 imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
 b.synth.fill_device(imgs)
 out = torch.zeros(n, dtype=torch.int32, device="cuda")

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """How long does a wave of the dual-tile kernel wait for its image tiles?  (round-2 plan, experiment 1)
+(BNM_DIAG_SRC_WRAP is honoured by the diagnostic libraries only — build.py --diag / --diag-timing.)
 
 Needs the diagnostic build:   python bitnetmcu_amd/build.py --diag-timing
 Run on the GPU box:           BNM_LIBRARY=bitnetmcu_amd/libbitnetmcu_hip_timing.so python profiles/wait_timing.py

@@ -19,7 +19,7 @@ def paths_for(ctx):
     """(label, setup) for every kernel path this model can run."""
     out = [("auto", lambda c: c.set_path(b.PATH_AUTO))]
     out.append(("layerwise", lambda c: c.set_path(b.PATH_LAYERWISE_ALU)))
-    for v in (0, 1, 2, 3):
+    for v in (0, 1, 2, 3, 4):          # 4 = the generic kernel (run-time widths, weights in LDS)
         def fused(c, v=v):
             c.set_path(b.PATH_FUSED_MFMA)
             c.set_tuning(variant=v)
@@ -303,6 +303,109 @@ def test_random_models_every_codec_through_model_kernels(codecs, widths, gpu_ok,
         labels.append(label)
     if 36 not in codecs:
         assert any(l.startswith("fused") for l in labels), (codecs, labels)
+    ctx.close()
+
+
+def _random_cnn_text(rng, C, codecs, widths, n_classes=10):
+    """Header text of a CNN model in the reference's topology (conv, conv, pool, conv, pool, 3 x FC;
+    BitNetMCU_MNIST_dll.c:48-91) with C channels and RANDOM weights."""
+    lines = ["#include <stdint.h>", "#define MODEL_CNNMNIST", "#define NUM_LAYERS 8", "#define MAX_N_ACTIVATIONS 256"]
+
+    def conv(k, cin, xin):
+        w = rng.integers(-6, 7, size=9 * C)
+        lines.extend([f"#define L{k}_active", f"#define L{k}_type BitConv2d", f"#define L{k}_in_channels {cin}", f"#define L{k}_out_channels {C}",
+                      f"#define L{k}_incoming_x {xin}", f"#define L{k}_incoming_y {xin}", f"#define L{k}_outgoing_x {xin - 2}",
+                      f"#define L{k}_outgoing_y {xin - 2}", f"#define L{k}_kernel_size 3", f"#define L{k}_stride 1", f"#define L{k}_padding 0",
+                      f"#define L{k}_groups {1 if cin == 1 else C}", f"#define L{k}_bitperweight 8",
+                      f"const int8_t L{k}_weights[] = {{" + ",".join(str(int(v)) for v in w) + "};"])
+
+    def pool(k, xin):
+        lines.extend([f"#define L{k}_active", f"#define L{k}_type MaxPool2d", f"#define L{k}_pool_size 2", f"#define L{k}_incoming_x {xin}",
+                      f"#define L{k}_incoming_y {xin}", f"#define L{k}_outgoing_x {xin // 2}", f"#define L{k}_outgoing_y {xin // 2}"])
+    conv(2, 1, 16)
+    conv(4, C, 14)
+    pool(6, 12)
+    conv(7, C, 6)
+    pool(9, 4)
+    n_in = 4 * C
+    for k, bpw, n_out in zip((11, 13, 15), codecs, list(widths) + [n_classes]):
+        fb = {1: 1, 2: 2, 4: 4, 12: 4, 20: 4, 16: 8}[bpw]
+        w = rng.integers(0, 2**32, size=n_out * (n_in * fb // 32), dtype=np.uint32)
+        lines.extend([f"#define L{k}_active", f"#define L{k}_bitperweight {bpw}", f"#define L{k}_incoming_weights {n_in}",
+                      f"#define L{k}_outgoing_weights {n_out}", f"const uint32_t L{k}_weights[] = {{" + ",".join(hex(int(x)) for x in w) + "};"])
+        n_in = n_out
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("codecs,widths,n_classes", [
+    ((4, 4, 4, 4), (32, 32, 32), 10),           # one tile per layer
+    ((4, 4, 4, 4), (128, 64, 64), 47),          # EMNIST-balanced head (models.py:83), 4-tile class
+    ((4, 4, 4), (96, 64), 10),                  # three layers, 3-tile first layer
+    ((4, 2, 4, 4), (48, 80, 24), 26),           # widths that are not multiples of 32
+    ((16, 16, 16, 16), (128, 128, 96), 37),     # 8-bit: not doubled
+    ((20, 20, 20, 20), (64, 64, 64), 10),       # FP1.3.0 with +128 present: second weight plane
+    ((20, 20, 20, 20), (96, 128, 40), 12),      # the same in the 4-tile class
+    ((4, 4, 4, 4), (200, 104, 56), 10),         # 8-tile class (one wave per SIMD)
+    ((2, 4, 1, 4), (256, 32, 64), 62),          # 8-tile class, narrow tail, 62 classes
+    ((64, 64, 64, 64), (64, 128, 32), 10),      # ternary through MFMA, exporter padding
+])
+def test_random_shapes_through_the_generic_fused_kernel(codecs, widths, n_classes, gpu_ok, orc):
+    """VERDICT r01 missing #1: widths are free parameters of the reference's models (models.py:62-84); every shape must
+    run through a fused kernel, bit-exact in class ids and logits, ragged batch sizes included."""
+    rng = np.random.default_rng(hash((codecs, widths, n_classes)) % 2**32)
+    text = _random_model_text(rng, codecs, widths, n_classes)
+    if 20 in codecs:
+        assert "7" in text     # random nibbles: +128 weights are present
+    model = b.Model.from_header_text(text)
+    om = util.OracleModel(model, orc)
+    ctx = b.Context(model)
+    assert ctx.path == b.PATH_FUSED_MFMA, "shape fell off the fused kernels"
+    ctx.set_tuning(variant=4)
+    for n in (1, 31, 33, 1000, 4097):
+        x = np.concatenate([synth.images(11, n, DIST_U)[: (n + 1) // 2], synth.images(11, n, DIST_M)[: n // 2]])
+        want = om.infer(x, logits=True)
+        got = ctx.infer(x, logits=True)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (widths, n)
+        assert np.array_equal(ctx.infer(x), want[0])          # class ids only (no logits buffer)
+    edge = np.concatenate([np.zeros((3, 256), np.int8), np.full((3, 256), -128, np.int8), np.full((3, 256), 127, np.int8)])
+    got, want = ctx.infer(edge, logits=True), om.infer(edge, logits=True)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ctx.close()
+
+
+@pytest.mark.parametrize("C,codecs,widths,n_classes", [
+    (24, (2, 4, 4), (96, 64), 10),      # 96-byte act rows -> padded to 128
+    (40, (4, 4, 4), (64, 32), 10),      # 160 -> 256
+    (80, (2, 4, 4), (96, 64), 10),      # the 80-wide CNN of docs/documentation.md:898: 320 -> 512, two channel groups
+    (8, (4, 4, 4), (32, 32), 37),       # 32 -> 64
+])
+def test_random_cnn_channel_counts_through_the_generic_tail(C, codecs, widths, n_classes, gpu_ok, orc):
+    rng = np.random.default_rng(C * 1000 + n_classes)
+    model = b.Model.from_header_text(_random_cnn_text(rng, C, codecs, widths, n_classes))
+    om = util.OracleModel(model, orc)
+    ctx = b.Context(model)
+    assert ctx.path == b.PATH_FUSED_MFMA and ctx.variant == 4
+    x = np.concatenate([synth.images(3, 700, DIST_U), synth.images(3, 701, DIST_M)])
+    want = om.infer(x, logits=True)
+    got = ctx.infer(x, logits=True)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ctx.set_path(b.PATH_LAYERWISE_ALU)
+    got = ctx.infer(x, logits=True)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ctx.close()
+
+
+def test_too_wide_model_falls_back_loudly_and_stays_exact(gpu_ok, orc, capfd):
+    """Shapes beyond the fused kernels (a layer wider than 256) run on the layer-wise path — with a warning, not silently."""
+    rng = np.random.default_rng(9)
+    model = b.Model.from_header_text(_random_model_text(rng, (4, 4, 4, 4), (320, 64, 64)))
+    ctx = b.Context(model)
+    assert ctx.path == b.PATH_LAYERWISE_ALU
+    assert "layer-wise ALU" in capfd.readouterr().err
+    x = synth.images(0, 500, DIST_U)
+    want = util.OracleModel(model, orc).infer(x, logits=True)
+    got = ctx.infer(x, logits=True)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     ctx.close()
 
 

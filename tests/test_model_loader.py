@@ -128,3 +128,31 @@ def test_blob_survives_corruption():
             Model.from_blob(bytes(b2[:int(rng.integers(1, len(b2) + 1))] if it % 2 else b2))
         except BnmError:
             pass
+
+
+def test_wrong_element_types_are_rejected():
+    """a weight array of the right element COUNT but the wrong C type would make the kernels read past
+    the uploaded bytes.  Text and blob paths both refuse it."""
+    import re
+    import struct
+    fc = write_header(util.load_golden_model("mcu_1k"), "exporter")
+    for bad_type in ("int8_t", "uint16_t", "uint8_t"):
+        with pytest.raises(BnmError):
+            Model.from_header_text(re.sub(r"const uint32_t (L\d+_weights)", rf"const {bad_type} \1", fc, count=1))
+    tern = write_header(util.load_golden_model("tern_96"), "exporter")
+    with pytest.raises(BnmError):
+        Model.from_header_text(re.sub(r"const uint16_t (L\d+_weights)", r"const uint32_t \1", tern, count=1))
+    cnn = write_header(util.load_golden_model("mcu_cnn_16small"), "exporter")
+    with pytest.raises(BnmError):
+        Model.from_header_text(re.sub(r"const int8_t (L\d+_weights)", r"const uint32_t \1", cnn, count=1))
+    # blob: patch weight_elem_bytes / byte counts of the first layer record (header 24 B, then {info 56 B, offset, bytes})
+    good = bytearray(util.load_golden_model("mcu_cnn_16small").to_blob())
+    info_off = 24
+    eb_off = info_off + 12 * 4           # weight_elem_bytes is the 13th uint32 of bnm_layer_info
+    for eb, cnt, nbytes in ((0, 9 * 16, 0), (4, 9 * 16, 9 * 16 * 4), (1, 9 * 16, 9 * 16 - 1)):
+        b2 = bytearray(good)
+        struct.pack_into("<II", b2, eb_off, eb, cnt)
+        struct.pack_into("<I", b2, info_off + 56 + 4, nbytes)
+        with pytest.raises(BnmError):
+            Model.from_blob(bytes(b2))
+    Model.from_blob(bytes(good))
