@@ -84,18 +84,42 @@ struct RowGeom {
 // tile around updates of one shared accumulator array: hipcc answered with accumulator copies and spills.)
 // A fragment (m, part, s) of a layer sits at off + ((m*SP + part)*KT + s) KiB of the LDS weight image, lane-linear; K-steps
 // past the previous layer's real tile count hold zero weights, so whatever the matching B registers contain is harmless.
+// The MFMA stream of (part of) a layer: items (part p, K-step s, tile m), K-step outermost so that consecutive MFMAs go to
+// DIFFERENT accumulators (no dependent-accumulator stalls), fragment reads issued DEPTH items ahead of their MFMA in source
+// order — hipcc keeps that order, whereas left to itself it put every ds_read directly in front of its MFMA and paid the
+// full LDS latency fifty times per tile.  The fragment of (m, p, K-step s0+s) sits at a + ((m*SP + p)*KSTRIDE + s)*1024.
+template <int MT, int NS, int KSTRIDE, int SP, bool INIT, int NB>
+BNM_DEVICE void mma_stream(const char *a, const i32x4 (&b)[NB], i32x16 (&acc)[MT]) {
+    static_assert(NS <= NB, "operand array too short");
+    constexpr int N = SP * NS * MT;
+    constexpr int DEPTH = N < 4 ? N : 4;
+    auto frag = [&](auto I) -> i32x4 {
+        constexpr int i = decltype(I)::value;
+        constexpr int pp = i / (NS * MT), ss = (i % (NS * MT)) / MT, mm = i % MT;
+        return *(const i32x4 *)(a + ((mm * SP + pp) * KSTRIDE + ss) * 1024);
+    };
+    __builtin_amdgcn_sched_barrier(0);      // the stream is its own scheduling region
+    i32x4 ring[DEPTH];
+    static_for<0, DEPTH>([&](auto I) { ring[decltype(I)::value] = frag(I); });
+    static_for<0, N>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int pp = i / (NS * MT), ss = (i % (NS * MT)) / MT, mm = i % MT;
+        const i32x16 c = (INIT && pp == 0 && ss == 0) ? zero16() : acc[mm];
+        acc[mm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[i % DEPTH], b[ss], c, 0, 0, 0);
+        if constexpr (i + DEPTH < N) ring[i % DEPTH] = frag(std::integral_constant<int, i + DEPTH>{});
+    });
+    // pin the issue order: DEPTH fragment reads, then { one MFMA, one read } pairs (0x100 = DS read, 0x008 = MFMA)
+    __builtin_amdgcn_sched_group_barrier(0x100, DEPTH, 0);
+    static_for<0, N>([&](auto I) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (decltype(I)::value + DEPTH < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int MT, int KT, int SP, int NB>
 BNM_DEVICE void block_mma(const char *smem, uint32_t lane16, uint32_t off, const i32x4 (&b)[NB], i32x16 (&acc)[MT]) {
-    static_assert(KT <= NB, "operand array too short");
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-        const char *a = smem + (off + (uint32_t)(m * SP * KT * 1024) + lane16);
-        i32x16 c = zero16();
-#pragma unroll
-        for (int s = 0; s < KT * SP; s++)     // SP == 2: FP1.3.0's +128 = 64 + 64, second plane over the same B operands
-            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const i32x4 *)(a + s * 1024), b[s % KT], c, 0, 0, 0);
-        acc[m] = c;
-    }
+    mma_stream<MT, KT, KT, SP, true, NB>(smem + (off + lane16), b, acc);
 }
 
 template <int MMAX, int MT>
@@ -243,19 +267,7 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
                         retire_lds_reads();
                         if (tile + stride < n_tiles) dma_tile(tile + stride);
                     }
-#pragma unroll
-                    for (int m = 0; m < mt; m++) {
-                        const char *a = smem + (d.frag_off[0] + (uint32_t)(m * SP * KT0 * 1024 + ch * KC * 1024) + lane16);
-                        i32x16 c = ch == 0 ? zero16() : acc[m];
-#pragma unroll
-                        for (int s = 0; s < KC; s++) c = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const i32x4 *)(a + s * 1024), b0[s], c, 0, 0, 0);
-                        if constexpr (SP == 2) {
-#pragma unroll
-                            for (int s = 0; s < KC; s++)
-                                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const i32x4 *)(a + (KT0 + s) * 1024), b0[s], c, 0, 0, 0);
-                        }
-                        acc[m] = c;
-                    }
+                    mma_stream<mt, KC, KT0, SP, ch == 0, KC>(smem + (d.frag_off[0] + (uint32_t)(ch * KC * 1024) + lane16), b0, acc);
                 });
                 i32x4 p[mt];
                 relunorm_pack<mt, DBL>(acc, p, h);

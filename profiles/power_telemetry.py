@@ -36,26 +36,48 @@ def read_int(path):
         return None
 
 
+def our_pci_bus_id():
+    """PCI address of HIP device 0 (the sysfs tree shows every GPU of the host, the container sees one of them)"""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+            return buf.value.decode().lower()
+    except Exception:
+        pass
+    return None
+
+
 class Sampler:
+    """samples EVERY amdgpu card's hwmon files; `ours` marks the card whose PCI address is HIP device 0's"""
+
     def __init__(self):
-        self.files = {}
+        self.cards = {}
+        want = our_pci_bus_id()
+        self.ours = None
         for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
             hw = glob.glob(os.path.join(card, "hwmon", "hwmon*"))
             if not hw:
                 continue
             h = hw[0]
+            files = {}
             cand = {"power_uW": ["power1_average", "power1_input"], "power_cap_uW": ["power1_cap"], "sclk_Hz": ["freq1_input"],
                     "mclk_Hz": ["freq2_input"], "temp_mC": ["temp1_input"], "temp_hbm_mC": ["temp3_input"]}
             for k, names in cand.items():
                 for nm in names:
                     p = os.path.join(h, nm)
                     if read_int(p) is not None:
-                        self.files[k] = p
+                        files[k] = p
                         break
-            if "power_uW" in self.files or "sclk_Hz" in self.files:
-                self.card = card
-                break
-        self.mode = "sysfs" if self.files else None
+            if files:
+                addr = os.path.basename(os.path.realpath(card)).lower()
+                name = os.path.basename(os.path.dirname(card)) + "@" + addr
+                self.cards[name] = files
+                if want and addr == want:
+                    self.ours = name
+        self.files = self.cards.get(self.ours) if self.ours else None
+        self.mode = "sysfs" if self.cards else None
         if not self.mode:
             for tool, args in (("rocm-smi", ["--showpower", "--showclocks", "--json"]), ("amd-smi", ["metric", "-p", "-c", "--json"])):
                 try:
@@ -73,8 +95,8 @@ class Sampler:
         while not self.stop:
             t = time.perf_counter() - t0
             if self.mode == "sysfs":
-                self.samples.append((t, {k: read_int(p) for k, p in self.files.items()}))
-                time.sleep(0.003)
+                self.samples.append((t, {c: {k: read_int(p) for k, p in f.items()} for c, f in self.cards.items()}))
+                time.sleep(0.002)
             elif self.mode:
                 try:
                     r = subprocess.run(self.cmd, capture_output=True, text=True, timeout=20)
@@ -88,16 +110,21 @@ class Sampler:
         if self.mode != "sysfs":
             return {"mode": self.mode, "n_samples": len(self.samples), "last": self.samples[-1][1] if self.samples else None,
                     "first": self.samples[0][1] if self.samples else None}
-        out = {"mode": "sysfs", "n_samples": len(self.samples),
-               "sample_period_ms": 1e3 * (self.samples[-1][0] - self.samples[0][0]) / max(1, len(self.samples) - 1) if len(self.samples) > 1 else None}
-        for k in self.files:
-            v = np.array([s[1][k] for s in self.samples if s[1].get(k) is not None], dtype=np.float64)
-            if len(v):
-                scale = 1e-6 if k.endswith("_uW") else 1e-9 if k.endswith("_Hz") else 1e-3
-                unit = "W" if k.endswith("_uW") else "GHz" if k.endswith("_Hz") else "C"
-                half = v[len(v) // 2:]
-                out[k.rsplit("_", 1)[0] + "_" + unit] = {"mean": float(v.mean() * scale), "max": float(v.max() * scale), "min": float(v.min() * scale),
-                                                       "second_half_mean": float(half.mean() * scale), "distinct": int(len(np.unique(v)))}
+        out = {"mode": "sysfs", "n_samples": len(self.samples), "our_card": self.ours, "hip_device_0_pci": our_pci_bus_id(),
+               "sample_period_ms": 1e3 * (self.samples[-1][0] - self.samples[0][0]) / max(1, len(self.samples) - 1) if len(self.samples) > 1 else None,
+               "cards": {}}
+        for card, files in self.cards.items():
+            o = {}
+            for k in files:
+                v = np.array([s[1][card][k] for s in self.samples if s[1][card].get(k) is not None], dtype=np.float64)
+                if len(v):
+                    scale = 1e-6 if k.endswith("_uW") else 1e-9 if k.endswith("_Hz") else 1e-3
+                    unit = "W" if k.endswith("_uW") else "GHz" if k.endswith("_Hz") else "C"
+                    half = v[len(v) // 2:]
+                    o[k.rsplit("_", 1)[0] + "_" + unit] = {"mean": round(float(v.mean() * scale), 4), "max": round(float(v.max() * scale), 4),
+                                                           "min": round(float(v.min() * scale), 4),
+                                                           "second_half_mean": round(float(half.mean() * scale), 4)}
+            out["cards"][card + (" (ours)" if card == self.ours else "")] = o
         return out
 
 
