@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include "bnm_kernels.h"
@@ -57,6 +59,87 @@ struct ScopedDev : DevBuf {
     ~ScopedDev() { release(); }
 };
 
+// page-locked host memory that the GPU can address directly (zero-copy): the latency path's buffers and the staging
+// buffers of the pipelined host path
+struct PinBuf {
+    void *host = nullptr, *dev = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return BNM_OK;
+        release();
+        HIP_TRY(hipHostMalloc(&host, need, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(&dev, host, 0));
+        bytes = need;
+        return BNM_OK;
+    }
+    void release() {
+        if (host) (void)hipHostFree(host);
+        host = dev = nullptr;
+        bytes = 0;
+    }
+};
+
+// memcpy on several host threads (a pageable -> pinned staging copy runs at one core's ~10 GB/s otherwise, a fifth of what
+// PCIe Gen5 x16 moves).  Persistent workers; run() returns when every slice has been copied.
+class ParallelCopier {
+public:
+    explicit ParallelCopier(unsigned workers) {
+        for (unsigned i = 0; i < workers; i++) th_.emplace_back([this, i, workers] { loop(i, workers); });
+    }
+    ~ParallelCopier() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void run(void *dst, const void *src, size_t bytes) {
+        if (th_.empty() || bytes < (1u << 20)) { std::memcpy(dst, src, bytes); return; }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            dst_ = (char *)dst; src_ = (const char *)src; bytes_ = bytes;
+            pending_ = (unsigned)th_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+private:
+    void loop(unsigned i, unsigned n) {
+        uint64_t seen = 0;
+        for (;;) {
+            char *d; const char *s; size_t b;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                d = dst_; s = src_; b = bytes_;
+            }
+            const size_t per = ((b + n - 1) / n + 4095) & ~size_t(4095);
+            const size_t lo = (size_t)i * per, hi = lo + per < b ? lo + per : b;
+            if (lo < b) std::memcpy(d + lo, s + lo, hi - lo);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    size_t bytes_ = 0;
+    unsigned pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
 struct FcDev {
     bnm_layer_info info{};
     uint32_t n_real = 0;      // activations actually consumed
@@ -94,6 +177,17 @@ struct bnm_ctx {
 #endif
     // scratch
     DevBuf act_a, act_b, out32, argmax, cnn_feat, stage_img, stage_cls, stage_logits;
+    // host-pointer paths: zero-copy buffers of the latency path (n <= kLatencyMax) and the two slots of the pipelined path
+    PinBuf lat_in, lat_cls, lat_logits;
+    hipStream_t lat_stream = nullptr;
+    struct HostSlot {
+        PinBuf in, cls, logits;
+        DevBuf d_in, d_cls, d_logits;
+        hipStream_t stream = nullptr;
+        hipEvent_t computed = nullptr;
+        uint64_t off = 0, count = 0;      // the chunk in flight on this slot (count == 0: idle)
+    } slot[2];
+    ParallelCopier *copier = nullptr;
     std::vector<void *> owned;
     std::mutex mu;
 };
@@ -481,6 +575,15 @@ void bnm_ctx_destroy(bnm_ctx *c) {
     for (void *p : c->owned) (void)hipFree(p);
     for (DevBuf *b : {&c->act_a, &c->act_b, &c->out32, &c->argmax, &c->cnn_feat, &c->stage_img, &c->stage_cls, &c->stage_logits})
         b->release();
+    for (PinBuf *b : {&c->lat_in, &c->lat_cls, &c->lat_logits}) b->release();
+    if (c->lat_stream) (void)hipStreamDestroy(c->lat_stream);
+    for (auto &sl : c->slot) {
+        for (PinBuf *b : {&sl.in, &sl.cls, &sl.logits}) b->release();
+        for (DevBuf *b : {&sl.d_in, &sl.d_cls, &sl.d_logits}) b->release();
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        if (sl.computed) (void)hipEventDestroy(sl.computed);
+    }
+    delete c->copier;
     delete c;
 }
 
@@ -519,12 +622,97 @@ int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d
     return infer_device_locked(c, d_images, n, d_cls, d_logits, nullptr, 0, (hipStream_t)stream);
 }
 
+// ---- host-pointer inference ---------------------------------------------------------------------------------------
+// (1) n <= kLatencyMax: zero-copy.  The images are copied into a persistent page-locked buffer the GPU addresses
+//     directly, the kernel reads it over PCIe and writes class ids (and logits) into another such buffer: one launch and one
+//     stream wait per call, no hipMemcpy.  This is what the drop-in Inference() symbol runs (one image per call).
+// (2) larger batches: two slots of page-locked staging + device buffers, each with its own stream.  Host threads copy chunk
+//     k+1 into its slot while the DMA engines move chunk k and return chunk k-1's results; compute of consecutive chunks is
+//     chained by an event (it shares per-context scratch on the CNN / layer-wise paths), which costs nothing: the kernels
+//     take microseconds per chunk, the PCIe transfer a millisecond.
+// (3) the activation tap (parity/debug): the plain synchronous path.
+constexpr uint64_t kLatencyMax = 64;
+constexpr uint64_t kHostChunk = 1ull << 18;      // images per pipelined chunk: 64 MiB of image bytes
+
+static int infer_host_small(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls, int32_t *logits) {
+    const uint32_t ncls = c->model.num_classes();
+    if (!c->lat_stream) {
+        if (int e = c->lat_in.ensure(kLatencyMax * 256)) return e;
+        if (int e = c->lat_cls.ensure(kLatencyMax * 4)) return e;
+        if (int e = c->lat_logits.ensure(kLatencyMax * (size_t)ncls * 4)) return e;
+        HIP_TRY(hipStreamCreateWithFlags(&c->lat_stream, hipStreamNonBlocking));
+    }
+    std::memcpy(c->lat_in.host, images, (size_t)n * 256);
+    if (int e = infer_device_locked(c, (const int8_t *)c->lat_in.dev, n, (uint32_t *)c->lat_cls.dev,
+                                    logits ? (int32_t *)c->lat_logits.dev : nullptr, nullptr, 0, c->lat_stream))
+        return e;
+    HIP_TRY(hipStreamSynchronize(c->lat_stream));
+    if (cls) std::memcpy(cls, c->lat_cls.host, (size_t)n * 4);
+    if (logits) std::memcpy(logits, c->lat_logits.host, (size_t)n * ncls * 4);
+    return BNM_OK;
+}
+
+static int infer_host_pipelined(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls, int32_t *logits) {
+    const uint32_t ncls = c->model.num_classes();
+    if (!c->copier) {
+        unsigned hw = std::thread::hardware_concurrency();
+        c->copier = new ParallelCopier(hw >= 16 ? 8u : hw >= 4 ? hw / 2u : 0u);
+    }
+    for (auto &sl : c->slot) {
+        if (!sl.stream) HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        if (!sl.computed) HIP_TRY(hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));
+        if (int e = sl.in.ensure(kHostChunk * 256)) return e;
+        if (int e = sl.d_in.ensure(kHostChunk * 256)) return e;
+        if (int e = sl.cls.ensure(kHostChunk * 4)) return e;
+        if (int e = sl.d_cls.ensure(kHostChunk * 4)) return e;
+        if (logits) {
+            if (int e = sl.logits.ensure(kHostChunk * (size_t)ncls * 4)) return e;
+            if (int e = sl.d_logits.ensure(kHostChunk * (size_t)ncls * 4)) return e;
+        }
+        sl.count = 0;
+    }
+    auto drain = [&](bnm_ctx::HostSlot &sl) -> int {      // results of the chunk in flight on this slot -> caller's arrays
+        if (!sl.count) return BNM_OK;
+        HIP_TRY(hipStreamSynchronize(sl.stream));
+        if (cls) std::memcpy(cls + sl.off, sl.cls.host, (size_t)sl.count * 4);
+        if (logits) std::memcpy(logits + sl.off * ncls, sl.logits.host, (size_t)sl.count * ncls * 4);
+        sl.count = 0;
+        return BNM_OK;
+    };
+    int k = 0;
+    hipEvent_t prev_computed = nullptr;
+    for (uint64_t off = 0; off < n; off += kHostChunk, k ^= 1) {
+        bnm_ctx::HostSlot &sl = c->slot[k];
+        const uint64_t cn = n - off < kHostChunk ? n - off : kHostChunk;
+        if (int e = drain(sl)) return e;
+        c->copier->run(sl.in.host, images + off * 256, (size_t)cn * 256);
+        HIP_TRY(hipMemcpyAsync(sl.d_in.p, sl.in.host, (size_t)cn * 256, hipMemcpyHostToDevice, sl.stream));
+        if (prev_computed) HIP_TRY(hipStreamWaitEvent(sl.stream, prev_computed, 0));
+        if (int e = infer_device_locked(c, (const int8_t *)sl.d_in.p, cn, (uint32_t *)sl.d_cls.p,
+                                        logits ? (int32_t *)sl.d_logits.p : nullptr, nullptr, 0, sl.stream))
+            return e;
+        HIP_TRY(hipEventRecord(sl.computed, sl.stream));
+        prev_computed = sl.computed;
+        HIP_TRY(hipMemcpyAsync(sl.cls.host, sl.d_cls.p, (size_t)cn * 4, hipMemcpyDeviceToHost, sl.stream));
+        if (logits) HIP_TRY(hipMemcpyAsync(sl.logits.host, sl.d_logits.p, (size_t)cn * ncls * 4, hipMemcpyDeviceToHost, sl.stream));
+        sl.off = off;
+        sl.count = cn;
+    }
+    if (int e = drain(c->slot[k])) return e;       // older chunk first
+    return drain(c->slot[k ^ 1]);
+}
+
 static int infer_host_impl(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls, int32_t *logits, int8_t *acts,
                            uint32_t acts_stride) {
     if (!c) return fail(BNM_EINVAL, "null ctx");
     if (n && (!images || (!cls && !acts))) return fail(BNM_EINVAL, "null host pointer");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    if (!n) return BNM_OK;
+    if (!acts) {
+        if (n <= kLatencyMax) return infer_host_small(c, images, n, cls, logits);
+        return infer_host_pipelined(c, images, n, cls, logits);
+    }
     const uint32_t ncls = c->model.num_classes();
     for (uint64_t off = 0; off < n; off += kChunk) {
         uint64_t cn = n - off < kChunk ? n - off : kChunk;
@@ -532,11 +720,10 @@ static int infer_host_impl(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
         if (int e = c->stage_cls.ensure((size_t)cn * 4)) return e;
         if (logits) if (int e = c->stage_logits.ensure((size_t)cn * ncls * 4)) return e;
         ScopedDev tap;
-        if (acts) if (int e = tap.ensure((size_t)cn * acts_stride)) return e;
+        if (int e = tap.ensure((size_t)cn * acts_stride)) return e;
         HIP_TRY(hipMemcpy(c->stage_img.p, images + off * 256, (size_t)cn * 256, hipMemcpyHostToDevice));
         int e = infer_device_locked(c, (const int8_t *)c->stage_img.p, cn, (uint32_t *)c->stage_cls.p,
-                                    logits ? (int32_t *)c->stage_logits.p : nullptr, acts ? (int8_t *)tap.p : nullptr,
-                                    acts_stride, nullptr);
+                                    logits ? (int32_t *)c->stage_logits.p : nullptr, (int8_t *)tap.p, acts_stride, nullptr);
         if (e == BNM_OK) {
             hipError_t he = hipDeviceSynchronize();
             if (he != hipSuccess) e = fail(BNM_EHIP, std::string("kernel execution: ") + hipGetErrorString(he));
@@ -544,8 +731,7 @@ static int infer_host_impl(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
         if (e == BNM_OK && cls) HIP_TRY(hipMemcpy(cls + off, c->stage_cls.p, (size_t)cn * 4, hipMemcpyDeviceToHost));
         if (e == BNM_OK && logits)
             HIP_TRY(hipMemcpy(logits + off * ncls, c->stage_logits.p, (size_t)cn * ncls * 4, hipMemcpyDeviceToHost));
-        if (e == BNM_OK && acts)
-            HIP_TRY(hipMemcpy(acts + off * acts_stride, tap.p, (size_t)cn * acts_stride, hipMemcpyDeviceToHost));
+        if (e == BNM_OK) HIP_TRY(hipMemcpy(acts + off * acts_stride, tap.p, (size_t)cn * acts_stride, hipMemcpyDeviceToHost));
         if (e != BNM_OK) return e;
     }
     return BNM_OK;
