@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="fused kernel variant (-1 = default; 4 = generic kernel)")
     ap.add_argument("--grid", type=int, default=0, help="workgroups (0 = default)")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 fused MFMA, 2 layer-wise ALU, 3 ternary ALU")
+    ap.add_argument("--cnn-variant", type=int, default=-1, help="CNN front end: 1 conv1 on MFMA (default), 0 all-VALU kernel of round 1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -218,6 +219,8 @@ def main():
         ctx.set_path(a.path)
     if a.variant >= 0 or a.grid > 0:
         ctx.set_tuning(a.variant, a.grid)
+    if a.cnn_variant >= 0:
+        ctx.set_cnn_variant(a.cnn_variant)
 
     # ---- resident workload: this rank's shard of the global synthetic image stream --------------------
     if a.scaling == "weak":

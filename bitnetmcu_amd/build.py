@@ -35,7 +35,7 @@ def newer(src_list, out):
 
 
 SOURCES = (("bnm_fused_fc.hip", True), ("bnm_fused_generic.hip", True), ("bnm_fused_generic_m2.hip", True),
-           ("bnm_fused_generic_m4.hip", True), ("bnm_fused_generic_m8.hip", True), ("bnm_cnn.hip", True), ("bnm_ternary.hip", True),
+           ("bnm_fused_generic_m4.hip", True), ("bnm_fused_generic_m8.hip", True), ("bnm_cnn.hip", True, ("-mllvm", "-amdgpu-mfma-vgpr-form")), ("bnm_ternary.hip", True),
            ("bnm_layerwise.hip", True), ("bnm_support.hip", True), ("bnm_qat.hip", True), ("bnm_capi.cpp", False),
            ("bnm_model.cpp", False))
 DIAG_SOURCES = (("bnm_diag.hip", True),)      # diagnostic library only (--diag / --diag-timing)
@@ -50,11 +50,12 @@ def objects(force=False, extra_flags=(), obj_dir=None, sources=SOURCES):
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".hpp"))] + \
            [os.path.join(HERE, "..", "include", "bitnetmcu_hip.h")]
     out, jobs = [], []
-    for src, is_hip in sources:
+    for entry in sources:
+        src, is_hip, file_flags = entry[0], entry[1], (entry[2] if len(entry) > 2 else ())
         s = os.path.join(CSRC, src)
         o = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         if force or newer([s] + hdrs, o):
-            cmd = [HIPCC, f"--offload-arch={ARCH}"] + CXXFLAGS + list(extra_flags) + ["-c", s, "-o", o]
+            cmd = [HIPCC, f"--offload-arch={ARCH}"] + CXXFLAGS + list(extra_flags) + list(file_flags) + ["-c", s, "-o", o]
             if not is_hip:
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")

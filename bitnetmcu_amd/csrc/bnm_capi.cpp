@@ -158,6 +158,8 @@ struct bnm_ctx {
     // CNN front end
     uint32_t channels = 0;
     int8_t *w_conv[3] = {nullptr, nullptr, nullptr};
+    int *cnn_wtab = nullptr;       // per-channel weight table of the conv1-on-MFMA front end
+    int cnn_variant = 1;           // 1: conv1 on the matrix cores (default), 0: the all-VALU kernel of round 1
     // fused MFMA path: shape-specialised kernels (register-resident weights, bnm_fused_fc.hip) and / or the generic
     // kernel (run-time widths, weights in LDS, bnm_fused_generic.hip; variant id BNM_FUSED_GENERIC)
     bool fused_ok = false;      // at least one of the two can run this model
@@ -180,6 +182,9 @@ struct bnm_ctx {
     // host-pointer paths: zero-copy buffers of the latency path (n <= kLatencyMax) and the two slots of the pipelined path
     PinBuf lat_in, lat_cls, lat_logits;
     hipStream_t lat_stream = nullptr;
+    bool lat_spin = true;            // poll the page-locked result words instead of waiting for the stream (bnm_ctx_set_host_tuning)
+    unsigned host_threads = 0;       // staging-copy threads of the pipelined path (0 = default)
+    int host_mode = 0;               // 0 pipelined page-locked staging, 1 the HIP runtime's own pageable copies (synchronous)
     struct HostSlot {
         PinBuf in, cls, logits;
         DevBuf d_in, d_cls, d_logits;
@@ -241,6 +246,16 @@ int ctx_build(bnm_ctx *c) {
             if (int e = dev_alloc(c, &p, L.weights.size())) return e;
             HIP_TRY(hipMemcpy(p, L.weights.data(), L.weights.size(), hipMemcpyHostToDevice));
             c->w_conv[k] = (int8_t *)p;
+        }
+        {
+            const uint32_t C = c->channels, C_pad = (C + 63u) / 64u * 64u;
+            std::vector<int> tab((size_t)2 * C_pad * BNM_CNN_WTAB_DWORDS);
+            bnm_cnn_weight_table((const int8_t *)m.layers[0].weights.data(), (const int8_t *)m.layers[1].weights.data(),
+                                 (const int8_t *)m.layers[3].weights.data(), C, tab.data());
+            void *p = nullptr;
+            if (int e = dev_alloc(c, &p, tab.size() * sizeof(int))) return e;
+            HIP_TRY(hipMemcpy(p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+            c->cnn_wtab = (int *)p;
         }
         width = c->channels * 4u;
         li = 5;
@@ -464,7 +479,8 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         if (int e = c->cnn_feat.ensure((size_t)cn * W * 4 + (size_t)cn * AS + 64)) return e;
         int32_t *feat = (c->channels > 64 || d_acts_tap) ? (int32_t *)c->cnn_feat.p : nullptr;
         int8_t *acts = (int8_t *)c->cnn_feat.p + (size_t)cn * W * 4;
-        HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->channels, 4, acts, AS, feat, s));
+        HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,
+                               c->channels, 4, acts, AS, feat, s));
         uint32_t *cls = d_cls + off;
         int32_t *lg = d_logits ? d_logits + off * ncls : nullptr;
         if (d_acts_tap)
@@ -615,6 +631,23 @@ int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
     return BNM_OK;
 }
 
+int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
+    if (!c || variant < 0 || variant > 1) return fail(BNM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->cnn_variant = variant;
+    return BNM_OK;
+}
+
+int bnm_ctx_set_host_tuning(bnm_ctx *c, int mode, int copy_threads, int spin) {
+    if (!c || mode < 0 || mode > 1 || copy_threads < 0 || copy_threads > 256) return fail(BNM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->host_mode = mode;
+    if ((unsigned)copy_threads != c->host_threads) { delete c->copier; c->copier = nullptr; }
+    c->host_threads = (unsigned)copy_threads;
+    c->lat_spin = spin != 0;
+    return BNM_OK;
+}
+
 int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls, int32_t *d_logits, void *stream) {
     if (!c) return fail(BNM_EINVAL, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
@@ -643,10 +676,27 @@ static int infer_host_small(bnm_ctx *c, const int8_t *images, uint64_t n, uint32
         HIP_TRY(hipStreamCreateWithFlags(&c->lat_stream, hipStreamNonBlocking));
     }
     std::memcpy(c->lat_in.host, images, (size_t)n * 256);
+    // class ids are <= 255: pre-set every slot to a sentinel and watch the page-locked words change — the kernel's stores to
+    // fine-grained host memory are visible as soon as they are written, several microseconds before the stream's completion
+    // signal has been processed.  (Each word is written exactly once, by the last instruction that touches the image, so a
+    // slot that changed also means its image has been read; logits have no spare value and take the stream wait.)
+    volatile uint32_t *out = (volatile uint32_t *)c->lat_cls.host;
+    const bool spin = !logits && c->lat_spin;
+    if (spin) for (uint64_t i = 0; i < n; i++) out[i] = 0xFFFFFFFFu;
     if (int e = infer_device_locked(c, (const int8_t *)c->lat_in.dev, n, (uint32_t *)c->lat_cls.dev,
                                     logits ? (int32_t *)c->lat_logits.dev : nullptr, nullptr, 0, c->lat_stream))
         return e;
-    HIP_TRY(hipStreamSynchronize(c->lat_stream));
+    bool done = false;
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t i = 0;
+        for (unsigned polls = 0; i < n;) {
+            if (out[i] != 0xFFFFFFFFu) { i++; continue; }
+            if ((++polls & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
+        }
+        done = i == n;      // else: slow start (first launch, clock ramp) — fall back to the stream wait
+    }
+    if (!done) HIP_TRY(hipStreamSynchronize(c->lat_stream));
     if (cls) std::memcpy(cls, c->lat_cls.host, (size_t)n * 4);
     if (logits) std::memcpy(logits, c->lat_logits.host, (size_t)n * ncls * 4);
     return BNM_OK;
@@ -656,7 +706,7 @@ static int infer_host_pipelined(bnm_ctx *c, const int8_t *images, uint64_t n, ui
     const uint32_t ncls = c->model.num_classes();
     if (!c->copier) {
         unsigned hw = std::thread::hardware_concurrency();
-        c->copier = new ParallelCopier(hw >= 16 ? 8u : hw >= 4 ? hw / 2u : 0u);
+        c->copier = new ParallelCopier(c->host_threads ? c->host_threads : hw >= 16 ? 8u : hw >= 4 ? hw / 2u : 0u);
     }
     for (auto &sl : c->slot) {
         if (!sl.stream) HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
@@ -711,7 +761,7 @@ static int infer_host_impl(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
     if (!n) return BNM_OK;
     if (!acts) {
         if (n <= kLatencyMax) return infer_host_small(c, images, n, cls, logits);
-        return infer_host_pipelined(c, images, n, cls, logits);
+        if (c->host_mode == 0) return infer_host_pipelined(c, images, n, cls, logits);
     }
     const uint32_t ncls = c->model.num_classes();
     for (uint64_t off = 0; off < n; off += kChunk) {
@@ -720,10 +770,10 @@ static int infer_host_impl(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
         if (int e = c->stage_cls.ensure((size_t)cn * 4)) return e;
         if (logits) if (int e = c->stage_logits.ensure((size_t)cn * ncls * 4)) return e;
         ScopedDev tap;
-        if (int e = tap.ensure((size_t)cn * acts_stride)) return e;
+        if (acts) if (int e = tap.ensure((size_t)cn * acts_stride)) return e;
         HIP_TRY(hipMemcpy(c->stage_img.p, images + off * 256, (size_t)cn * 256, hipMemcpyHostToDevice));
         int e = infer_device_locked(c, (const int8_t *)c->stage_img.p, cn, (uint32_t *)c->stage_cls.p,
-                                    logits ? (int32_t *)c->stage_logits.p : nullptr, (int8_t *)tap.p, acts_stride, nullptr);
+                                    logits ? (int32_t *)c->stage_logits.p : nullptr, acts ? (int8_t *)tap.p : nullptr, acts_stride, nullptr);
         if (e == BNM_OK) {
             hipError_t he = hipDeviceSynchronize();
             if (he != hipSuccess) e = fail(BNM_EHIP, std::string("kernel execution: ") + hipGetErrorString(he));
@@ -731,7 +781,7 @@ static int infer_host_impl(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
         if (e == BNM_OK && cls) HIP_TRY(hipMemcpy(cls + off, c->stage_cls.p, (size_t)cn * 4, hipMemcpyDeviceToHost));
         if (e == BNM_OK && logits)
             HIP_TRY(hipMemcpy(logits + off * ncls, c->stage_logits.p, (size_t)cn * ncls * 4, hipMemcpyDeviceToHost));
-        if (e == BNM_OK) HIP_TRY(hipMemcpy(acts + off * acts_stride, tap.p, (size_t)cn * acts_stride, hipMemcpyDeviceToHost));
+        if (e == BNM_OK && acts) HIP_TRY(hipMemcpy(acts + off * acts_stride, tap.p, (size_t)cn * acts_stride, hipMemcpyDeviceToHost));
         if (e != BNM_OK) return e;
     }
     return BNM_OK;

@@ -196,26 +196,371 @@ __global__ __launch_bounds__(256) void cnn_front_kernel(const int8_t *__restrict
     }
 }
 
-// acts: int8 [n][4C] (always produced).  feat: int32 [n][4C]; optional when C <= 64, REQUIRED scratch when
+// =================================================================================================
+// CNN front end, round 2: conv1 on the matrix cores.
+//
+// Stage 1 is an int8 GEMM that all channels share — [positions x 9 taps] . [9 taps x channels] — so it goes to
+// v_mfma_i32_32x32x32_i8 with the image patches as the A operand (rows = positions, K = taps) and the conv1 weights as the
+// B operand (columns = channels).  The D layout hands lane (j, h) column j (= a channel) and 16 of a tile's 32 rows, and the
+// row -> position map is chosen so that the two lane halves own two BANDS of the image:
+//   half h = 0: conv1 window rows 0..7 = image-space conv1 rows 0..7   (feeds conv2 rows 0..5, pooled rows 0..2)
+//   half h = 1: the image processed UPSIDE DOWN: window rows 0..7 = conv1 rows 13..6 (conv2 rows 11..6, pooled rows 5..3)
+// 8 rows x 14 columns = 112 positions = exactly 7 tiles x 16 rows per half, D register r of tile t <-> window position
+// 16t + r.  The overlap of the two bands (conv1 rows 6, 7) is recomputed by the otherwise idle matrix pipe.  With the lower
+// band flipped and its kernels flipped with it (per-lane weight registers, see the table below) both halves execute the
+// SAME instruction stream on band-local coordinates, including the one exchange the split needs: conv3 row "b" of each
+// band misses one kernel row's contribution, which the partner lane computes from its own last pooled row and sends over
+// (one ds_bpermute per value, 4 values).  A wave = one image; a lane = channel j of block 0 (channels 0..31) and then
+// of block 1 (32..63), same registers.
+// VALU per image: 588 v_dot4 + 588 ReLU/shift/pack of stage 1 become 448 (shift-and-pack by SDWA, ReLU on int16 pairs,
+// odd pairs by v_alignbit); stages 2-3 keep their instruction count.  The A operand costs no VALU: three
+// global_load_dword per tile with per-lane byte offsets that are the same for every image.
+// Per-channel weight table (built on the host, bnm_cnn_weight_table): [band][channel][20 dwords] =
+//   [0..3]  conv1 B operand: byte 4*dy+dx = w1[dy][dx], all zero for band 1 (= K-slots 16..31 of the MFMA)
+//   [4..9]  conv2, per kernel row dy' (flipped for band 1): int16 pairs (w0, w1), (w2, 0)
+//   [10..18] conv3 w3[dy'][dx] as ints;  [19] padding
+// =================================================================================================
+constexpr int CNN_WTAB_DWORDS = 20;
+
+typedef short i16x2v __attribute__((ext_vector_type(2)));
+BNM_DEVICE int pk_relu_i16(int pair) {     // max(pair, 0) on both int16 halves: one v_pk_max_i16
+    i16x2v v = __builtin_bit_cast(i16x2v, pair), z = {0, 0};
+    return __builtin_bit_cast(int, __builtin_elementwise_max(v, z));
+}
+// 16 accumulators -> 8 int16 pairs (acc[2k] >> s, acc[2k+1] >> s), arithmetic shift, low 16 bits kept: one SDWA shift per
+// value writes its half-word in place.  The eight low halves first, then the eight high halves (same destination 8
+// instructions later), trailing s_nop for the dst_sel forwarding hazard hipcc cannot see inside an asm statement.
+BNM_DEVICE void sdwa_ashr_pack8(const i32x16 &a, int s, int (&d)[8]) {
+    // The accumulators come straight from an MFMA and hipcc's hazard recognizer does not look inside an asm statement: a
+    // 16-pass XDL write needs 18 wait states before a VALU read, so the block pads them itself (the other wave of the SIMD
+    // issues meanwhile).
+    asm("s_nop 15\n\ts_nop 3\n\t"
+        "v_ashrrev_i32_sdwa %0, %8, %9 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %1, %8, %11 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %2, %8, %13 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %3, %8, %15 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %4, %8, %17 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %5, %8, %19 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %6, %8, %21 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %7, %8, %23 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %0, %8, %10 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %1, %8, %12 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %2, %8, %14 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %3, %8, %16 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %4, %8, %18 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %5, %8, %20 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %6, %8, %22 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %7, %8, %24 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 1"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(s), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+          "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
+}
+
+// v_dot2_i32_i16 in its VOP3P form (src2 may be the constant 0): hipcc only emits the accumulate-in-place v_dot2c, which costs
+// a v_mov 0 to start every chain.  A chain uses one opcode throughout, so no wait states are needed inside it; the last link
+// pads the DOT-write -> other-VALU-read hazard itself (see dot4_su_last).
+BNM_DEVICE int dot2_first(int a, int b) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+BNM_DEVICE int dot2_next(int a, int b, int acc) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+    return r;
+}
+BNM_DEVICE int dot2_last(int a, int b, int acc) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3\n\ts_nop 2" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+    return r;
+}
+
+// maximum of a non-negative value over the wave's 64 lanes, as a wave-uniform scalar: four DPP steps leave every row of 16
+// lanes holding its row maximum (quad xor 1, quad xor 2, half-row mirror, row mirror), four v_readlane + scalar max join the
+// rows.  (The six dependent ds_bpermute round trips of __shfl_xor cost several hundred cycles of waiting per image.)
+BNM_DEVICE int wave_max_nonneg(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));    // row_mirror
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// SAFE: the patch loads of image row 15, column 13 reach one byte past the image; for the LAST image of the caller's buffer
+// that byte may not exist.  The launcher runs that one image through the SAFE instantiation (clamped address, bytes shifted
+// into place: 2 extra VALU per load) and every other image through the plain one — no run-time test in the hot loop.
+template <bool FUSE, bool SAFE>
+__global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__restrict__ images, uint64_t n,
+                                                             const int *__restrict__ wtab, uint32_t C_pad, uint32_t C, uint32_t c0,
+                                                             uint32_t n_shift, int8_t *__restrict__ acts, uint32_t acts_stride,
+                                                             int32_t *__restrict__ feat) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4u + (uint64_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4u;
+    const uint32_t nblk = (C - c0) > 32u ? 2u : 1u;
+
+    // A-operand addressing (the same for every image): A row i of tile t is window position 16t + q of band beta
+    // (band 1 rows compute conv1 at image row 13 - wr with the kernel the right way up: only the ORDER in which the window
+    // presents rows to stages 2-3 is reversed, and those stages' kernels are reversed with it in the weight table)
+    const int ia = lane & 31, beta = (ia >> 2) & 1, q = (ia & 3) + 4 * (ia >> 3);
+    int o1[7];      // byte offset of the MIDDLE patch row's four pixels; the other two rows are 16 bytes before / after
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int p = 16 * t + q, wr = p / 14, x = p % 14;
+        const int g = beta ? 13 - wr : wr;
+        o1[t] = 16 * (g + 1) + x;
+    }
+    const int vshift = (int)n_shift;
+    const int partner = (lane ^ 32) << 2;        // ds_bpermute address of the lane that owns the other band of this channel
+
+    // ---- work items: (image, 32-channel block), the wave's images in order, block 0 then block 1 of each ----------------
+    const uint32_t blk_shift = nblk == 2u ? 1u : 0u;
+    const uint64_t my_images = wave0 < n ? (n - wave0 + nwaves - 1) / nwaves : 0;
+    const uint64_t items = my_images << blk_shift;
+    // A operand of a tile: bytes 0-3, 4-7, 8-11 of the lane's 16 K-bytes = image rows g, g+1, g+2 at columns x..x+3
+    // (K-slots 12..15 meet zero weights); three L1-resident dword loads, reloaded per channel block.
+    auto load_A = [&](const int8_t *ip, int o) -> i32x4 {
+        int va, vb, vc;
+        if constexpr (!SAFE) {
+            va = *(const int *)(ip + (o - 16));
+            vb = *(const int *)(ip + o);
+            vc = *(const int *)(ip + (o + 16));
+        } else {      // offsets 253..255 (last image row, x = 13): read the dword at 252 and shift the bytes down
+            auto ld = [&](int oo) {
+                const int oc = oo > 252 ? 252 : oo;
+                return (int)((uint32_t)(*(const int *)(ip + oc)) >> (8 * (oo - oc)));
+            };
+            va = ld(o - 16); vb = ld(o); vc = ld(o + 16);
+        }
+        return i32x4{va, vb, vc, vc};
+    };
+    // what an item needs before its first MFMA: its block's 20 weight dwords and its first A tile.  Fetched one item AHEAD
+    // (while the previous item runs its stage 3) so that neither load latency is exposed.
+    struct Head {
+        i32x4 q0, q1, q2, q3, q4, a0;
+    };
+    auto fetch = [&](uint64_t k) -> Head {
+        const uint64_t im = wave0 + (k >> blk_shift) * nwaves;
+        const uint32_t bb = (uint32_t)k & (nblk - 1u);
+        const i32x4 *wp = (const i32x4 *)(wtab + ((size_t)h * C_pad + c0 + 32u * bb + (uint32_t)j) * CNN_WTAB_DWORDS);
+        Head hd;
+        hd.q0 = wp[0]; hd.q1 = wp[1]; hd.q2 = wp[2]; hd.q3 = wp[3]; hd.q4 = wp[4];
+        hd.a0 = load_A(images + im * 256ull, o1[0]);
+        return hd;
+    };
+    Head cur{};
+    if (items) cur = fetch(0);
+    int touch = 0;
+    int fo[2][2] = {{0, 0}, {0, 0}};          // the lane's pooled outputs: [block][t & 1], t = 2h + (t & 1)
+    // The act bytes of an image are stored at the START of the next item, not at the end of their own: vmcnt counts stores,
+    // and the wait hipcc places on the loop's back edge would otherwise park the wave for the write acknowledgement of a
+    // store it has just issued (measured: as long as the whole arithmetic of an image).  Deferred, whatever that wait
+    // covers is thousands of cycles old.
+    uint16_t *pend_p[2] = {nullptr, nullptr};
+    uint16_t pend_v[2] = {0, 0};
+    auto flush_pending = [&]() {
+#pragma unroll
+        for (int bb = 0; bb < 2; bb++)
+            if (pend_p[bb]) { *pend_p[bb] = pend_v[bb]; pend_p[bb] = nullptr; }
+    };
+    for (uint64_t k = 0; k < items; k++) {
+        const uint64_t img = wave0 + (k >> blk_shift) * nwaves;
+        const uint32_t blk = (uint32_t)k & (nblk - 1u);
+        const int8_t *__restrict__ ip = images + img * 256ull;          // wave-uniform
+        // Touch the wave's NEXT image (64 lanes x 4 B = its 256 bytes) so that its patch loads hit the cache instead of waiting
+        // a microsecond for HBM.  The value is never used; its register stays reserved until the end of the iteration, by
+        // when the in-order vector-memory returns behind this iteration's own (waited-for) loads guarantee it has landed.
+        if (blk == 0 && img + nwaves < n) {
+            const int8_t *np = ip + nwaves * 256ull;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(touch) : "v"(lane * 4), "s"(np) : "memory");
+        }
+        const i32x4 wB = cur.q0, wq1 = cur.q1, wq2 = cur.q2, wq3 = cur.q3, wq4 = cur.q4;
+        const int w01[3] = {wq1[0], wq1[2], wq2[0]}, w2z[3] = {wq1[1], wq1[3], wq2[1]};
+        const int k3[9] = {wq2[2], wq2[3], wq3[0], wq3[1], wq3[2], wq3[3], wq4[0], wq4[1], wq4[2]};
+        // ---- stage 1: 7 MFMAs, each followed by the shift / pack / ReLU of its 16 window positions -------------------
+        int E[56], O[56];          // even pairs (r[2k], r[2k+1]) and odd pairs (r[2k+1], r[2k+2]) of the window, raster order
+        int r2[6][12];             // raw conv2 sums of the window rows
+        int p1[3][6];              // pooled rows (band-local)
+        i32x4 Anext = cur.a0;
+        static_for<0, 7>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            i32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0;
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Anext, wB, acc, 0, 0, 0);
+            if constexpr (t < 6) Anext = load_A(ip, o1[t + 1]);
+            // (the previous image's act bytes go out here, BEHIND all of this item's patch loads in program order: no wait
+            // for a patch load covers them, and the back-edge wait finds them ~500 VALU instructions old)
+            if constexpr (t == 6) { if (blk == 0) flush_pending(); }
+            int d[8];
+            sdwa_ashr_pack8(acc, vshift, d);
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) E[8 * t + kk] = pk_relu_i16(d[kk]);
+            // odd pairs whose two neighbours now exist
+            static_for<0, 8>([&](auto K) {
+                constexpr int P = 8 * t + decltype(K)::value - 1;          // O[P] needs E[P] and E[P + 1]
+                if constexpr (P >= 0) O[P] = (int)__builtin_amdgcn_alignbit((uint32_t)E[P + 1], (uint32_t)E[P], 16);
+            });
+            if constexpr (t == 6) O[55] = (int)((uint32_t)E[55] >> 16);
+            // ---- stage 2: the conv2 window rows whose three conv1 rows (and the odd pair closing the last) now exist ------
+            static_for<0, 6>([&](auto Y) {
+                constexpr int y = decltype(Y)::value;
+                constexpr int ready = (7 * (y + 3) < 56) ? (7 * (y + 3)) / 8 : 6;     // tile that produced O[7 (y + 2) + 6]
+                if constexpr (ready == t) {
+                    static_for<0, 12>([&](auto X) {
+                        constexpr int x = decltype(X)::value;
+                        int sum = 0;
+                        static_for<0, 3>([&](auto DY) {
+                            constexpr int dy = decltype(DY)::value;
+                            constexpr int base = 7 * (y + dy);              // first pair of conv1 window row y + dy
+                            const int pa = (x & 1) ? O[base + x / 2] : E[base + x / 2];              // (r[x], r[x+1])
+                            const int pb = (x & 1) ? O[base + x / 2 + 1] : E[base + x / 2 + 1];      // (r[x+2], r[x+3])
+                            sum = dy == 0 ? dot2_first(pa, w01[0]) : dot2_next(pa, w01[dy], sum);
+                            sum = dy == 2 ? dot2_last(pb, w2z[2], sum) : dot2_next(pb, w2z[dy], sum);
+                        });
+                        r2[y][x] = sum;
+                    });
+                    if constexpr (y & 1) {
+                        static_for<0, 6>([&](auto X) {
+                            constexpr int x = decltype(X)::value;
+                            int m = max(max(r2[y - 1][2 * x], r2[y - 1][2 * x + 1]), r2[y][2 * x]);
+                            p1[y >> 1][x] = max(max(m, r2[y][2 * x + 1]), 0) >> n_shift;
+                        });
+                    }
+                }
+            });
+        });
+        // the next item's weights and first tile: in flight during this item's stage 3 (after the last item: the same item
+        // again — a conditional fetch would make hipcc wait for the loads at the merge point)
+        const Head nxt = fetch(k + 1 < items ? k + 1 : k);
+        // ---- stage 3 on band-local rows: conv3 row a complete, row b misses kernel row 2 over the PARTNER's pooled
+        // row 2, which the partner computes (its `send`) while this lane computes the partner's missing term -------------
+        int oa3[4], ob3[4], snd[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            int sa = mul24(k3[0], p1[0][x]);
+#pragma unroll
+            for (int tt = 1; tt < 9; tt++) sa = mad24(k3[tt], p1[tt / 3][x + tt % 3], sa);
+            int sb = mul24(k3[0], p1[1][x]);
+#pragma unroll
+            for (int tt = 1; tt < 6; tt++) sb = mad24(k3[tt], p1[1 + tt / 3][x + tt % 3], sb);
+            int sc = mul24(k3[0], p1[2][x]);
+            sc = mad24(k3[1], p1[2][x + 1], sc);
+            sc = mad24(k3[2], p1[2][x + 2], sc);
+            oa3[x] = sa; ob3[x] = sb; snd[x] = sc;
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) ob3[x] += __builtin_amdgcn_ds_bpermute(partner, snd[x]);
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            int m = max(max(oa3[2 * x], oa3[2 * x + 1]), ob3[2 * x]);
+            const int v = max(max(m, ob3[2 * x + 1]), 0) >> n_shift;
+            fo[0][x] = blk == 0 ? v : fo[0][x];
+            fo[1][x] = blk == 1 ? v : fo[1][x];
+        }
+        cur = nxt;
+        if (blk + 1 == nblk) {
+            // ---- outputs: lane (j, h), block b: channel c0 + 32 b + j, values t = 2h, 2h + 1 ---------------------------------
+            if (feat) {
+#pragma unroll
+                for (uint32_t bb = 0; bb < 2; bb++) {
+                    const uint32_t c = c0 + 32u * bb + (uint32_t)j;
+                    if (bb < nblk && c < C) {
+                        int *fp = feat + img * (4ull * C) + 4ull * c + 2u * (uint32_t)h;
+                        fp[0] = fo[bb][0];
+                        fp[1] = fo[bb][1];
+                    }
+                }
+            }
+            if constexpr (FUSE) {
+                // fused ReLUNorm over the 4*C features (all >= 0; channels >= C have zero weights and contribute 0)
+                const int mxl = max(max(fo[0][0], fo[0][1]), nblk == 2u ? max(fo[1][0], fo[1][1]) : 0);
+                const int mx = wave_max_nonneg(mxl);
+                const uint32_t tt = (uint32_t)mx >> 7;
+                const int sh = tt ? 32 - __builtin_clz(tt) : 0;
+                const int rnd = (1 << sh) >> 1;
+#pragma unroll
+                for (uint32_t bb = 0; bb < 2; bb++) {
+                    const uint32_t c = c0 + 32u * bb + (uint32_t)j;
+                    const bool on = bb < nblk && c < C;
+                    pend_v[bb] = (uint16_t)((uint32_t)min((fo[bb][0] + rnd) >> sh, 127) | ((uint32_t)min((fo[bb][1] + rnd) >> sh, 127) << 8));
+                    pend_p[bb] = on ? (uint16_t *)(acts + img * (uint64_t)acts_stride + 4ull * c + 2u * (uint32_t)h) : nullptr;
+                }
+            }
+        }
+        asm volatile("" ::"v"(touch));      // end of the touch register's reservation
+    }
+    flush_pending();
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------------
+// Host-side weight table for cnn_front_mfma_kernel (layout above).  w1/w2/w3: int8 [C][9] as in the header; out:
+// 2 * C_pad * 20 ints with C_pad = C rounded up to 64 (surplus channels: zero weights).
+void bnm_cnn_weight_table(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int *out) {
+    const uint32_t C_pad = (C + 63u) / 64u * 64u;
+    for (uint32_t i = 0; i < 2u * C_pad * CNN_WTAB_DWORDS; i++) out[i] = 0;
+    for (uint32_t band = 0; band < 2; band++)
+        for (uint32_t c = 0; c < C; c++) {
+            int *e = out + ((size_t)band * C_pad + c) * CNN_WTAB_DWORDS;
+            if (band == 0) {
+                uint8_t bytes[16] = {0};
+                for (int dy = 0; dy < 3; dy++)
+                    for (int dx = 0; dx < 3; dx++) bytes[4 * dy + dx] = (uint8_t)w1[9u * c + 3 * dy + dx];
+                for (int d = 0; d < 4; d++)
+                    e[d] = (int)((uint32_t)bytes[4 * d] | ((uint32_t)bytes[4 * d + 1] << 8) | ((uint32_t)bytes[4 * d + 2] << 16) | ((uint32_t)bytes[4 * d + 3] << 24));
+            }
+            for (int dyp = 0; dyp < 3; dyp++) {
+                const int dy = band ? 2 - dyp : dyp;        // the lower band sees the image upside down
+                const int a0 = w2[9u * c + 3 * dy], a1 = w2[9u * c + 3 * dy + 1], a2 = w2[9u * c + 3 * dy + 2];
+                e[4 + 2 * dyp] = (int)(((uint32_t)a0 & 0xFFFFu) | ((uint32_t)a1 << 16));
+                e[5 + 2 * dyp] = (int)((uint32_t)a2 & 0xFFFFu);
+                for (int dx = 0; dx < 3; dx++) e[10 + 3 * dyp + dx] = (int)w3[9u * c + 3 * dy + dx];
+            }
+        }
+}
+
+// acts: int8 [n][acts_stride] (always produced).  feat: int32 [n][4C]; optional when C <= 64, REQUIRED scratch when
 // C > 64 (several channel groups: ReLUNorm then runs as its own kernel over the complete vector).
-hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, const int8_t *w2, const int8_t *w3,
+// wtab != nullptr: conv1 on the matrix cores (cnn_front_mfma_kernel, default); nullptr: the all-VALU kernel of round 1.
+hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, const int8_t *w2, const int8_t *w3, const int *wtab,
                           uint32_t C, uint32_t n_shift, int8_t *acts, uint32_t acts_stride, int32_t *feat, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (C == 0 || C > 256 || n_shift < 4 || n_shift > 31 || acts_stride < 4u * C || (acts_stride & 3u)) return hipErrorInvalidValue;
+    if (C == 0 || C > 256 || n_shift < 4 || n_shift > 15 || acts_stride < 4u * C || (acts_stride & 3u)) return hipErrorInvalidValue;
     uint64_t blocks = (n + 3) / 4;
-    uint64_t cap = (uint64_t)bnm_num_cus() * 4ull;
+    // persistent grid = what is resident: 3 workgroups of 4 waves per CU for the MFMA kernel (168 VGPRs), 4 for the VALU one
+    uint64_t cap = (uint64_t)bnm_num_cus() * (wtab ? 3ull : 4ull);
     if (blocks > cap) blocks = cap;
     dim3 g((unsigned)blocks), b(256);
+    const uint32_t C_pad = (C + 63u) / 64u * 64u;
+    // MFMA kernel: images [0, n-1) through the plain instantiation, the last one through the SAFE one (see the kernel)
+    const uint64_t n_main = n - 1;
+    const uint64_t tail_off = n_main * 256ull;
     if (C <= 64) {
-        cnn_front_kernel<true><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, 0, n_shift, acts, acts_stride, feat);
+        if (wtab) {
+            if (n_main) cnn_front_mfma_kernel<true, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, 0, n_shift, acts, acts_stride, feat);
+            cnn_front_mfma_kernel<true, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, C, 0, n_shift,
+                                                                  acts + n_main * (uint64_t)acts_stride, acts_stride,
+                                                                  feat ? feat + n_main * 4ull * C : nullptr);
+        } else {
+            cnn_front_kernel<true><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, 0, n_shift, acts, acts_stride, feat);
+        }
         return hipGetLastError();
     }
     if (!feat) return hipErrorInvalidValue;
     for (uint32_t c0 = 0; c0 < C; c0 += 64) {
-        cnn_front_kernel<false><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, c0, n_shift, acts, acts_stride, feat);
+        if (wtab) {
+            if (n_main) cnn_front_mfma_kernel<false, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, c0, n_shift, acts, acts_stride, feat);
+            cnn_front_mfma_kernel<false, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, C, c0, n_shift,
+                                                                   acts + n_main * (uint64_t)acts_stride, acts_stride, feat + n_main * 4ull * C);
+        } else {
+            cnn_front_kernel<false><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, c0, n_shift, acts, acts_stride, feat);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return bnmk_relunorm(feat, 4u * C, acts, acts_stride, nullptr, n, s);
 }
-

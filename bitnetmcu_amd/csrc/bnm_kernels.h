@@ -87,9 +87,13 @@ hipError_t bnmk_maxpool22(const int32_t *d_in, uint32_t xy, int32_t *d_out, hipS
 // images [n][256] int8 -> acts [n][4*C] int8 after the fused ReLUNorm (channel-major,
 // BitNetMCU_MNIST_dll.c:65,76,80); feat (optional) = the int32 values before ReLUNorm
 // acts_stride: bytes between consecutive images' act rows (>= 4*C; bytes past 4*C are left untouched)
+// d_wtab: the per-channel weight table of the conv1-on-MFMA kernel (bnm_cnn_weight_table, uploaded by the caller) — or
+// nullptr to run the all-VALU kernel of round 1 (kept for A/B measurements, bnm_ctx_set_cnn_variant)
 hipError_t bnmk_cnn_front(const int8_t *d_images, uint64_t n, const int8_t *d_w1, const int8_t *d_w2,
-                          const int8_t *d_w3, uint32_t C, uint32_t n_shift, int8_t *d_acts, uint32_t acts_stride,
-                          int32_t *d_feat, hipStream_t s);
+                          const int8_t *d_w3, const int *d_wtab, uint32_t C, uint32_t n_shift, int8_t *d_acts,
+                          uint32_t acts_stride, int32_t *d_feat, hipStream_t s);
+constexpr int BNM_CNN_WTAB_DWORDS = 20;      // per (band, channel); 2 bands x C rounded up to 64 channels
+void bnm_cnn_weight_table(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int *out);
 
 // ---- ternary ALU whole-model kernel (sign-accumulate, no MFMA) -------------------------------
 struct BnmTernArgs {

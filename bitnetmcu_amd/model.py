@@ -128,6 +128,13 @@ class Context:
     def set_tuning(self, variant=-1, grid_blocks=0):
         L.check(self._lib, self._lib.bnm_ctx_set_tuning(self._h, variant, grid_blocks), "bnm_ctx_set_tuning")
 
+    def set_cnn_variant(self, variant):
+        """1: conv1 on the matrix cores (default); 0: the all-VALU front end of round 1"""
+        L.check(self._lib, self._lib.bnm_ctx_set_cnn_variant(self._h, variant), "bnm_ctx_set_cnn_variant")
+
+    def set_host_tuning(self, mode=0, copy_threads=0, spin=True):
+        L.check(self._lib, self._lib.bnm_ctx_set_host_tuning(self._h, mode, copy_threads, 1 if spin else 0), "bnm_ctx_set_host_tuning")
+
     # ---- host-pointer API (numpy) -------------------------------------------------------------
     def infer(self, images, logits=False):
         """images: int8 array [n,256] (or [n,16,16]).  Returns class ids (uint32[n]) and, if asked,

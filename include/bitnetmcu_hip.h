@@ -144,9 +144,17 @@ BNM_API int bnm_ctx_get_variant(const bnm_ctx *c);
  * [n][num_classes] or NULL.  No host synchronisation is performed. */
 BNM_API int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls,
                              int32_t *d_logits, void *stream);
-/* Same with HOST pointers: stages through device memory in chunks, synchronises. */
+/* Same with HOST pointers; synchronous.  Up to 64 images: zero-copy (page-locked buffers the GPU addresses directly, one launch,
+ * results polled in place) — the path behind Inference().  Larger batches: two page-locked staging slots on two streams,
+ * host copy threads, H2D / compute / D2H of consecutive chunks overlapped. */
 BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls,
                            int32_t *logits);
+/* CNN front end: 1 (default) conv1 on the matrix cores, 0 the all-VALU kernel (kept for A/B measurements). */
+BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
+/* Tuning of the host-pointer path.  mode 0 (default): pipelined page-locked staging; 1: the HIP runtime's own pageable copies,
+ * chunk by chunk.  copy_threads: host threads of the staging copy (0 = default).  spin: poll the page-locked result words of the
+ * <= 64-image path (default 1) instead of waiting for the stream. */
+BNM_API int bnm_ctx_set_host_tuning(bnm_ctx *c, int mode, int copy_threads, int spin);
 /* Debug/parity tap: int8 activations after every ReLUNorm of the FC chain, concatenated per
  * image (host pointers, layer-wise path). */
 BNM_API int bnm_infer_host_activations(bnm_ctx *c, const int8_t *images, uint64_t n,

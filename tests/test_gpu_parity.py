@@ -142,6 +142,24 @@ def test_model_vs_oracle_synthetic(name, gpu_ok, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", [n for n in MODEL_NAMES if "cnn" in n])
+def test_cnn_front_end_both_kernels(name, gpu_ok, orc):
+    """conv1 on the matrix cores (default) and the all-VALU front end of round 1: ids, logits and the int8 features equal the
+    oracle's on synthetic images of both distributions, odd batch sizes and the extreme images."""
+    model = util.load_golden_model(name)
+    om = util.OracleModel(model, orc)
+    ctx = b.Context(model)
+    x = np.concatenate([synth.images(123, 1501, DIST_U), synth.images(9, 1502, DIST_M), np.zeros((2, 256), np.int8),
+                        np.full((2, 256), -128, np.int8), np.full((2, 256), 127, np.int8)])
+    want = om.infer(x, logits=True)
+    for variant in (1, 0):
+        ctx.set_cnn_variant(variant)
+        for n in (len(x), 1, 5):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (name, variant, n)
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", ["fc_4bitsym_64", "tern_96", "cnn_64"])
 def test_ragged_and_empty_batches(name, gpu_ok, orc):
     model = util.load_golden_model(name)
