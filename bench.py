@@ -105,7 +105,8 @@ def kernel_name(b, ctx, model):
     v = ctx.variant
     fused = {3: "fused_fc_dual_kernel", 4: "fused_fc_generic_kernel"}.get(v, "fused_fc_kernel")
     k = {1: fused, 2: "fc_layer_bitserial_kernel+relunorm_kernel", 3: "ternary_alu_kernel"}.get(ctx.path, "?")
-    return k + ("+cnn_front_kernel" if model.kind == b.KIND_CNN else "")
+    cnn = "cnn_front_mfma_kernel" if getattr(ctx, "cnn_variant", 1) else "cnn_front_kernel"
+    return k + ("+" + cnn if model.kind == b.KIND_CNN else "")
 
 
 def load_model_through_the_text_parser(b, util, name, header=None):
@@ -382,7 +383,7 @@ def extra_configs(a, np, torch, b, util, dev, images, cls, n, counters):
     res["ternary_mfma_generic"]["roofline"] = hbm(r, BYTES_PER_INFERENCE)
     # configs[3]: CNN 64-wide
     r = run("cnn_64", "cnn_64", n_cnn, 3, 1, note="BASELINE configs[3]")
-    res["cnn_64"]["roofline"] = valu(r, "cnn_front_kernel", BYTES_PER_INFERENCE)
+    res["cnn_64"]["roofline"] = valu(r, "cnn_front_mfma_kernel", BYTES_PER_INFERENCE)
     # headline model through the generic kernel (what any non-zoo 64-wide export would get)
     r = run("fc_generic_kernel", "fc_4bitsym_64", n, 5, 2, variant=4)
     res["fc_generic_kernel"]["roofline"] = hbm(r, BYTES_PER_INFERENCE)

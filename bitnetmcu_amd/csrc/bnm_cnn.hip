@@ -338,8 +338,8 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
         }
         return i32x4{va, vb, vc, vc};
     };
-    // what an item needs before its first MFMA: its block's 20 weight dwords and its first A tile.  Fetched one item AHEAD
-    // (while the previous item runs its stage 3) so that neither load latency is exposed.
+    // what an item needs before its first MFMA: its block's 20 weight dwords and its first A tile.  (Fetching them one item
+    // ahead was tried: hipcc waits for loop-carried loads on the back edge, and the extra live registers cost the third wave.)
     struct Head {
         i32x4 q0, q1, q2, q3, q4, a0;
     };
@@ -352,20 +352,23 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
         hd.a0 = load_A(images + im * 256ull, o1[0]);
         return hd;
     };
-    Head cur{};
-    if (items) cur = fetch(0);
     int touch = 0;
     int fo[2][2] = {{0, 0}, {0, 0}};          // the lane's pooled outputs: [block][t & 1], t = 2h + (t & 1)
     // The act bytes of an image are stored at the START of the next item, not at the end of their own: vmcnt counts stores,
     // and the wait hipcc places on the loop's back edge would otherwise park the wave for the write acknowledgement of a
     // store it has just issued (measured: as long as the whole arithmetic of an image).  Deferred, whatever that wait
     // covers is thousands of cycles old.
-    uint16_t *pend_p[2] = {nullptr, nullptr};
-    uint16_t pend_v[2] = {0, 0};
+    const int8_t *pend_row = acts;            // wave-uniform: the pending image's act row
+    uint32_t pend_v = 0;                      // block 0's two bytes | block 1's two bytes << 16
+    bool pend = false;
     auto flush_pending = [&]() {
+        if (!pend) return;
 #pragma unroll
-        for (int bb = 0; bb < 2; bb++)
-            if (pend_p[bb]) { *pend_p[bb] = pend_v[bb]; pend_p[bb] = nullptr; }
+        for (uint32_t bb = 0; bb < 2; bb++) {
+            const uint32_t c = c0 + 32u * bb + (uint32_t)j;
+            if (bb < nblk && c < C) *(uint16_t *)(const_cast<int8_t *>(pend_row) + 4u * c + 2u * (uint32_t)h) = (uint16_t)(pend_v >> (16 * bb));
+        }
+        pend = false;
     };
     for (uint64_t k = 0; k < items; k++) {
         const uint64_t img = wave0 + (k >> blk_shift) * nwaves;
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
             const int8_t *np = ip + nwaves * 256ull;
             asm volatile("global_load_dword %0, %1, %2" : "=v"(touch) : "v"(lane * 4), "s"(np) : "memory");
         }
+        const Head cur = fetch(k);
         const i32x4 wB = cur.q0, wq1 = cur.q1, wq2 = cur.q2, wq3 = cur.q3, wq4 = cur.q4;
         const int w01[3] = {wq1[0], wq1[2], wq2[0]}, w2z[3] = {wq1[1], wq1[3], wq2[1]};
         const int k3[9] = {wq2[2], wq2[3], wq3[0], wq3[1], wq3[2], wq3[3], wq4[0], wq4[1], wq4[2]};
@@ -392,6 +396,9 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0;
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Anext, wB, acc, 0, 0, 0);
+            // (a scheduling fence per tile: left alone hipcc hoists all seven tiles' patch loads to the top of the item, 18 live
+            // registers that push the kernel over the 168 of three waves per SIMD)
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (t < 6) Anext = load_A(ip, o1[t + 1]);
             // (the previous image's act bytes go out here, BEHIND all of this item's patch loads in program order: no wait
             // for a patch load covers them, and the back-edge wait finds them ~500 VALU instructions old)
@@ -434,9 +441,6 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
                 }
             });
         });
-        // the next item's weights and first tile: in flight during this item's stage 3 (after the last item: the same item
-        // again — a conditional fetch would make hipcc wait for the loads at the merge point)
-        const Head nxt = fetch(k + 1 < items ? k + 1 : k);
         // ---- stage 3 on band-local rows: conv3 row a complete, row b misses kernel row 2 over the PARTNER's pooled
         // row 2, which the partner computes (its `send`) while this lane computes the partner's missing term -------------
         int oa3[4], ob3[4], snd[4];
@@ -462,7 +466,6 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
             fo[0][x] = blk == 0 ? v : fo[0][x];
             fo[1][x] = blk == 1 ? v : fo[1][x];
         }
-        cur = nxt;
         if (blk + 1 == nblk) {
             // ---- outputs: lane (j, h), block b: channel c0 + 32 b + j, values t = 2h, 2h + 1 ---------------------------------
             if (feat) {
@@ -483,13 +486,12 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
                 const uint32_t tt = (uint32_t)mx >> 7;
                 const int sh = tt ? 32 - __builtin_clz(tt) : 0;
                 const int rnd = (1 << sh) >> 1;
+                pend_v = 0;
 #pragma unroll
-                for (uint32_t bb = 0; bb < 2; bb++) {
-                    const uint32_t c = c0 + 32u * bb + (uint32_t)j;
-                    const bool on = bb < nblk && c < C;
-                    pend_v[bb] = (uint16_t)((uint32_t)min((fo[bb][0] + rnd) >> sh, 127) | ((uint32_t)min((fo[bb][1] + rnd) >> sh, 127) << 8));
-                    pend_p[bb] = on ? (uint16_t *)(acts + img * (uint64_t)acts_stride + 4ull * c + 2u * (uint32_t)h) : nullptr;
-                }
+                for (uint32_t bb = 0; bb < 2; bb++)
+                    pend_v |= ((uint32_t)min((fo[bb][0] + rnd) >> sh, 127) | ((uint32_t)min((fo[bb][1] + rnd) >> sh, 127) << 8)) << (16 * bb);
+                pend_row = acts + img * (uint64_t)acts_stride;
+                pend = true;
             }
         }
         asm volatile("" ::"v"(touch));      // end of the touch register's reservation

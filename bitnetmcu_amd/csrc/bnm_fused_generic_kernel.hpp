@@ -122,15 +122,6 @@ BNM_DEVICE void block_mma(const char *smem, uint32_t lane16, uint32_t off, const
     mma_stream<MT, KT, KT, SP, true, NB>(smem + (off + lane16), b, acc);
 }
 
-template <int MMAX, int MT>
-BNM_DEVICE void pack_out(const i32x4 (&p)[MT], i32x4 (&out)[MMAX]) {
-#pragma unroll
-    for (int m = 0; m < MMAX; m++) {
-        if (m < MT) out[m] = p[m];
-        else out[m] = i32x4{0, 0, 0, 0};
-    }
-}
-
 // K-step count a layer's fragments are padded to, given the previous layer's tile count
 template <int MMAX>
 constexpr int kpad(int m_prev) { return MMAX == 2 ? 2 : (m_prev <= MMAX / 2 ? MMAX / 2 : MMAX); }
@@ -147,9 +138,9 @@ BNM_DEVICE void hidden_layer(const char *smem, uint32_t lane16, uint32_t off, ui
             if (M == (uint32_t)mt && KTP == (uint32_t)kt) {
                 i32x16 acc[mt];
                 block_mma<mt, kt, SP, MMAX>(smem, lane16, off, in, acc);
-                i32x4 p[mt];
-                relunorm_pack<mt, DBL>(acc, p, h);
-                pack_out<MMAX, mt>(p, out);
+                relunorm_pack<mt, DBL, MMAX>(acc, out, h);
+#pragma unroll
+                for (int m = mt; m < MMAX; m++) out[m] = i32x4{0, 0, 0, 0};     // K-steps past the real tiles: zero weights meet zeros
             }
         });
     });
@@ -251,7 +242,7 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         const int j = (int)(lv & 31u), h = (int)(lv >> 5);
         const uint32_t lane16 = 16u * lv;
         const uint32_t rd_off = tile_off + (uint32_t)j * (uint32_t)ROW + 16u * ((uint32_t)h ^ G::mask((uint32_t)j));
-        i32x4 pa[MMAX], pb[MMAX];
+        i32x4 pa[MMAX], pb[MMAX];       // packed layer outputs = the next layer's B operands
         // ---- layer 1: B operands from the tile buffer, KC K-steps at a time; the buffer is refilled with the wave's
         // next tile as soon as its last operand has been read (the load is then in flight for the rest of the tile)
         static_for<1, MMAX / MSTEP + 1>([&](auto MI) {
@@ -269,9 +260,9 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
                     }
                     mma_stream<mt, KC, KT0, SP, ch == 0, KC>(smem + (d.frag_off[0] + (uint32_t)(ch * KC * 1024) + lane16), b0, acc);
                 });
-                i32x4 p[mt];
-                relunorm_pack<mt, DBL>(acc, p, h);
-                pack_out<MMAX, mt>(p, pa);
+                relunorm_pack<mt, DBL, MMAX>(acc, pa, h);
+#pragma unroll
+                for (int m = mt; m < MMAX; m++) pa[m] = i32x4{0, 0, 0, 0};
             }
         });
         hidden_layer<MMAX, SP, DBL>(smem, lane16, d.frag_off[1], M2, K2, pa, pb, h);

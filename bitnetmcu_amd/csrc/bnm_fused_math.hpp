@@ -55,8 +55,9 @@ BNM_DEVICE i32x4 sdwa_shift_pack16(const int (&c)[16], int s) {
 //   (0..254, one v_med3 + one SDWA shift that also packs), the rounded result is
 //   (x + 2^(s-1)) >> s = (2x + 2^s) >> (s+1) = (y + 1) >> 1, which v_lerp_u8 computes for 4 bytes at once;
 //   y <= 254 makes the "clip 128 to 127" case (:62-66) fall out.  2.25 VALU per value, bit-exact.
-template <int MT, bool DBL>
-BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[MT], int h) {
+template <int MT, bool DBL, int NP = MT>
+BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[NP], int h) {
+    static_assert(NP >= MT, "output array too short");
     int mx = acc[0][0];
 #pragma unroll
     for (int m = 0; m < MT; m++)

@@ -95,6 +95,7 @@ class Context:
         h = C.c_void_p()
         L.check(self._lib, self._lib.bnm_ctx_create(model._h, device, C.byref(h)), "bnm_ctx_create")
         self._h = h
+        self.cnn_variant = 1
         # diagnostic library only (BNM_LIBRARY=.../libbitnetmcu_hip_diag.so, build.py --diag): cache-resident source for
         # compute-side timing.  The product library does not export the symbol and ignores the variable.
         import os
@@ -131,6 +132,7 @@ class Context:
     def set_cnn_variant(self, variant):
         """1: conv1 on the matrix cores (default); 0: the all-VALU front end of round 1"""
         L.check(self._lib, self._lib.bnm_ctx_set_cnn_variant(self._h, variant), "bnm_ctx_set_cnn_variant")
+        self.cnn_variant = variant
 
     def set_host_tuning(self, mode=0, copy_threads=0, spin=True):
         L.check(self._lib, self._lib.bnm_ctx_set_host_tuning(self._h, mode, copy_threads, 1 if spin else 0), "bnm_ctx_set_host_tuning")

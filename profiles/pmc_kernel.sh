@@ -19,4 +19,4 @@ if [ "${PMC_TRAFFIC:-0}" = "1" ]; then
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$OUT/write" -o pmc -- $B > "$OUT/write.log" 2>&1
 fi
 cd "$REPO"
-python profiles/pmc_table.py "$OUT"
+python profiles/pmc_table.py "$OUT" --json "$OUT/table.json"

@@ -258,8 +258,13 @@ def test_bench_json_contract(gpu_ok):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "i8" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["verified_vs_oracle"] is True and "workload" in d["config"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "frac_of_measured_ceiling", "mfma_busy_frac"):
         assert k in d["roofline"]
+    assert d["digest"].startswith("0x") and "header text" in d["config"]["model_source"]
+    ex = d["extra_configs"]
+    for k in ("ternary_alu", "ternary_mfma_generic", "cnn_64", "fc_generic_kernel", "fc_logits", "fc_dist_m"):
+        assert ex[k]["verified_vs_oracle"] is True and ex[k]["value"] > 0 and "roofline" in ex[k], k
+    assert ex["ternary_alu"]["roofline"]["bound"] == "valu" and ex["cnn_64"]["roofline"]["bound"] == "valu"
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"]
 
@@ -458,11 +463,13 @@ def test_bench_under_torchrun_single_rank(gpu_ok):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(util.REPO, "bench.py"), "--gpus", "1", "--steps", "2",
-                          "--warmup", "1", "--images", "1000000", "--no-cpu"], capture_output=True, text=True, timeout=900, env=env)
+                          "--warmup", "1", "--images", "1000000", "--no-cpu", "--scaling", "strong"], capture_output=True, text=True,
+                         timeout=900, env=env)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert lines, out.stderr[-2000:]
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 1 and d["verified_vs_oracle"] is True and sum(d["class_histogram"]) == 1000000
+    assert d["scaling"] == "strong" and d["config"]["global_images"] == 1000000 and "extra_configs" in d
 
 
 def test_c_abi_multi_gpu_entry_point(gpu_ok, bnm, orc):
