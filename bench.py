@@ -104,7 +104,8 @@ def load_counters():
 def kernel_name(b, ctx, model):
     v = ctx.variant
     fused = {3: "fused_fc_dual_kernel", 4: "fused_fc_generic_kernel"}.get(v, "fused_fc_kernel")
-    k = {1: fused, 2: "fc_layer_bitserial_kernel+relunorm_kernel", 3: "ternary_alu_kernel"}.get(ctx.path, "?")
+    tern = "ternary_stream_kernel" if getattr(ctx, "ternary_variant", 2) else "ternary_alu_kernel"
+    k = {1: fused, 2: "fc_layer_bitserial_kernel+relunorm_kernel", 3: tern}.get(ctx.path, "?")
     cnn = "cnn_front_mfma_kernel" if getattr(ctx, "cnn_variant", 1) else "cnn_front_kernel"
     return k + ("+" + cnn if model.kind == b.KIND_CNN else "")
 
@@ -174,6 +175,8 @@ def main():
     ap.add_argument("--grid", type=int, default=0, help="workgroups (0 = default)")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 fused MFMA, 2 layer-wise ALU, 3 ternary ALU")
     ap.add_argument("--cnn-variant", type=int, default=-1, help="CNN front end: 1 conv1 on MFMA (default), 0 all-VALU kernel of round 1")
+    ap.add_argument("--ternary-variant", type=int, default=-1,
+                    help="ternary ALU kernel: 2 streamed weights, two images per lane (default), 1 one image per lane, 0 round 1's kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -222,6 +225,8 @@ def main():
         ctx.set_tuning(a.variant, a.grid)
     if a.cnn_variant >= 0:
         ctx.set_cnn_variant(a.cnn_variant)
+    if a.ternary_variant >= 0:
+        ctx.set_ternary_variant(a.ternary_variant)
 
     # ---- resident workload: this rank's shard of the global synthetic image stream --------------------
     if a.scaling == "weak":
@@ -377,7 +382,7 @@ def extra_configs(a, np, torch, b, util, dev, images, cls, n, counters):
     n_cnn = min(n, 10_000_000)
     # configs[2]: ternary 96-96-96, bit-unpack / sign-accumulate ALU kernel, no MFMA — bound by the VALU issue rate
     r = run("ternary_alu", "tern_96", n, 3, 1, path=b.PATH_TERNARY_ALU, note="BASELINE configs[2]")
-    res["ternary_alu"]["roofline"] = valu(r, "ternary_alu_kernel", BYTES_PER_INFERENCE)
+    res["ternary_alu"]["roofline"] = valu(r, "ternary_stream_kernel", BYTES_PER_INFERENCE)
     # the same model through the generic MFMA kernel (option; no spills since round 2)
     r = run("ternary_mfma_generic", "tern_96", n, 5, 1, path=b.PATH_FUSED_MFMA)
     res["ternary_mfma_generic"]["roofline"] = hbm(r, BYTES_PER_INFERENCE)

@@ -171,6 +171,8 @@ struct bnm_ctx {
     int variant = -1, grid_blocks = 0;
     // ternary ALU path
     bool tern_ok = false;
+    int *tern_stream = nullptr;   // the trits in the streamed kernel's consumption order (bnmk_ternary_stream_build)
+    int tern_variant = 2;         // 2: streamed weights, two images per lane (default); 1: one image per lane; 0: round 1's kernel
     int requested_path = BNM_PATH_AUTO, path = BNM_PATH_LAYERWISE_ALU;
     bool warned_layerwise = false;
     std::string fused_reason = "unknown";   // why fused_ok is false
@@ -381,8 +383,19 @@ int ctx_build(bnm_ctx *c) {
     }
     // ---- ternary ALU path ------------------------------------------------------------------------------
     if (m.kind == BNM_KIND_FC && all_tern && nfc == 4 && c->fc[0].n_real == 256 && c->fc[0].info.n_output == 96 &&
-        c->fc[1].info.n_output == 96 && c->fc[2].info.n_output == 96 && c->fc[3].info.n_output <= 64)
+        c->fc[1].info.n_output == 96 && c->fc[2].info.n_output == 96 && c->fc[3].info.n_output <= 64) {
+        BnmTernArgs a{};
+        for (int i = 0; i < 4; i++) {
+            a.rows[i] = c->fc[i].rows_lo;
+            a.stride[i] = c->fc[i].row_stride;
+            a.n_out[i] = c->fc[i].info.n_output;
+        }
+        void *p = nullptr;
+        if (int e = dev_alloc(c, &p, (size_t)bnmk_ternary_stream_dwords(a.n_out) * 4u)) return e;
+        c->tern_stream = (int *)p;
+        HIP_TRY(bnmk_ternary_stream_build(a, c->tern_stream, s));
         c->tern_ok = true;
+    }
     HIP_TRY(hipDeviceSynchronize());
     return resolve_path(c);
 }
@@ -447,6 +460,8 @@ int run_ternary(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int
     }
     a.cls = d_cls;
     a.logits = d_logits;
+    a.wstream = c->tern_stream;
+    a.variant = c->tern_variant;
     HIP_TRY(bnmk_ternary_alu(a, c->grid_blocks, s));
     return BNM_OK;
 }
@@ -635,6 +650,13 @@ int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
     if (!c || variant < 0 || variant > 1) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     c->cnn_variant = variant;
+    return BNM_OK;
+}
+
+int bnm_ctx_set_ternary_variant(bnm_ctx *c, int variant) {
+    if (!c || variant < 0 || variant > 2) return fail(BNM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->tern_variant = variant;
     return BNM_OK;
 }
 

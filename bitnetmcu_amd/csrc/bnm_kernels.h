@@ -106,7 +106,11 @@ struct BnmTernArgs {
     uint32_t n_layers;
     uint32_t *cls;
     int32_t *logits;
+    const int *wstream;     // bnmk_ternary_stream_build's output (variants 1, 2)
+    int variant;            // 0: round 1's kernel; 1: streamed weights, one image per lane; 2: two images per lane
 };
+uint32_t bnmk_ternary_stream_dwords(const uint32_t n_out[4]);
+hipError_t bnmk_ternary_stream_build(const BnmTernArgs &a, int *d_stream, hipStream_t s);
 hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s);
 
 // ---- diagnostics (bnm_diag.hip, diagnostic library only): cost of the image stream alone, pipe overlap ----

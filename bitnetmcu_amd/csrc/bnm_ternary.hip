@@ -100,17 +100,336 @@ __global__ __launch_bounds__(64) void ternary_alu_kernel(const int8_t *__restric
     }
 }
 
+// =================================================================================================
+// Round 2: the streamed kernel.  Round 1's kernel (above) left the VALU 70 % busy: hipcc waits for every batch of
+// scalar weight loads right after issuing it (s_waitcnt lgkmcnt(0) ahead of the first use), and the 44 KB of trit rows
+// cycle through a 16 KB scalar cache, so each batch is an L2 round trip a wave sits out (SQ_WAIT_ANY 0.40 of wave time).
+// Here
+//  * the model's trits are laid out once per model as ONE linear stream of 128-byte chunks in exactly the order the
+//    kernel consumes them (tern_stream_kernel): chunk = 4 neurons x 8 activation dwords = 32 SGPRs = 2 cache lines;
+//  * the loads are inline asm hipcc neither counts nor waits for (guide 5.7): chunk i+1 is issued into the second SGPR
+//    buffer, chunk i is consumed (32 x G v_dot4), then ONE s_waitcnt lgkmcnt(0) retires chunk i+1 (scalar loads return
+//    out of order, so only "all" can be waited for) - a chunk's latency hides under the previous chunk's dots;
+//  * a lane carries G images (G = 2 by default: 128 image VGPRs), so every weight dword feeds G dots: half the scalar
+//    traffic per image and twice the VALU work behind each load;
+//  * the next images are requested right after layer 1 (their registers are dead from there on) and land under layers 2-4;
+//  * layer sums are parked as SATURATED int16 pairs (v_cvt_pk_i16_i32; the only sum that saturates is +32768, which
+//    forces shift 9 and rounds to 64 either way) and ReLU / rounding add / shift / clip run on packed 16-bit pairs:
+//    3.25 VALU per hidden value instead of 6.5.  With G = 2 a wave's LDS share (20 KiB at 2 waves per SIMD) holds 80 of
+//    a layer's 96 sums per image; the last 16 stay in registers (those neuron quads are peeled, all indices constant).
+// =================================================================================================
+typedef int sx16 __attribute__((ext_vector_type(16)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+struct TernW {
+    sx16 lo, hi;   // one chunk: dword d = 8 * neuron-in-quad + activation dword in the K-slice
+};
+// issue (not wait for) the two cache lines of the chunk at p + 128 * OFF bytes
+template <int OFF>
+BNM_DEVICE void tern_issue(TernW &w, const int *p) {
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"
+                 : "=&s"(w.lo), "=&s"(w.hi)
+                 : "s"(p), "i"(OFF * 128), "i"(OFF * 128 + 64));
+}
+BNM_DEVICE void tern_land(TernW &w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.lo), "+s"(w.hi)); }
+// the same, also naming the running sums: pins the chunk's dots between the issue and this wait (left free, hipcc sinks
+// a class quad's dots into the `class < n_classes` blocks behind all the waits and keeps every chunk live)
+template <int G>
+BNM_DEVICE void tern_land(TernW &w, int (&acc)[4][G]) {
+    if constexpr (G == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.lo), "+s"(w.hi), "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+s"(w.lo), "+s"(w.hi), "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]),
+                       "+v"(acc[0][1]), "+v"(acc[1][1]), "+v"(acc[2][1]), "+v"(acc[3][1]));
+}
+
+template <int D>
+BNM_DEVICE int tern_wd(const TernW &w) {
+    if constexpr (D < 16) return w.lo[D]; else return w.hi[D - 16];
+}
+
+// 32 x G dots of one chunk: neuron i of the quad, activation dwords X0 .. X0+7
+template <int G, int NX, int X0>
+BNM_DEVICE void tern_chunk(const int (&x)[G][NX], const TernW &w, int (&acc)[4][G]) {
+    static_for<0, 8>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+#pragma unroll
+            for (int g = 0; g < G; g++) acc[i][g] = __builtin_amdgcn_sdot4(x[g][X0 + j], tern_wd<8 * i + j>(w), acc[i][g], false);
+        });
+    });
+}
+
+// One neuron quad over KQ activation dwords = KQ/8 chunks.  On entry `a` holds the quad's first chunk (landed); on exit
+// the buffer named by the return parity holds the NEXT chunk of the stream (landed): chunks alternate a, b, a, ...
+// `p` points at the quad's first chunk; the chunk after the quad's last one is simply the next one in the stream.
+template <int G, int NX, int KQ, bool AFIRST>
+BNM_DEVICE void tern_quad(const int (&x)[G][NX], TernW &a, TernW &b, const int *p, int (&acc)[4][G]) {
+    constexpr int NC = KQ / 8;
+    static_for<0, NC>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        constexpr bool cur_a = ((c & 1) == 0) == AFIRST;
+        TernW &cur = cur_a ? a : b;
+        TernW &nxt = cur_a ? b : a;
+        tern_issue<c + 1>(nxt, p);
+        __builtin_amdgcn_sched_barrier(0);
+        tern_chunk<G, NX, 8 * c>(x, cur, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        tern_land<G>(nxt, acc);
+    });
+}
+
+// park one quad's sums of group g: saturated int16 pairs; running maximum from the 32-bit sums
+BNM_DEVICE void tern_pairs(const int (&s)[4], int &mx, uint32_t &p01, uint32_t &p23) {
+    s16x2 a = __builtin_amdgcn_cvt_pk_i16(s[0], s[1]), b = __builtin_amdgcn_cvt_pk_i16(s[2], s[3]);
+    p01 = __builtin_bit_cast(uint32_t, a);
+    p23 = __builtin_bit_cast(uint32_t, b);
+    mx = max(mx, max(s[0], s[1]));
+    mx = max(mx, max(s[2], s[3]));
+}
+
+// ReLUNorm (BitNetMCU_inference.c:23-72) of four parked sums -> four packed int8 activations
+BNM_DEVICE int tern_norm4(uint32_t p01, uint32_t p23, uint32_t rnd2, uint32_t sh2) {
+    const s16x2 z = {0, 0};
+    const u16x2 c127 = {127, 127};
+    s16x2 a = __builtin_bit_cast(s16x2, p01), b = __builtin_bit_cast(s16x2, p23);
+    a = __builtin_elementwise_max(a, z);
+    b = __builtin_elementwise_max(b, z);
+    u16x2 ua = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, rnd2);
+    u16x2 ub = __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, rnd2);
+    ua = ua >> __builtin_bit_cast(u16x2, sh2);
+    ub = ub >> __builtin_bit_cast(u16x2, sh2);
+    ua = __builtin_elementwise_min(ua, c127);
+    ub = __builtin_elementwise_min(ub, c127);
+    // bytes: [n0, n1, n2, n3] = low bytes of the four halves
+    return (int)__builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, ub), __builtin_bit_cast(uint32_t, ua), 0x06040200u);
+}
+
+template <int G, int H, int QL>
+BNM_DEVICE void tern_norm(const uint32_t *col, const uint32_t (&tail)[G][(H / 4 - QL) * 2 + 1], const int (&mx)[G],
+                          int (&act)[G][H / 4]) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        uint32_t t = (uint32_t)mx[g] >> 7;                    // mx >= 0
+        uint32_t sh = t ? 32u - (uint32_t)__builtin_clz(t) : 0u;
+        uint32_t rnd = (1u << sh) >> 1;
+        uint32_t rnd2 = rnd | (rnd << 16), sh2 = sh | (sh << 16);
+        static_for<0, H / 4>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            uint32_t p01, p23;
+            if constexpr (q < QL) {
+                p01 = col[((g * QL + q) * 2 + 0) * 64];
+                p23 = col[((g * QL + q) * 2 + 1) * 64];
+            } else {
+                p01 = tail[g][(q - QL) * 2 + 0];
+                p23 = tail[g][(q - QL) * 2 + 1];
+            }
+            act[g][q] = tern_norm4(p01, p23, rnd2, sh2);
+        });
+    }
+}
+
+// One hidden layer: H neurons over KQ activation dwords.  Quads [0, QL) are a run-time loop whose sums go to the LDS
+// column, quads [QL, H/4) are peeled and keep theirs in registers.  `a` holds the layer's first chunk on entry and the
+// next layer's first chunk on exit (every layer here has an even number of chunks per loop step).
+template <int G, int NX, int KQ, int H, int QL>
+BNM_DEVICE void tern_layer_s(const int (&x)[G][NX], TernW &a, TernW &b, const int *&p, uint32_t *col,
+                             uint32_t (&tail)[G][(H / 4 - QL) * 2 + 1], int (&mx)[G]) {
+    constexpr int NC = KQ / 8;                 // chunks per quad
+    constexpr int STEP = (NC & 1) ? 2 : 1;     // quads per loop step: an even number of chunks
+    static_assert(QL % STEP == 0 && (H / 4 - QL) % STEP == 0, "quad split must keep the buffer parity");
+#pragma unroll
+    for (int g = 0; g < G; g++) mx[g] = 0;
+    auto step = [&](auto park) {
+        static_for<0, STEP>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            int acc[4][G];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[i][g] = 0;
+            if constexpr ((s * NC) % 2 == 0) tern_quad<G, NX, KQ, true>(x, a, b, p + s * NC * 32, acc);
+            else tern_quad<G, NX, KQ, false>(x, a, b, p + s * NC * 32, acc);
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                int sums[4] = {acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
+                uint32_t p01, p23;
+                tern_pairs(sums, mx[g], p01, p23);
+                park(S, g, p01, p23);
+            }
+        });
+        p += STEP * NC * 32;
+    };
+#pragma unroll 1
+    for (int q = 0; q < QL; q += STEP)
+        step([&](auto S, int g, uint32_t p01, uint32_t p23) {
+            constexpr int s = decltype(S)::value;
+            col[((g * QL + q + s) * 2 + 0) * 64] = p01;
+            col[((g * QL + q + s) * 2 + 1) * 64] = p23;
+        });
+    static_for<0, (H / 4 - QL) / STEP>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        step([&](auto S, int g, uint32_t p01, uint32_t p23) {
+            constexpr int s = decltype(S)::value;
+            tail[g][(t * STEP + s) * 2 + 0] = p01;
+            tail[g][(t * STEP + s) * 2 + 1] = p23;
+        });
+    });
+}
+
+template <int G, int H1, int H2, int H3, int QL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 1 ? 3 : 2, G == 1 ? 3 : 2)))
+void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const int *__restrict__ wstream,
+                           uint32_t n_classes, uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out) {
+    static_assert(H1 == H2 && H2 == H3, "one LDS column geometry for all hidden layers");
+    __shared__ uint32_t s_col[G * QL * 2 * 64];
+    const int lane = threadIdx.x;
+    uint32_t *col = s_col + lane;
+    const uint64_t stride = (uint64_t)gridDim.x * (64ull * G);
+    uint64_t base = (uint64_t)blockIdx.x * (64ull * G);
+    if (base >= n) return;
+
+    int x0[G][64];
+    auto request = [&](uint64_t b) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            uint64_t img = b + (uint64_t)(g * 64 + lane);
+            img = img < n ? img : n - 1ull;
+            const i32x4 *ptr = (const i32x4 *)(images + img * 256ull);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                i32x4 v = __builtin_nontemporal_load(ptr + q);
+                x0[g][4 * q + 0] = v[0]; x0[g][4 * q + 1] = v[1]; x0[g][4 * q + 2] = v[2]; x0[g][4 * q + 3] = v[3];
+            }
+        }
+    };
+    request(base);
+    TernW wa, wb;
+    tern_issue<0>(wa, wstream);
+    tern_land(wa);
+    const uint32_t nq4 = (n_classes + 3u) / 4u;
+    for (; base < n; base += stride) {
+        const int *p = wstream;
+        uint32_t tail[G][(H1 / 4 - QL) * 2 + 1];
+        int mx[G];
+        int a1[G][H1 / 4], a2[G][H2 / 4], a3[G][H3 / 4];
+        tern_layer_s<G, 64, 64, H1, QL>(x0, wa, wb, p, col, tail, mx);
+        if (base + stride < n) request(base + stride);      // lands under layers 2-4
+        tern_norm<G, H1, QL>(col, tail, mx, a1);
+        tern_layer_s<G, H1 / 4, H1 / 4, H2, QL>(a1, wa, wb, p, col, tail, mx);
+        tern_norm<G, H2, QL>(col, tail, mx, a2);
+        tern_layer_s<G, H2 / 4, H2 / 4, H3, QL>(a2, wa, wb, p, col, tail, mx);
+        tern_norm<G, H3, QL>(col, tail, mx, a3);
+        // classifier layer (first strict maximum = ReLUNorm's return value): quads of classes, 3 chunks each; the stream
+        // wraps to its first chunk after the last class quad, so `wa` is ready for the next images
+        int bv[G];
+        uint32_t bi[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) { bv[g] = -INT_MAX; bi[g] = 255u; }
+        auto classes = [&](auto AF, uint32_t q, const int *pq) {
+            constexpr bool af = decltype(AF)::value;
+            int acc[4][G];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[i][g] = 0;
+            tern_quad<G, H3 / 4, H3 / 4, af>(a3, wa, wb, pq, acc);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t c = 4u * q + (uint32_t)i;
+                if (c < n_classes) {
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        if (acc[i][g] > bv[g]) { bv[g] = acc[i][g]; bi[g] = c; }
+                        const uint64_t img = base + (uint64_t)(g * 64 + lane);
+                        if (logits_out && img < n) logits_out[img * n_classes + c] = acc[i][g];
+                    }
+                }
+            }
+        };
+        constexpr int NC3 = H3 / 32;   // chunks per class quad
+        static_assert(NC3 % 2 == 1, "the class loop below alternates the buffers per quad");
+        // the stream ends with a copy of its first chunk, so the prefetch after the last class quad leaves the next
+        // images' first chunk landed - in wb after an odd number of quads (copied over: both buffers have landed)
+        for (uint32_t q = 0; q < nq4; q += 2u) {
+            classes(std::true_type{}, q, p);
+            p += NC3 * 32;
+            if (q + 1u < nq4) {
+                classes(std::false_type{}, q + 1u, p);
+                p += NC3 * 32;
+            } else {
+                wa = wb;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const uint64_t img = base + (uint64_t)(g * 64 + lane);
+            if (img < n) cls_out[img] = bi[g];
+        }
+    }
+}
+
+// ---- weight stream of the streamed kernel -----------------------------------------------------------------------
+// per layer: for each quad of neurons, for each slice of 8 activation dwords: [4 neurons][8 dwords]; after the last layer
+// one more chunk = a copy of the first (the prefetch that follows the last class quad).  Rows past n_out are zero.
+__global__ void tern_stream_kernel(const int8_t *__restrict__ rows, uint32_t stride, uint32_t n_out, uint32_t kq,
+                                   uint32_t n_quads, int *__restrict__ out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nc = kq / 8u;
+    if (idx >= n_quads * nc * 32u) return;
+    const uint32_t chunk = idx / 32u, d = idx % 32u;
+    const uint32_t neuron = 4u * (chunk / nc) + d / 8u, k = 8u * (chunk % nc) + d % 8u;
+    out[idx] = neuron < n_out ? ((const int *)(rows + (size_t)neuron * stride))[k] : 0;
+}
+
+uint32_t bnmk_ternary_stream_dwords(const uint32_t n_out[4]) {
+    uint32_t dw = 0, kq = 64;
+    for (int i = 0; i < 4; i++) {
+        dw += ((n_out[i] + 3u) / 4u) * (kq / 8u) * 32u;
+        kq = n_out[i] / 4u;
+    }
+    return dw + 32u;
+}
+
+hipError_t bnmk_ternary_stream_build(const BnmTernArgs &a, int *d_stream, hipStream_t s) {
+    uint32_t off = 0, kq = 64;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t nq = (a.n_out[i] + 3u) / 4u, dw = nq * (kq / 8u) * 32u;
+        tern_stream_kernel<<<dim3((dw + 255u) / 256u), dim3(256), 0, s>>>(a.rows[i], a.stride[i], a.n_out[i], kq, nq,
+                                                                        d_stream + off);
+        off += dw;
+        kq = a.n_out[i] / 4u;
+    }
+    hipError_t e = hipMemcpyAsync(d_stream + off, d_stream, 128, hipMemcpyDeviceToDevice, s);
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
 hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s) {
     if (!a.n) return hipSuccess;
     if (a.n_layers != 4 || a.n_in[0] != 256 || a.n_out[0] != 96 || a.n_out[1] != 96 || a.n_out[2] != 96 ||
         a.n_in[1] != 96 || a.n_in[2] != 96 || a.n_in[3] != 96)
         return hipErrorInvalidValue;
-    uint64_t want = (a.n + 63ull) / 64ull;
-    uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * 12ull;
-    unsigned blocks = (unsigned)(want < cap ? want : cap);
-    ternary_alu_kernel<96, 96, 96><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.rows[0], a.rows[1], a.rows[2],
-                                                                       a.rows[3], a.stride[0], a.stride[1], a.stride[2],
-                                                                       a.stride[3], a.n_out[3], a.cls, a.logits);
+    const int G = a.variant == 2 ? 2 : 1;
+    const uint64_t per = 64ull * (uint64_t)G;
+    const uint64_t want = (a.n + per - 1ull) / per;
+    const uint64_t wpc = a.variant == 2 ? 8ull : 12ull;   // resident waves per CU
+    const uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * wpc;
+    const unsigned blocks = (unsigned)(want < cap ? want : cap);
+    if (a.variant == 0) {
+        ternary_alu_kernel<96, 96, 96><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.rows[0], a.rows[1], a.rows[2],
+                                                                           a.rows[3], a.stride[0], a.stride[1], a.stride[2],
+                                                                           a.stride[3], a.n_out[3], a.cls, a.logits);
+    } else {
+        if (!a.wstream) return hipErrorInvalidValue;
+        if (G == 2)
+            ternary_stream_kernel<2, 96, 96, 96, 20><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.wstream, a.n_out[3],
+                                                                                         a.cls, a.logits);
+        else
+            ternary_stream_kernel<1, 96, 96, 96, 24><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.wstream, a.n_out[3],
+                                                                                         a.cls, a.logits);
+    }
     return hipGetLastError();
 }
-

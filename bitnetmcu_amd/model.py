@@ -96,6 +96,7 @@ class Context:
         L.check(self._lib, self._lib.bnm_ctx_create(model._h, device, C.byref(h)), "bnm_ctx_create")
         self._h = h
         self.cnn_variant = 1
+        self.ternary_variant = 2
         # diagnostic library only (BNM_LIBRARY=.../libbitnetmcu_hip_diag.so, build.py --diag): cache-resident source for
         # compute-side timing.  The product library does not export the symbol and ignores the variable.
         import os
@@ -128,6 +129,11 @@ class Context:
 
     def set_tuning(self, variant=-1, grid_blocks=0):
         L.check(self._lib, self._lib.bnm_ctx_set_tuning(self._h, variant, grid_blocks), "bnm_ctx_set_tuning")
+
+    def set_ternary_variant(self, variant):
+        """Ternary ALU kernel: 2 streamed weights + two images per lane (default), 1 one image per lane, 0 round 1's."""
+        L.check(self._lib, self._lib.bnm_ctx_set_ternary_variant(self._h, variant), "bnm_ctx_set_ternary_variant")
+        self.ternary_variant = variant
 
     def set_cnn_variant(self, variant):
         """1: conv1 on the matrix cores (default); 0: the all-VALU front end of round 1"""

@@ -151,6 +151,9 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
                            int32_t *logits);
 /* CNN front end: 1 (default) conv1 on the matrix cores, 0 the all-VALU kernel (kept for A/B measurements). */
 BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
+/* Ternary ALU kernel: 2 (default) weights streamed through double-buffered scalar registers, two images per lane;
+ * 1 the same with one image per lane; 0 round 1's kernel (kept for A/B measurements). */
+BNM_API int bnm_ctx_set_ternary_variant(bnm_ctx *c, int variant);
 /* Tuning of the host-pointer path.  mode 0 (default): pipelined page-locked staging; 1: the HIP runtime's own pageable copies,
  * chunk by chunk.  copy_threads: host threads of the staging copy (0 = default).  spin: poll the page-locked result words of the
  * <= 64-image path (default 1) instead of waiting for the stream. */

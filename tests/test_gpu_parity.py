@@ -30,7 +30,11 @@ def paths_for(ctx):
             pass
     try:
         ctx.set_path(b.PATH_TERNARY_ALU)
-        out.append(("ternary_alu", lambda c: c.set_path(b.PATH_TERNARY_ALU)))
+        for tv in (2, 1, 0):     # streamed weights with two / one image per lane, round 1's kernel
+            def tern(c, tv=tv):
+                c.set_path(b.PATH_TERNARY_ALU)
+                c.set_ternary_variant(tv)
+            out.append((f"ternary_alu_v{tv}", tern))
     except b.BnmError:
         pass
     ctx.set_path(b.PATH_AUTO)
@@ -269,9 +273,10 @@ def test_bench_json_contract(gpu_ok):
         assert k in d["cpu_baseline"]
 
 
-def _random_model_text(rng, codecs, widths, n_classes=10):
+def _random_model_text(rng, codecs, widths, n_classes=10, trit_digits=None):
     """Header text of an FC model with RANDOM packed weights: every codec id through the whole-model kernels, in
-    shapes of the fused table.  Ternary layers get the exporter's padding to a multiple of 10 (pad trits = 0)."""
+    shapes of the fused table.  Ternary layers get the exporter's padding to a multiple of 10 (pad trits = 0).
+    trit_digits(layer, n_out, n_in) -> base-3 digits (0: +1, 1: -1, 2: 0) replaces the random trits of ternary layers."""
     lines = ["#include <stdint.h>", "#define MODEL_FCMNIST", "#define NUM_LAYERS %d" % len(codecs), "#define MAX_N_ACTIVATIONS 256"]
     n_in = 256
     outs = list(widths) + [n_classes]
@@ -279,6 +284,8 @@ def _random_model_text(rng, codecs, widths, n_classes=10):
         if bpw == 64:
             padded = (n_in + 9) // 10 * 10
             trits = rng.integers(0, 3, size=(n_out, padded))
+            if trit_digits is not None:
+                trits[:, :n_in] = trit_digits(k, n_out, n_in)
             trits[:, n_in:] = 2                                   # pad = zero weight (exportquant.py:132-137)
             # base-3, most significant trit first, per 10-trit group (exportquant.py:146-156)
             g = trits.reshape(n_out, padded // 10, 10)
@@ -326,6 +333,36 @@ def test_random_models_every_codec_through_model_kernels(codecs, widths, gpu_ok,
         labels.append(label)
     if 36 not in codecs:
         assert any(l.startswith("fused") for l in labels), (codecs, labels)
+    ctx.close()
+
+
+@pytest.mark.parametrize("signs", ["-+-+", "+-+-", "----", "++++", "dense"])
+def test_ternary_alu_kernels_extreme_sums(signs, gpu_ok, orc):
+    """Ternary 256-96-96-96-10 models whose layers are all +1, all -1 or zero-free random trits, on all -128 / 127 / 0 / random
+    images: layer sums reach -32768 .. +32768 (the streamed kernels park sums as saturated int16 pairs: +32768 is the one value
+    that saturates) and every ReLUNorm shift from 0 to 9 occurs.  All three ALU kernels, ids and logits vs the oracle."""
+    rng = np.random.default_rng(len(signs) * 131 + ord(signs[0]))
+
+    def digits(k, n_out, n_in):
+        if signs == "dense":
+            return rng.integers(0, 2, size=(n_out, n_in))
+        d = np.full((n_out, n_in), 0 if signs[k - 1] == "+" else 1)
+        if k > 1:      # a few neurons of the other sign so that later layers see a mix
+            d[::7] = 1 - d[::7]
+        return d
+    model = b.Model.from_header_text(_random_model_text(rng, (64, 64, 64, 64), (96, 96, 96), trit_digits=digits))
+    om = util.OracleModel(model, orc)
+    x = np.concatenate([np.full((70, 256), -128, np.int8), np.full((70, 256), 127, np.int8), np.zeros((5, 256), np.int8),
+                        synth.images(11, 700, DIST_U), synth.images(11, 700, DIST_M),
+                        np.where(np.arange(256) % 2 == 0, -128, 127).astype(np.int8)[None].repeat(3, 0)])
+    want = om.infer(x, logits=True)
+    ctx = b.Context(model)
+    ctx.set_path(b.PATH_TERNARY_ALU)
+    for tv in (2, 1, 0):
+        ctx.set_ternary_variant(tv)
+        for n in (len(x), 129, 128, 127, 65, 1):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (signs, tv, n)
     ctx.close()
 
 
