@@ -293,7 +293,7 @@ BNM_DEVICE int wave_max_nonneg(int v) {
 // that byte may not exist.  The launcher runs that one image through the SAFE instantiation (clamped address, bytes shifted
 // into place: 2 extra VALU per load) and every other image through the plain one — no run-time test in the hot loop.
 template <bool FUSE, bool SAFE>
-__global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__restrict__ images, uint64_t n,
+__global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                              const int *__restrict__ wtab, uint32_t C_pad, uint32_t C, uint32_t c0,
                                                              uint32_t n_shift, int8_t *__restrict__ acts, uint32_t acts_stride,
                                                              int32_t *__restrict__ feat) {
@@ -307,34 +307,46 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
     // (band 1 rows compute conv1 at image row 13 - wr with the kernel the right way up: only the ORDER in which the window
     // presents rows to stages 2-3 is reversed, and those stages' kernels are reversed with it in the weight table)
     const int ia = lane & 31, beta = (ia >> 2) & 1, q = (ia & 3) + 4 * (ia >> 3);
-    int o1[7];      // byte offset of the MIDDLE patch row's four pixels; the other two rows are 16 bytes before / after
+    // byte offset of the TOP patch row's four pixels; the other two rows are 16 and 32 bytes further.  Unsigned 32-bit, so
+    // that the loads take the "uniform base + 32-bit lane offset" form: one register per tile and no 64-bit address
+    // arithmetic (with signed offsets hipcc kept seven 64-bit lane addresses alive across the item loop)
+    uint32_t o1[7];
 #pragma unroll
     for (int t = 0; t < 7; t++) {
         const int p = 16 * t + q, wr = p / 14, x = p % 14;
         const int g = beta ? 13 - wr : wr;
-        o1[t] = 16 * (g + 1) + x;
+        o1[t] = (uint32_t)(16 * g + x);
     }
     const int vshift = (int)n_shift;
     const int partner = (lane ^ 32) << 2;        // ds_bpermute address of the lane that owns the other band of this channel
 
     // ---- work items: (image, 32-channel block), the wave's images in order, block 0 then block 1 of each ----------------
     const uint32_t blk_shift = nblk == 2u ? 1u : 0u;
-    const uint64_t my_images = wave0 < n ? (n - wave0 + nwaves - 1) / nwaves : 0;
-    const uint64_t items = my_images << blk_shift;
+    const uint64_t my_images_v = wave0 < n ? (n - wave0 + nwaves - 1) / nwaves : 0;
+    // (the 64-bit division runs on the vector unit; hand the wave-uniform result back to scalar registers, or the loop bound
+    // lives - and is spilled - as a lane register pair)
+    // (32-bit counters: the launcher refuses n >= 2^31, and the only 64-bit comparison the scalar unit has is "equal")
+    const uint32_t my_images = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)my_images_v);
+    const uint32_t items = my_images << blk_shift;
     // A operand of a tile: bytes 0-3, 4-7, 8-11 of the lane's 16 K-bytes = image rows g, g+1, g+2 at columns x..x+3
     // (K-slots 12..15 meet zero weights); three L1-resident dword loads, reloaded per channel block.
-    auto load_A = [&](const int8_t *ip, int o) -> i32x4 {
+    auto load_A = [&](const int8_t *ip, uint32_t o) -> i32x4 {
         int va, vb, vc;
         if constexpr (!SAFE) {
-            va = *(const int *)(ip + (o - 16));
-            vb = *(const int *)(ip + o);
-            vc = *(const int *)(ip + (o + 16));
+            // buffer loads: wave-uniform descriptor of this image (rebuilt per item on the scalar unit) + the lane's 32-bit
+            // offset.  (As plain pointer arithmetic hipcc formed a 64-bit lane address per tile - one more VALU per tile and
+            // seven register PAIRS carried across the item loop.)  512 bytes are in range: the one-byte overrun of the last
+            // row belongs to the next image, which exists for every image this instantiation sees.
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)ip, 0, 512, 0x00020000);
+            va = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o, 0, 0);
+            vb = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + 16u), 0, 0);
+            vc = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + 32u), 0, 0);
         } else {      // offsets 253..255 (last image row, x = 13): read the dword at 252 and shift the bytes down
-            auto ld = [&](int oo) {
-                const int oc = oo > 252 ? 252 : oo;
-                return (int)((uint32_t)(*(const int *)(ip + oc)) >> (8 * (oo - oc)));
+            auto ld = [&](uint32_t oo) {
+                const uint32_t oc = oo > 252u ? 252u : oo;
+                return (int)((uint32_t)(*(const int *)(ip + oc)) >> (8u * (oo - oc)));
             };
-            va = ld(o - 16); vb = ld(o); vc = ld(o + 16);
+            va = ld(o); vb = ld(o + 16u); vc = ld(o + 32u);
         }
         return i32x4{va, vb, vc, vc};
     };
@@ -343,16 +355,24 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
     struct Head {
         i32x4 q0, q1, q2, q3, q4, a0;
     };
-    auto fetch = [&](uint64_t k) -> Head {
-        const uint64_t im = wave0 + (k >> blk_shift) * nwaves;
+    // the weight table through a wave-uniform descriptor + one 32-bit lane offset (the channel block is a scalar offset)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wtab, 0, (int)(2u * C_pad * CNN_WTAB_DWORDS * 4u), 0x00020000);
+    const int wvoff = (int)(((uint32_t)h * C_pad + c0 + (uint32_t)j) * (CNN_WTAB_DWORDS * 4u));
+    auto fetch = [&](uint32_t k) -> Head {
+        const uint64_t im = wave0 + (uint64_t)(k >> blk_shift) * nwaves;
         const uint32_t bb = (uint32_t)k & (nblk - 1u);
-        const i32x4 *wp = (const i32x4 *)(wtab + ((size_t)h * C_pad + c0 + 32u * bb + (uint32_t)j) * CNN_WTAB_DWORDS);
         Head hd;
-        hd.q0 = wp[0]; hd.q1 = wp[1]; hd.q2 = wp[2]; hd.q3 = wp[3]; hd.q4 = wp[4];
+        hd.q0 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
+        hd.q1 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 16, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
+        hd.q2 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 32, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
+        hd.q3 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 48, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
+        hd.q4 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 64, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.a0 = load_A(images + im * 256ull, o1[0]);
         return hd;
     };
-    int touch = 0;
+    // landing zone of the next-image touch: an LDS-DMA load has no register destination to keep reserved
+    __shared__ int s_touch[4][64];
+    const uint32_t touch_lds = (uint32_t)(uintptr_t)&s_touch[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0];
     int fo[2][2] = {{0, 0}, {0, 0}};          // the lane's pooled outputs: [block][t & 1], t = 2h + (t & 1)
     // The act bytes of an image are stored at the START of the next item, not at the end of their own: vmcnt counts stores,
     // and the wait hipcc places on the loop's back edge would otherwise park the wave for the write acknowledgement of a
@@ -361,33 +381,57 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
     const int8_t *pend_row = acts;            // wave-uniform: the pending image's act row
     uint32_t pend_v = 0;                      // block 0's two bytes | block 1's two bytes << 16
     bool pend = false;
+    // stores go through a wave-uniform descriptor of the image's act row (4 C valid bytes) + the lane's constant offset: the
+    // range check drops the lanes of channels >= C (and the whole second block of a <= 32-channel model), no lane addresses
+    // (lane-constant offsets that are needed once per image are re-derived from the lane id behind an opaque copy: hoisted
+    // out of the item loop they would each hold a register for the whole kernel)
+    auto lane_now = []() -> int {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    auto store_off = [&]() -> int {
+        const int l = lane_now();
+        return 4 * (int)c0 + 4 * (l & 31) + 2 * (l >> 5);
+    };
     auto flush_pending = [&]() {
         if (!pend) return;
-#pragma unroll
-        for (uint32_t bb = 0; bb < 2; bb++) {
-            const uint32_t c = c0 + 32u * bb + (uint32_t)j;
-            if (bb < nblk && c < C) *(uint16_t *)(const_cast<int8_t *>(pend_row) + 4u * c + 2u * (uint32_t)h) = (uint16_t)(pend_v >> (16 * bb));
-        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)pend_row, 0, (int)(4u * C), 0x00020000);
+        const int st_off = store_off();
+        __builtin_amdgcn_raw_buffer_store_b16((short)(pend_v & 0xFFFFu), rs, st_off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((short)(pend_v >> 16), rs, st_off, 128, 0);     // block 1: scalar offset
         pend = false;
     };
-    for (uint64_t k = 0; k < items; k++) {
-        const uint64_t img = wave0 + (k >> blk_shift) * nwaves;
+    for (uint32_t k = 0; k < items; k++) {
+        const uint64_t img = wave0 + (uint64_t)(k >> blk_shift) * nwaves;
         const uint32_t blk = (uint32_t)k & (nblk - 1u);
         const int8_t *__restrict__ ip = images + img * 256ull;          // wave-uniform
         // Touch the wave's NEXT image (64 lanes x 4 B = its 256 bytes) so that its patch loads hit the cache instead of waiting
-        // a microsecond for HBM.  The value is never used; its register stays reserved until the end of the iteration, by
-        // when the in-order vector-memory returns behind this iteration's own (waited-for) loads guarantee it has landed.
-        if (blk == 0 && img + nwaves < n) {
+        // a microsecond for HBM.  The data is never used: an LDS-DMA load drops it into a per-wave landing zone.
+        if (blk == 0 && (k >> blk_shift) + 1u < my_images) {
             const int8_t *np = ip + nwaves * 256ull;
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(touch) : "v"(lane * 4), "s"(np) : "memory");
+            uint32_t keep;
+            const int lane4 = lane_now() * 4;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane4), "s"(touch_lds), "s"(np) : "memory");
         }
         const Head cur = fetch(k);
         const i32x4 wB = cur.q0, wq1 = cur.q1, wq2 = cur.q2, wq3 = cur.q3, wq4 = cur.q4;
         const int w01[3] = {wq1[0], wq1[2], wq2[0]}, w2z[3] = {wq1[1], wq1[3], wq2[1]};
         const int k3[9] = {wq2[2], wq2[3], wq3[0], wq3[1], wq3[2], wq3[3], wq4[0], wq4[1], wq4[2]};
         // ---- stage 1: 7 MFMAs, each followed by the shift / pack / ReLU of its 16 window positions -------------------
-        int E[56], O[56];          // even pairs (r[2k], r[2k+1]) and odd pairs (r[2k+1], r[2k+2]) of the window, raster order
-        int r2[6][12];             // raw conv2 sums of the window rows
+        // conv1 window as int16 pairs E[k] = (r[2k], r[2k+1]), raster order, 7 pairs per row.  conv2 at an even column x reads
+        // (r[x], r[x+1]) . (w0, w1) + (r[x+2], r[x+3]) . (w2, 0); at an odd column the SAME two registers hold
+        // (r[x-1], r[x]) and (r[x+1], r[x+2]), so it is (.) . (0, w0) + (.) . (w1, w2): two more weight pairs per kernel row
+        // (6 VALU per item) instead of a second, odd-aligned copy of the window (56 v_alignbit and 56 registers per item).
+        int E[56];
+        int wz0[3], w12[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            wz0[dy] = (int)((uint32_t)w01[dy] << 16);
+            w12[dy] = (int)__builtin_amdgcn_alignbit((uint32_t)w2z[dy], (uint32_t)w01[dy], 16);
+        }
+        int hm[6];                 // even conv2 rows, already reduced to max(sum[2x], sum[2x+1], 0): 6 live values, not 12 raw sums
         int p1[3][6];              // pooled rows (band-local)
         i32x4 Anext = cur.a0;
         static_for<0, 7>([&](auto T) {
@@ -407,37 +451,32 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
             sdwa_ashr_pack8(acc, vshift, d);
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) E[8 * t + kk] = pk_relu_i16(d[kk]);
-            // odd pairs whose two neighbours now exist
-            static_for<0, 8>([&](auto K) {
-                constexpr int P = 8 * t + decltype(K)::value - 1;          // O[P] needs E[P] and E[P + 1]
-                if constexpr (P >= 0) O[P] = (int)__builtin_amdgcn_alignbit((uint32_t)E[P + 1], (uint32_t)E[P], 16);
-            });
-            if constexpr (t == 6) O[55] = (int)((uint32_t)E[55] >> 16);
-            // ---- stage 2: the conv2 window rows whose three conv1 rows (and the odd pair closing the last) now exist ------
+            // ---- stage 2: the conv2 window rows whose three conv1 rows now exist ---------------------------------------
             static_for<0, 6>([&](auto Y) {
                 constexpr int y = decltype(Y)::value;
-                constexpr int ready = (7 * (y + 3) < 56) ? (7 * (y + 3)) / 8 : 6;     // tile that produced O[7 (y + 2) + 6]
+                constexpr int ready = (7 * (y + 3) - 1) / 8;                          // tile that produced E[7 (y + 2) + 6]
                 if constexpr (ready == t) {
-                    static_for<0, 12>([&](auto X) {
-                        constexpr int x = decltype(X)::value;
-                        int sum = 0;
-                        static_for<0, 3>([&](auto DY) {
-                            constexpr int dy = decltype(DY)::value;
-                            constexpr int base = 7 * (y + dy);              // first pair of conv1 window row y + dy
-                            const int pa = (x & 1) ? O[base + x / 2] : E[base + x / 2];              // (r[x], r[x+1])
-                            const int pb = (x & 1) ? O[base + x / 2 + 1] : E[base + x / 2 + 1];      // (r[x+2], r[x+3])
-                            sum = dy == 0 ? dot2_first(pa, w01[0]) : dot2_next(pa, w01[dy], sum);
-                            sum = dy == 2 ? dot2_last(pb, w2z[2], sum) : dot2_next(pb, w2z[dy], sum);
+                    // pool-before-ReLU, two columns at a time: an even row leaves max(s0, s1, 0), the odd row below it
+                    // max(that, s0, s1) >> shift (3 VALU per pooled value, as before, with 6 values carried instead of 12)
+                    static_for<0, 6>([&](auto XP) {
+                        constexpr int xp = decltype(XP)::value;
+                        int sm[2];
+                        static_for<0, 2>([&](auto XL) {
+                            constexpr int x = 2 * xp + decltype(XL)::value;
+                            int sum = 0;
+                            static_for<0, 3>([&](auto DY) {
+                                constexpr int dy = decltype(DY)::value;
+                                constexpr int base = 7 * (y + dy);              // first pair of conv1 window row y + dy
+                                const int pa = E[base + x / 2], pb = E[base + x / 2 + 1];
+                                const int wa = (x & 1) ? wz0[dy] : w01[dy], wb = (x & 1) ? w12[dy] : w2z[dy];
+                                sum = dy == 0 ? dot2_first(pa, wa) : dot2_next(pa, wa, sum);
+                                sum = dy == 2 ? dot2_last(pb, wb, sum) : dot2_next(pb, wb, sum);
+                            });
+                            sm[x & 1] = sum;
                         });
-                        r2[y][x] = sum;
+                        if constexpr (y & 1) p1[y >> 1][xp] = max(max(hm[xp], sm[0]), sm[1]) >> n_shift;
+                        else hm[xp] = max(max(sm[0], sm[1]), 0);
                     });
-                    if constexpr (y & 1) {
-                        static_for<0, 6>([&](auto X) {
-                            constexpr int x = decltype(X)::value;
-                            int m = max(max(r2[y - 1][2 * x], r2[y - 1][2 * x + 1]), r2[y][2 * x]);
-                            p1[y >> 1][x] = max(max(m, r2[y][2 * x + 1]), 0) >> n_shift;
-                        });
-                    }
                 }
             });
         });
@@ -469,15 +508,11 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
         if (blk + 1 == nblk) {
             // ---- outputs: lane (j, h), block b: channel c0 + 32 b + j, values t = 2h, 2h + 1 ---------------------------------
             if (feat) {
-#pragma unroll
-                for (uint32_t bb = 0; bb < 2; bb++) {
-                    const uint32_t c = c0 + 32u * bb + (uint32_t)j;
-                    if (bb < nblk && c < C) {
-                        int *fp = feat + img * (4ull * C) + 4ull * c + 2u * (uint32_t)h;
-                        fp[0] = fo[bb][0];
-                        fp[1] = fo[bb][1];
-                    }
-                }
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(feat + img * (4ull * C)), 0, (int)(16u * C), 0x00020000);
+                typedef int i32x2 __attribute__((ext_vector_type(2)));
+                const int f_off = 4 * store_off();
+                __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[0][0], fo[0][1]}, rs, f_off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[1][0], fo[1][1]}, rs, f_off, 512, 0);
             }
             if constexpr (FUSE) {
                 // fused ReLUNorm over the 4*C features (all >= 0; channels >= C have zero weights and contribute 0)
@@ -494,7 +529,6 @@ __global__ __launch_bounds__(256, 3) void cnn_front_mfma_kernel(const int8_t *__
                 pend = true;
             }
         }
-        asm volatile("" ::"v"(touch));      // end of the touch register's reservation
     }
     flush_pending();
 }
@@ -531,10 +565,11 @@ void bnm_cnn_weight_table(const int8_t *w1, const int8_t *w2, const int8_t *w3, 
 hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, const int8_t *w2, const int8_t *w3, const int *wtab,
                           uint32_t C, uint32_t n_shift, int8_t *acts, uint32_t acts_stride, int32_t *feat, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (C == 0 || C > 256 || n_shift < 4 || n_shift > 15 || acts_stride < 4u * C || (acts_stride & 3u)) return hipErrorInvalidValue;
+    if (C == 0 || C > 256 || n_shift < 4 || n_shift > 15 || acts_stride < 4u * C || (acts_stride & 3u) || n >= (1ull << 31))
+        return hipErrorInvalidValue;
     uint64_t blocks = (n + 3) / 4;
-    // persistent grid = what is resident: 3 workgroups of 4 waves per CU for the MFMA kernel (168 VGPRs), 4 for the VALU one
-    uint64_t cap = (uint64_t)bnm_num_cus() * (wtab ? 3ull : 4ull);
+    // persistent grid = what is resident: 4 workgroups of 4 waves per CU (both kernels fit 128 VGPRs)
+    uint64_t cap = (uint64_t)bnm_num_cus() * 4ull;
     if (blocks > cap) blocks = cap;
     dim3 g((unsigned)blocks), b(256);
     const uint32_t C_pad = (C + 63u) / 64u * 64u;
