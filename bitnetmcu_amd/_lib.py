@@ -89,6 +89,7 @@ PROTOTYPES = {
 DIAG_PROTOTYPES = {
     "bnm_diag_stream_device": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, _vp, _vp]),
     "bnm_diag_set_src_wrap": (C.c_int, [_vp, C.c_uint64]),
+    "bnm_diag_cnn_set_record": (C.c_int, [_vp]),
 }
 
 

@@ -160,6 +160,8 @@ struct bnm_ctx {
     int8_t *w_conv[3] = {nullptr, nullptr, nullptr};
     int *cnn_wtab = nullptr;       // per-channel weight table of the conv1-on-MFMA front end
     int cnn_variant = 1;           // 1: conv1 on the matrix cores (default), 0: the all-VALU kernel of round 1
+    uint32_t cnn_grab = 8;         // images a wave of the MFMA front end takes from the work counter at a time (0: fixed shares)
+    uint32_t *cnn_counter = nullptr;
     // fused MFMA path: shape-specialised kernels (register-resident weights, bnm_fused_fc.hip) and / or the generic
     // kernel (run-time widths, weights in LDS, bnm_fused_generic.hip; variant id BNM_FUSED_GENERIC)
     bool fused_ok = false;      // at least one of the two can run this model
@@ -258,6 +260,9 @@ int ctx_build(bnm_ctx *c) {
             if (int e = dev_alloc(c, &p, tab.size() * sizeof(int))) return e;
             HIP_TRY(hipMemcpy(p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
             c->cnn_wtab = (int *)p;
+            void *q = nullptr;
+            if (int e = dev_alloc(c, &q, 256)) return e;
+            c->cnn_counter = (uint32_t *)q;
         }
         width = c->channels * 4u;
         li = 5;
@@ -495,7 +500,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         int32_t *feat = (c->channels > 64 || d_acts_tap) ? (int32_t *)c->cnn_feat.p : nullptr;
         int8_t *acts = (int8_t *)c->cnn_feat.p + (size_t)cn * W * 4;
         HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,
-                               c->channels, 4, acts, AS, feat, s));
+                               c->channels, 4, acts, AS, feat, c->cnn_counter, c->cnn_grab, s));
         uint32_t *cls = d_cls + off;
         int32_t *lg = d_logits ? d_logits + off * ncls : nullptr;
         if (d_acts_tap)
@@ -647,9 +652,10 @@ int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
 }
 
 int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
-    if (!c || variant < 0 || variant > 1) return fail(BNM_EINVAL, "bad argument");
+    if (!c || variant < 0 || (variant > 2 && variant < 101) || variant > 164) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
-    c->cnn_variant = variant;
+    c->cnn_variant = variant == 0 ? 0 : 1;
+    c->cnn_grab = variant == 2 ? 0u : variant > 100 ? (uint32_t)(variant - 100) : 8u;
     return BNM_OK;
 }
 
@@ -925,6 +931,12 @@ int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int gri
     return BNM_OK;
 }
 // the fused kernels read tile (t mod wrap) instead of tile t: WRONG class ids by design, timing only
+#ifdef BNM_DIAG_TIMING
+int bnm_diag_cnn_set_record(uint64_t *d_rec) {
+    HIP_TRY(bnmk_diag_cnn_set_record(d_rec));
+    return BNM_OK;
+}
+#endif
 int bnm_diag_set_src_wrap(bnm_ctx *c, uint64_t wrap) {
     if (!c) return fail(BNM_EINVAL, "null ctx");
     c->diag_src_wrap = wrap;

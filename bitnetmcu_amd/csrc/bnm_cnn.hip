@@ -253,7 +253,7 @@ BNM_DEVICE void sdwa_ashr_pack8(const i32x16 &a, int s, int (&d)[8]) {
         "v_ashrrev_i32_sdwa %7, %8, %24 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
         "s_nop 1"
         : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
-        : "v"(s), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+        : "s"(s), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
           "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
 }
 
@@ -292,42 +292,55 @@ BNM_DEVICE int wave_max_nonneg(int v) {
 // SAFE: the patch loads of image row 15, column 13 reach one byte past the image; for the LAST image of the caller's buffer
 // that byte may not exist.  The launcher runs that one image through the SAFE instantiation (clamped address, bytes shifted
 // into place: 2 extra VALU per load) and every other image through the plain one — no run-time test in the hot loop.
+#ifdef BNM_DIAG_TIMING
+// diagnostic build only (build.py --diag-timing; profiles/cnn_wait_timing.py): per wave {loop cycles, cycles waiting for the
+// item's head loads, for the patch tiles, for the partner exchange, items, start stamp, XCC_ID register, HW_ID register}
+__device__ uint64_t *g_cnn_rec = nullptr;
+hipError_t bnmk_diag_cnn_set_record(uint64_t *d_rec) { return hipMemcpyToSymbol(HIP_SYMBOL(g_cnn_rec), &d_rec, sizeof(d_rec)); }
+#define CNN_STAMP() __builtin_readcyclecounter()
+#endif
 template <bool FUSE, bool SAFE>
 __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                              const int *__restrict__ wtab, uint32_t C_pad, uint32_t C, uint32_t c0,
                                                              uint32_t n_shift, int8_t *__restrict__ acts, uint32_t acts_stride,
-                                                             int32_t *__restrict__ feat) {
+                                                             int32_t *__restrict__ feat, uint32_t *__restrict__ counter, uint32_t grab) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * 4u + (uint64_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4u;
+    const uint32_t wave_id = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * 4u;
+    const uint32_t n32 = (uint32_t)n;           // the launcher refuses n >= 2^31
     const uint32_t nblk = (C - c0) > 32u ? 2u : 1u;
 
     // A-operand addressing (the same for every image): A row i of tile t is window position 16t + q of band beta
     // (band 1 rows compute conv1 at image row 13 - wr with the kernel the right way up: only the ORDER in which the window
     // presents rows to stages 2-3 is reversed, and those stages' kernels are reversed with it in the weight table)
     const int ia = lane & 31, beta = (ia >> 2) & 1, q = (ia & 3) + 4 * (ia >> 3);
-    // byte offset of the TOP patch row's four pixels; the other two rows are 16 and 32 bytes further.  Unsigned 32-bit, so
-    // that the loads take the "uniform base + 32-bit lane offset" form: one register per tile and no 64-bit address
-    // arithmetic (with signed offsets hipcc kept seven 64-bit lane addresses alive across the item loop)
-    uint32_t o1[7];
+    // byte offset of the TOP patch row's four pixels (the other two rows are 16 and 32 bytes further): at most 13 * 16 + 13,
+    // so the seven tiles' offsets travel as bytes of two registers and cost one v_bfe_u32 per tile instead of seven registers
+    uint32_t o1p[2] = {0u, 0u};
 #pragma unroll
     for (int t = 0; t < 7; t++) {
         const int p = 16 * t + q, wr = p / 14, x = p % 14;
         const int g = beta ? 13 - wr : wr;
-        o1[t] = (uint32_t)(16 * g + x);
+        o1p[t >> 2] |= (uint32_t)(16 * g + x) << (8 * (t & 3));
     }
+    // (extracted behind an opaque copy, or hipcc hoists the seven extractions out of the item loop - seven registers again)
+    auto o1 = [&](int t) -> uint32_t {
+        uint32_t w = o1p[t >> 2];
+        asm volatile("" : "+v"(w));
+        return (w >> (8 * (t & 3))) & 0xFFu;
+    };
     const int vshift = (int)n_shift;
     const int partner = (lane ^ 32) << 2;        // ds_bpermute address of the lane that owns the other band of this channel
 
-    // ---- work items: (image, 32-channel block), the wave's images in order, block 0 then block 1 of each ----------------
+    // ---- work items: (image, 32-channel block), block 0 then block 1 of each image.  Images are handed out in batches of
+    // `grab` consecutive images from ONE device-wide counter (the first batch of every wave is static).  Why not a fixed
+    // share per wave: the SIMD's arbiter favours its oldest wave, so with equal shares the four waves of a SIMD finish one
+    // after the other (measured, profiles/cnn_wait_timing.py: the fastest wave of a launch took 3.9 M cycles, the slowest
+    // 8.3 M for the same 512 items) and the last quarter of the launch runs at one wave per SIMD with every latency exposed.
+    // With the counter every wave works until the images run out.  counter == nullptr: fixed shares (single-image launches).
     const uint32_t blk_shift = nblk == 2u ? 1u : 0u;
-    const uint64_t my_images_v = wave0 < n ? (n - wave0 + nwaves - 1) / nwaves : 0;
-    // (the 64-bit division runs on the vector unit; hand the wave-uniform result back to scalar registers, or the loop bound
-    // lives - and is spilled - as a lane register pair)
-    // (32-bit counters: the launcher refuses n >= 2^31, and the only 64-bit comparison the scalar unit has is "equal")
-    const uint32_t my_images = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)my_images_v);
-    const uint32_t items = my_images << blk_shift;
+    const uint32_t per_batch = grab << blk_shift;
     // A operand of a tile: bytes 0-3, 4-7, 8-11 of the lane's 16 K-bytes = image rows g, g+1, g+2 at columns x..x+3
     // (K-slots 12..15 meet zero weights); three L1-resident dword loads, reloaded per channel block.
     auto load_A = [&](const int8_t *ip, uint32_t o) -> i32x4 {
@@ -358,16 +371,14 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
     // the weight table through a wave-uniform descriptor + one 32-bit lane offset (the channel block is a scalar offset)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wtab, 0, (int)(2u * C_pad * CNN_WTAB_DWORDS * 4u), 0x00020000);
     const int wvoff = (int)(((uint32_t)h * C_pad + c0 + (uint32_t)j) * (CNN_WTAB_DWORDS * 4u));
-    auto fetch = [&](uint32_t k) -> Head {
-        const uint64_t im = wave0 + (uint64_t)(k >> blk_shift) * nwaves;
-        const uint32_t bb = (uint32_t)k & (nblk - 1u);
+    auto fetch = [&](uint32_t im, uint32_t bb) -> Head {
         Head hd;
         hd.q0 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.q1 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 16, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.q2 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 32, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.q3 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 48, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.q4 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 64, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
-        hd.a0 = load_A(images + im * 256ull, o1[0]);
+        hd.a0 = load_A(images + (uint64_t)im * 256ull, o1(0));
         return hd;
     };
     // landing zone of the next-image touch: an LDS-DMA load has no register destination to keep reserved
@@ -402,20 +413,46 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         __builtin_amdgcn_raw_buffer_store_b16((short)(pend_v >> 16), rs, st_off, 128, 0);     // block 1: scalar offset
         pend = false;
     };
-    for (uint32_t k = 0; k < items; k++) {
-        const uint64_t img = wave0 + (uint64_t)(k >> blk_shift) * nwaves;
-        const uint32_t blk = (uint32_t)k & (nblk - 1u);
-        const int8_t *__restrict__ ip = images + img * 256ull;          // wave-uniform
+#ifdef BNM_DIAG_TIMING
+    uint64_t t_head = 0, t_tile = 0, t_xchg = 0;
+    const uint64_t t_start = CNN_STAMP();
+#endif
+    uint32_t cur_batch = wave_id * grab, off = 0;
+#ifdef BNM_DIAG_TIMING
+    uint32_t n_items = 0;
+#endif
+    int nxt_v = 0;                            // lane 0: the counter before this wave's add = first image of its next batch - nwaves * grab
+    for (;;) {
+        const uint32_t img = cur_batch + (off >> blk_shift);
+        if (img >= n32) break;                // batches are handed out in increasing order: nothing is left for this wave
+        const uint32_t blk = off & (nblk - 1u);
+        const int8_t *__restrict__ ip = images + (uint64_t)img * 256ull;          // wave-uniform
+        // the batch after this one is requested at the start of this one; the answer is needed `grab` images later
+        if (off == 0 && counter != nullptr && lane_now() == 0)
+            nxt_v = (int)__hip_atomic_fetch_add(counter, grab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // Touch the wave's NEXT image (64 lanes x 4 B = its 256 bytes) so that its patch loads hit the cache instead of waiting
         // a microsecond for HBM.  The data is never used: an LDS-DMA load drops it into a per-wave landing zone.
-        if (blk == 0 && (k >> blk_shift) + 1u < my_images) {
-            const int8_t *np = ip + nwaves * 256ull;
-            uint32_t keep;
-            const int lane4 = lane_now() * 4;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(lane4), "s"(touch_lds), "s"(np) : "memory");
+        if (blk == 0) {
+            uint32_t ni = img + 1u;
+            if ((off >> blk_shift) + 1u == grab)     // last image of the batch: the next one opens the next batch
+                ni = counter != nullptr ? (grab > 1u ? nwaves * grab + (uint32_t)__builtin_amdgcn_readfirstlane(nxt_v) : n32)
+                                        : cur_batch + nwaves * grab;
+            if (ni < n32) {
+                const int8_t *np = images + (uint64_t)ni * 256ull;
+                uint32_t keep;
+                const int lane4 = lane_now() * 4;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(lane4), "s"(touch_lds), "s"(np) : "memory");
+            }
         }
-        const Head cur = fetch(k);
+        const Head cur = fetch(img, blk);
+#ifdef BNM_DIAG_TIMING
+        {
+            const uint64_t t0 = CNN_STAMP();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t_head += CNN_STAMP() - t0;
+        }
+#endif
         const i32x4 wB = cur.q0, wq1 = cur.q1, wq2 = cur.q2, wq3 = cur.q3, wq4 = cur.q4;
         const int w01[3] = {wq1[0], wq1[2], wq2[0]}, w2z[3] = {wq1[1], wq1[3], wq2[1]};
         const int k3[9] = {wq2[2], wq2[3], wq3[0], wq3[1], wq3[2], wq3[3], wq4[0], wq4[1], wq4[2]};
@@ -439,11 +476,18 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
             i32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0;
+#ifdef BNM_DIAG_TIMING
+            if constexpr (t > 0) {
+                const uint64_t t0 = CNN_STAMP();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                t_tile += CNN_STAMP() - t0;
+            }
+#endif
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Anext, wB, acc, 0, 0, 0);
             // (a scheduling fence per tile: left alone hipcc hoists all seven tiles' patch loads to the top of the item, 18 live
             // registers that push the kernel over the 168 of three waves per SIMD)
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (t < 6) Anext = load_A(ip, o1[t + 1]);
+            if constexpr (t < 6) Anext = load_A(ip, o1(t + 1));
             // (the previous image's act bytes go out here, BEHIND all of this item's patch loads in program order: no wait
             // for a patch load covers them, and the back-edge wait finds them ~500 VALU instructions old)
             if constexpr (t == 6) { if (blk == 0) flush_pending(); }
@@ -496,8 +540,15 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
             sc = mad24(k3[2], p1[2][x + 2], sc);
             oa3[x] = sa; ob3[x] = sb; snd[x] = sc;
         }
+#ifdef BNM_DIAG_TIMING
+        const uint64_t tx0 = CNN_STAMP();
+#endif
 #pragma unroll
         for (int x = 0; x < 4; x++) ob3[x] += __builtin_amdgcn_ds_bpermute(partner, snd[x]);
+#ifdef BNM_DIAG_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t_xchg += CNN_STAMP() - tx0;
+#endif
 #pragma unroll
         for (int x = 0; x < 2; x++) {
             int m = max(max(oa3[2 * x], oa3[2 * x + 1]), ob3[2 * x]);
@@ -508,7 +559,7 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         if (blk + 1 == nblk) {
             // ---- outputs: lane (j, h), block b: channel c0 + 32 b + j, values t = 2h, 2h + 1 ---------------------------------
             if (feat) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(feat + img * (4ull * C)), 0, (int)(16u * C), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(feat + (uint64_t)img * (4ull * C)), 0, (int)(16u * C), 0x00020000);
                 typedef int i32x2 __attribute__((ext_vector_type(2)));
                 const int f_off = 4 * store_off();
                 __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[0][0], fo[0][1]}, rs, f_off, 0, 0);
@@ -525,12 +576,27 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
 #pragma unroll
                 for (uint32_t bb = 0; bb < 2; bb++)
                     pend_v |= ((uint32_t)min((fo[bb][0] + rnd) >> sh, 127) | ((uint32_t)min((fo[bb][1] + rnd) >> sh, 127) << 8)) << (16 * bb);
-                pend_row = acts + img * (uint64_t)acts_stride;
+                pend_row = acts + (uint64_t)img * (uint64_t)acts_stride;
                 pend = true;
             }
         }
+        // ---- next item; after the batch's last one: the batch the counter handed out ------------------------------------------
+#ifdef BNM_DIAG_TIMING
+        n_items++;
+#endif
+        if (++off == per_batch) {
+            off = 0;
+            cur_batch = counter != nullptr ? nwaves * grab + (uint32_t)__builtin_amdgcn_readfirstlane(nxt_v) : cur_batch + nwaves * grab;
+        }
     }
     flush_pending();
+#ifdef BNM_DIAG_TIMING
+    if (g_cnn_rec && lane_now() == 0) {
+        uint64_t *rec = g_cnn_rec + 8ull * wave_id;
+        rec[0] = CNN_STAMP() - t_start; rec[1] = t_head; rec[2] = t_tile; rec[3] = t_xchg; rec[4] = n_items;
+        rec[5] = t_start; rec[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); rec[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
+#endif
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------
@@ -563,7 +629,8 @@ void bnm_cnn_weight_table(const int8_t *w1, const int8_t *w2, const int8_t *w3, 
 // C > 64 (several channel groups: ReLUNorm then runs as its own kernel over the complete vector).
 // wtab != nullptr: conv1 on the matrix cores (cnn_front_mfma_kernel, default); nullptr: the all-VALU kernel of round 1.
 hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, const int8_t *w2, const int8_t *w3, const int *wtab,
-                          uint32_t C, uint32_t n_shift, int8_t *acts, uint32_t acts_stride, int32_t *feat, hipStream_t s) {
+                          uint32_t C, uint32_t n_shift, int8_t *acts, uint32_t acts_stride, int32_t *feat, uint32_t *counter,
+                          uint32_t grab, hipStream_t s) {
     if (!n) return hipSuccess;
     if (C == 0 || C > 256 || n_shift < 4 || n_shift > 15 || acts_stride < 4u * C || (acts_stride & 3u) || n >= (1ull << 31))
         return hipErrorInvalidValue;
@@ -576,12 +643,19 @@ hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, co
     // MFMA kernel: images [0, n-1) through the plain instantiation, the last one through the SAFE one (see the kernel)
     const uint64_t n_main = n - 1;
     const uint64_t tail_off = n_main * 256ull;
+    // MFMA kernel: batches of `grab` images from `counter` (zeroed ahead of every launch: the waves' first batches are
+    // static, the counter hands out what follows); counter == nullptr or grab == 0: fixed shares of single images
+    if (!counter || !grab) { counter = nullptr; grab = 1; }
+    auto zero = [&]() -> hipError_t { return counter ? hipMemsetAsync(counter, 0, sizeof(uint32_t), s) : hipSuccess; };
     if (C <= 64) {
         if (wtab) {
-            if (n_main) cnn_front_mfma_kernel<true, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, 0, n_shift, acts, acts_stride, feat);
+            if (n_main) {
+                if (hipError_t e = zero(); e != hipSuccess) return e;
+                cnn_front_mfma_kernel<true, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, 0, n_shift, acts, acts_stride, feat, counter, grab);
+            }
             cnn_front_mfma_kernel<true, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, C, 0, n_shift,
                                                                   acts + n_main * (uint64_t)acts_stride, acts_stride,
-                                                                  feat ? feat + n_main * 4ull * C : nullptr);
+                                                                  feat ? feat + n_main * 4ull * C : nullptr, nullptr, 1);
         } else {
             cnn_front_kernel<true><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, 0, n_shift, acts, acts_stride, feat);
         }
@@ -590,9 +664,13 @@ hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, co
     if (!feat) return hipErrorInvalidValue;
     for (uint32_t c0 = 0; c0 < C; c0 += 64) {
         if (wtab) {
-            if (n_main) cnn_front_mfma_kernel<false, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, c0, n_shift, acts, acts_stride, feat);
+            if (n_main) {
+                if (hipError_t e = zero(); e != hipSuccess) return e;
+                cnn_front_mfma_kernel<false, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, c0, n_shift, acts, acts_stride, feat, counter, grab);
+            }
             cnn_front_mfma_kernel<false, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, C, c0, n_shift,
-                                                                   acts + n_main * (uint64_t)acts_stride, acts_stride, feat + n_main * 4ull * C);
+                                                                   acts + n_main * (uint64_t)acts_stride, acts_stride, feat + n_main * 4ull * C,
+                                                                   nullptr, 1);
         } else {
             cnn_front_kernel<false><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, c0, n_shift, acts, acts_stride, feat);
         }

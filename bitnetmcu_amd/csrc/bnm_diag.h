@@ -15,6 +15,9 @@ BNM_API int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode,
 /* Make the fused kernels of this context read tile (t mod wrap) — a cache-resident source, for compute-side timing.
  * Class ids are WRONG by design while wrap != 0. */
 BNM_API int bnm_diag_set_src_wrap(bnm_ctx *c, uint64_t wrap);
+/* --diag-timing build only: where cnn_front_mfma_kernel's waves wait.  d_rec: uint64 [waves][8] = {loop cycles, cycles waiting
+ * for an item's head loads, for the patch tiles, for the partner exchange, items, start stamp, XCC_ID, HW_ID}; NULL switches the records off. */
+BNM_API int bnm_diag_cnn_set_record(uint64_t *d_rec);
 #ifdef __cplusplus
 }
 #endif

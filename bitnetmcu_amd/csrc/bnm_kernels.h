@@ -89,9 +89,11 @@ hipError_t bnmk_maxpool22(const int32_t *d_in, uint32_t xy, int32_t *d_out, hipS
 // acts_stride: bytes between consecutive images' act rows (>= 4*C; bytes past 4*C are left untouched)
 // d_wtab: the per-channel weight table of the conv1-on-MFMA kernel (bnm_cnn_weight_table, uploaded by the caller) — or
 // nullptr to run the all-VALU kernel of round 1 (kept for A/B measurements, bnm_ctx_set_cnn_variant)
+// d_counter / grab: the MFMA kernel's waves take batches of `grab` images from this device word (zeroed by the launcher);
+// nullptr / 0: a fixed share per wave
 hipError_t bnmk_cnn_front(const int8_t *d_images, uint64_t n, const int8_t *d_w1, const int8_t *d_w2,
                           const int8_t *d_w3, const int *d_wtab, uint32_t C, uint32_t n_shift, int8_t *d_acts,
-                          uint32_t acts_stride, int32_t *d_feat, hipStream_t s);
+                          uint32_t acts_stride, int32_t *d_feat, uint32_t *d_counter, uint32_t grab, hipStream_t s);
 constexpr int BNM_CNN_WTAB_DWORDS = 20;      // per (band, channel); 2 bands x C rounded up to 64 channels
 void bnm_cnn_weight_table(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int *out);
 
@@ -114,6 +116,9 @@ hipError_t bnmk_ternary_stream_build(const BnmTernArgs &a, int *d_stream, hipStr
 hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s);
 
 // ---- diagnostics (bnm_diag.hip, diagnostic library only): cost of the image stream alone, pipe overlap ----
+#ifdef BNM_DIAG_TIMING
+hipError_t bnmk_diag_cnn_set_record(uint64_t *d_rec);   // 5 x uint64 per wave of cnn_front_mfma_kernel
+#endif
 #ifdef BNM_DIAG
 hipError_t bnmk_diag_stream(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out, hipStream_t s);
 hipError_t bnmk_diag_pipes(int mode, uint64_t tiles_per_wave, uint32_t *d_out, hipStream_t s);   // modes 5/6/7: pipe overlap probe

@@ -136,9 +136,10 @@ class Context:
         self.ternary_variant = variant
 
     def set_cnn_variant(self, variant):
-        """1: conv1 on the matrix cores (default); 0: the all-VALU front end of round 1"""
+        """1: conv1 on the matrix cores, dynamic image batches (default); 2: fixed share per wave; 100 + g: batches of g images;
+        0: the all-VALU front end of round 1"""
         L.check(self._lib, self._lib.bnm_ctx_set_cnn_variant(self._h, variant), "bnm_ctx_set_cnn_variant")
-        self.cnn_variant = variant
+        self.cnn_variant = 0 if variant == 0 else 1
 
     def set_host_tuning(self, mode=0, copy_threads=0, spin=True):
         L.check(self._lib, self._lib.bnm_ctx_set_host_tuning(self._h, mode, copy_threads, 1 if spin else 0), "bnm_ctx_set_host_tuning")

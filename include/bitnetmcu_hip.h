@@ -149,7 +149,9 @@ BNM_API int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uin
  * host copy threads, H2D / compute / D2H of consecutive chunks overlapped. */
 BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls,
                            int32_t *logits);
-/* CNN front end: 1 (default) conv1 on the matrix cores, 0 the all-VALU kernel (kept for A/B measurements). */
+/* CNN front end: 1 (default) conv1 on the matrix cores, waves take batches of 8 images from a device-wide work counter;
+ * 2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the all-VALU kernel
+ * of round 1 (2, 100 + g and 0 are kept for A/B measurements). */
 BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
 /* Ternary ALU kernel: 2 (default) weights streamed through double-buffered scalar registers, two images per lane;
  * 1 the same with one image per lane; 0 round 1's kernel (kept for A/B measurements). */
