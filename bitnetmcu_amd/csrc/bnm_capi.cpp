@@ -161,7 +161,12 @@ struct bnm_ctx {
     int *cnn_wtab = nullptr;       // per-channel weight table of the conv1-on-MFMA front end
     int cnn_variant = 1;           // 1: conv1 on the matrix cores (default), 0: the all-VALU kernel of round 1
     uint32_t cnn_grab = 8;         // images a wave of the MFMA front end takes from the work counter at a time (0: fixed shares)
-    uint32_t *cnn_counter = nullptr;
+    // work counters of the persistent kernels that hand their work out dynamically (CNN front end, streamed ternary kernel):
+    // a ring of words, one per launch, so that launches queued on different streams never share one
+    uint32_t *counters = nullptr;
+    uint32_t counter_next = 0;
+    bool tern_dynamic = true;
+    uint32_t *next_counter() { return counters ? counters + 16u * (counter_next++ % 64u) : nullptr; }
     // fused MFMA path: shape-specialised kernels (register-resident weights, bnm_fused_fc.hip) and / or the generic
     // kernel (run-time widths, weights in LDS, bnm_fused_generic.hip; variant id BNM_FUSED_GENERIC)
     bool fused_ok = false;      // at least one of the two can run this model
@@ -260,12 +265,14 @@ int ctx_build(bnm_ctx *c) {
             if (int e = dev_alloc(c, &p, tab.size() * sizeof(int))) return e;
             HIP_TRY(hipMemcpy(p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
             c->cnn_wtab = (int *)p;
-            void *q = nullptr;
-            if (int e = dev_alloc(c, &q, 256)) return e;
-            c->cnn_counter = (uint32_t *)q;
         }
         width = c->channels * 4u;
         li = 5;
+    }
+    {
+        void *q = nullptr;
+        if (int e = dev_alloc(c, &q, 64 * 64)) return e;
+        c->counters = (uint32_t *)q;
     }
     const uint32_t in_width = width;
     bool all_known = true, any_fp130 = false, all_tern = true;
@@ -467,6 +474,7 @@ int run_ternary(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int
     a.logits = d_logits;
     a.wstream = c->tern_stream;
     a.variant = c->tern_variant;
+    a.counter = c->tern_dynamic ? c->next_counter() : nullptr;
     HIP_TRY(bnmk_ternary_alu(a, c->grid_blocks, s));
     return BNM_OK;
 }
@@ -500,7 +508,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         int32_t *feat = (c->channels > 64 || d_acts_tap) ? (int32_t *)c->cnn_feat.p : nullptr;
         int8_t *acts = (int8_t *)c->cnn_feat.p + (size_t)cn * W * 4;
         HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,
-                               c->channels, 4, acts, AS, feat, c->cnn_counter, c->cnn_grab, s));
+                               c->channels, 4, acts, AS, feat, c->next_counter(), c->cnn_grab, s));
         uint32_t *cls = d_cls + off;
         int32_t *lg = d_logits ? d_logits + off * ncls : nullptr;
         if (d_acts_tap)
@@ -660,9 +668,10 @@ int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
 }
 
 int bnm_ctx_set_ternary_variant(bnm_ctx *c, int variant) {
-    if (!c || variant < 0 || variant > 2) return fail(BNM_EINVAL, "bad argument");
+    if (!c || variant < 0 || (variant > 2 && variant != 11 && variant != 12)) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
-    c->tern_variant = variant;
+    c->tern_variant = variant % 10;
+    c->tern_dynamic = variant < 10;
     return BNM_OK;
 }
 

@@ -110,6 +110,7 @@ struct BnmTernArgs {
     int32_t *logits;
     const int *wstream;     // bnmk_ternary_stream_build's output (variants 1, 2)
     int variant;            // 0: round 1's kernel; 1: streamed weights, one image per lane; 2: two images per lane
+    uint32_t *counter;      // device word the streamed kernels hand image groups out from (zeroed by the launcher); nullptr: fixed stride
 };
 uint32_t bnmk_ternary_stream_dwords(const uint32_t n_out[4]);
 hipError_t bnmk_ternary_stream_build(const BnmTernArgs &a, int *d_stream, hipStream_t s);

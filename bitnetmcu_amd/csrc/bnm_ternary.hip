@@ -125,24 +125,45 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 struct TernW {
     sx16 lo, hi;   // one chunk: dword d = 8 * neuron-in-quad + activation dword in the K-slice
 };
+// The two chunk buffers live in FIXED scalar registers - A = s[36:67], B = s[68:99] - named in the constraints of the issue
+// and of the wait.  With ordinary "s" operands hipcc is free to give the issue's output and the wait's tied operand
+// different registers and to copy one into the other AHEAD of the wait, i.e. while the load is still in flight (it did, in
+// the class loop, as soon as the kernel grew a little: wrong class ids).  Pinned, the value never moves between the two.
 // issue (not wait for) the two cache lines of the chunk at p + 128 * OFF bytes
-template <int OFF>
+template <bool ISA, int OFF>
 BNM_DEVICE void tern_issue(TernW &w, const int *p) {
-    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"
-                 : "=&s"(w.lo), "=&s"(w.hi)
-                 : "s"(p), "i"(OFF * 128), "i"(OFF * 128 + 64));
+    if constexpr (ISA)
+        asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"
+                     : "=&{s[36:51]}"(w.lo), "=&{s[52:67]}"(w.hi) : "s"(p), "i"(OFF * 128), "i"(OFF * 128 + 64));
+    else
+        asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"
+                     : "=&{s[68:83]}"(w.lo), "=&{s[84:99]}"(w.hi) : "s"(p), "i"(OFF * 128), "i"(OFF * 128 + 64));
 }
-BNM_DEVICE void tern_land(TernW &w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.lo), "+s"(w.hi)); }
+template <bool ISA>
+BNM_DEVICE void tern_land(TernW &w) {
+    if constexpr (ISA) asm volatile("s_waitcnt lgkmcnt(0)" : "+{s[36:51]}"(w.lo), "+{s[52:67]}"(w.hi));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+{s[68:83]}"(w.lo), "+{s[84:99]}"(w.hi));
+}
 // the same, also naming the running sums: pins the chunk's dots between the issue and this wait (left free, hipcc sinks
 // a class quad's dots into the `class < n_classes` blocks behind all the waits and keeps every chunk live)
-template <int G>
+template <bool ISA, int G>
 BNM_DEVICE void tern_land(TernW &w, int (&acc)[4][G]) {
-    if constexpr (G == 1)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.lo), "+s"(w.hi), "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]));
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+s"(w.lo), "+s"(w.hi), "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]),
-                       "+v"(acc[0][1]), "+v"(acc[1][1]), "+v"(acc[2][1]), "+v"(acc[3][1]));
+    static_assert(G == 1 || G == 2, "one or two images per lane");
+    if constexpr (G == 1) {
+        if constexpr (ISA)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+{s[36:51]}"(w.lo), "+{s[52:67]}"(w.hi), "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+{s[68:83]}"(w.lo), "+{s[84:99]}"(w.hi), "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]));
+    } else {
+        if constexpr (ISA)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+{s[36:51]}"(w.lo), "+{s[52:67]}"(w.hi), "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]),
+                           "+v"(acc[0][1]), "+v"(acc[1][1]), "+v"(acc[2][1]), "+v"(acc[3][1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+{s[68:83]}"(w.lo), "+{s[84:99]}"(w.hi), "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]),
+                           "+v"(acc[0][1]), "+v"(acc[1][1]), "+v"(acc[2][1]), "+v"(acc[3][1]));
+    }
 }
 
 template <int D>
@@ -174,11 +195,11 @@ BNM_DEVICE void tern_quad(const int (&x)[G][NX], TernW &a, TernW &b, const int *
         constexpr bool cur_a = ((c & 1) == 0) == AFIRST;
         TernW &cur = cur_a ? a : b;
         TernW &nxt = cur_a ? b : a;
-        tern_issue<c + 1>(nxt, p);
+        tern_issue<!cur_a, c + 1>(nxt, p);        // `a` is buffer A, `b` is buffer B: the next chunk goes to the one not in use
         __builtin_amdgcn_sched_barrier(0);
         tern_chunk<G, NX, 8 * c>(x, cur, acc);
         __builtin_amdgcn_sched_barrier(0);
-        tern_land<G>(nxt, acc);
+        tern_land<!cur_a, G>(nxt, acc);
     });
 }
 
@@ -283,14 +304,19 @@ BNM_DEVICE void tern_layer_s(const int (&x)[G][NX], TernW &a, TernW &b, const in
 template <int G, int H1, int H2, int H3, int QL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 1 ? 3 : 2, G == 1 ? 3 : 2)))
 void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const int *__restrict__ wstream,
-                           uint32_t n_classes, uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out) {
+                           uint32_t n_classes, uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out,
+                           uint32_t *__restrict__ counter) {
     static_assert(H1 == H2 && H2 == H3, "one LDS column geometry for all hidden layers");
     __shared__ uint32_t s_col[G * QL * 2 * 64];
     const int lane = threadIdx.x;
     uint32_t *col = s_col + lane;
+    // Groups of 64 G images: a wave's first group is static, every later one comes from a device-wide counter (zeroed by the
+    // launcher).  With a fixed stride the two waves of a SIMD do not finish together - the arbiter favours the older one -
+    // and the tail of the launch runs at one wave per SIMD; counter == nullptr keeps the fixed stride.
     const uint64_t stride = (uint64_t)gridDim.x * (64ull * G);
     uint64_t base = (uint64_t)blockIdx.x * (64ull * G);
     if (base >= n) return;
+    int nxt_v = 0;
 
     int x0[G][64];
     auto request = [&](uint64_t b) {
@@ -308,16 +334,20 @@ void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const 
     };
     request(base);
     TernW wa, wb;
-    tern_issue<0>(wa, wstream);
-    tern_land(wa);
+    tern_issue<true, 0>(wa, wstream);
+    tern_land<true>(wa);
     const uint32_t nq4 = (n_classes + 3u) / 4u;
-    for (; base < n; base += stride) {
+    while (base < n) {
         const int *p = wstream;
+        if (counter != nullptr && lane == 0)
+            nxt_v = (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t tail[G][(H1 / 4 - QL) * 2 + 1];
         int mx[G];
         int a1[G][H1 / 4], a2[G][H2 / 4], a3[G][H3 / 4];
         tern_layer_s<G, 64, 64, H1, QL>(x0, wa, wb, p, col, tail, mx);
-        if (base + stride < n) request(base + stride);      // lands under layers 2-4
+        const uint64_t next_base = counter != nullptr
+            ? ((uint64_t)gridDim.x + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(nxt_v)) * (64ull * G) : base + stride;
+        if (next_base < n) request(next_base);      // lands under layers 2-4
         tern_norm<G, H1, QL>(col, tail, mx, a1);
         tern_layer_s<G, H1 / 4, H1 / 4, H2, QL>(a1, wa, wb, p, col, tail, mx);
         tern_norm<G, H2, QL>(col, tail, mx, a2);
@@ -369,6 +399,7 @@ void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const 
             const uint64_t img = base + (uint64_t)(g * 64 + lane);
             if (img < n) cls_out[img] = bi[g];
         }
+        base = next_base;
     }
 }
 
@@ -423,13 +454,15 @@ hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s
                                                                            a.rows[3], a.stride[0], a.stride[1], a.stride[2],
                                                                            a.stride[3], a.n_out[3], a.cls, a.logits);
     } else {
-        if (!a.wstream) return hipErrorInvalidValue;
+        if (!a.wstream || want >= (1ull << 32)) return hipErrorInvalidValue;
+        if (a.counter)
+            if (hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s); e != hipSuccess) return e;
         if (G == 2)
             ternary_stream_kernel<2, 96, 96, 96, 20><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.wstream, a.n_out[3],
-                                                                                         a.cls, a.logits);
+                                                                                         a.cls, a.logits, a.counter);
         else
             ternary_stream_kernel<1, 96, 96, 96, 24><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.wstream, a.n_out[3],
-                                                                                         a.cls, a.logits);
+                                                                                         a.cls, a.logits, a.counter);
     }
     return hipGetLastError();
 }

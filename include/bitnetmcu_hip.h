@@ -153,8 +153,9 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
  * 2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the all-VALU kernel
  * of round 1 (2, 100 + g and 0 are kept for A/B measurements). */
 BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
-/* Ternary ALU kernel: 2 (default) weights streamed through double-buffered scalar registers, two images per lane;
- * 1 the same with one image per lane; 0 round 1's kernel (kept for A/B measurements). */
+/* Ternary ALU kernel: 2 (default) weights streamed through double-buffered scalar registers, two images per lane, image
+ * groups handed out from a device-wide work counter; 1 the same with one image per lane; 12 / 11: as 2 / 1 with a fixed
+ * stride per wave; 0 round 1's kernel (1, 11, 12 and 0 are kept for A/B measurements). */
 BNM_API int bnm_ctx_set_ternary_variant(bnm_ctx *c, int variant);
 /* Tuning of the host-pointer path.  mode 0 (default): pipelined page-locked staging; 1: the HIP runtime's own pageable copies,
  * chunk by chunk.  copy_threads: host threads of the staging copy (0 = default).  spin: poll the page-locked result words of the

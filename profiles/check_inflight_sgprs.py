@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Static check of the streamed ternary kernels (no GPU needed): between an asm-issued s_load_dwordx16 and the s_waitcnt
+lgkmcnt(0) that retires it, no instruction may read or write the destination scalar registers (a compiler copy or spill
+there would move a value that has not landed).  Reads bitnetmcu_amd/_build/bnm_ternary.o; exit status 1 on a violation."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def disasm(obj):
+    with tempfile.TemporaryDirectory() as t:
+        fat, co = os.path.join(t, "fat"), os.path.join(t, "k.co")
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj])
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               f"--input={fat}", f"--output={co}"])
+        return subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
+
+
+def sregs(text):
+    out = set()
+    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bs(\d+)\b", text):
+        out.add(int(a))
+    return out
+
+
+def main():
+    asm = disasm(os.path.join(REPO, "bitnetmcu_amd", "_build", "bnm_ternary.o"))
+    bad, kernel, inflight, loads = [], None, set(), 0
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            kernel, inflight = m.group(1), set()
+            continue
+        if "ternary_stream_kernel" not in (kernel or ""):
+            continue
+        ins = line.split("//")[0].strip()
+        if not ins:
+            continue
+        if ins.startswith("s_load_dwordx16"):
+            dst = re.match(r"s_load_dwordx16 s\[(\d+):(\d+)\]", ins)
+            inflight |= set(range(int(dst.group(1)), int(dst.group(2)) + 1))
+            loads += 1
+            continue
+        if ins.startswith("s_waitcnt") and "lgkmcnt(0)" in ins:
+            inflight = set()
+            continue
+        if inflight and sregs(ins) & inflight:
+            bad.append((kernel[:40], ins))
+    print(f"{loads} asm-issued chunk loads checked, {len(bad)} instructions touch registers of a load in flight")
+    for b in bad[:20]:
+        print("  ", b)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -53,6 +53,8 @@ def main():
         "wait_B_cycles_per_iteration_median": float(np.median(wb / it)),
         "wait_A_share_of_loop": float(np.median(wa / loop)), "wait_B_share_of_loop": float(np.median(wb / loop)),
         "wait_A_p95_share": float(np.percentile(wa / loop, 95)), "wait_B_p95_share": float(np.percentile(wb / loop, 95)),
+        "loop_cycles_percentiles_1_10_25_50_75_90_99_100": [float(x) for x in np.percentile(loop, [1, 10, 25, 50, 75, 90, 99, 100])],
+        "iterations_percentiles_1_50_99": [float(x) for x in np.percentile(it, [1, 50, 99])],
         "shader_clock_GHz": float(np.median(loop) / (e0.elapsed_time(e1) * 1e6)),
         "src_wrap": os.environ.get("BNM_DIAG_SRC_WRAP", "0"),
     }

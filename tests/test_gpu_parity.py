@@ -30,7 +30,7 @@ def paths_for(ctx):
             pass
     try:
         ctx.set_path(b.PATH_TERNARY_ALU)
-        for tv in (2, 1, 0):     # streamed weights with two / one image per lane, round 1's kernel
+        for tv in (2, 1, 12, 11, 0):     # streamed weights (two / one image per lane; work counter / fixed stride), round 1's kernel
             def tern(c, tv=tv):
                 c.set_path(b.PATH_TERNARY_ALU)
                 c.set_ternary_variant(tv)
@@ -358,7 +358,7 @@ def test_ternary_alu_kernels_extreme_sums(signs, gpu_ok, orc):
     want = om.infer(x, logits=True)
     ctx = b.Context(model)
     ctx.set_path(b.PATH_TERNARY_ALU)
-    for tv in (2, 1, 0):
+    for tv in (2, 1, 12, 11, 0):
         ctx.set_ternary_variant(tv)
         for n in (len(x), 129, 128, 127, 65, 1):
             got = ctx.infer(x[:n], logits=True)
