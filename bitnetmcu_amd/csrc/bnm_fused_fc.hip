@@ -59,7 +59,12 @@ BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 
 //                 issuing the second DMA in front of the MFMAs instead serialises the wave (profiles/r01).
 // Tried and dropped in round 1 (tag r01-experiments-all-variants): 8-wave workgroups with staggered halves, a
 // software-pipelined MFMA||VALU form, three waves per SIMD with weights in LDS, split half-tile refills.
-enum { FUSED_DIRECT = 0, FUSED_LDSDMA = 1, FUSED_LDSDMA2 = 2, FUSED_DUAL = 3 };
+//   3  DUAL       two tiles per wave per iteration (fused_fc_dual_kernel), fixed stride per wave
+//   5  DUAL_SHARED  the same loop in ONE 8-wave workgroup per CU whose waves take their pairs from a counter in LDS (4 is the
+//                 generic kernel's id).  The SIMD arbiter favours the older of a SIMD's two waves: with a fixed stride the
+//                 favoured waves finish after ~65 % of the launch and the rest of it runs at one wave per SIMD
+//                 (profiles/r02/wait_timing_hbm_r02s_fixed_stride.json: 4.6 M .. 7.2 M cycles for the same 763 iterations).
+enum { FUSED_DIRECT = 0, FUSED_LDSDMA = 1, FUSED_LDSDMA2 = 2, FUSED_DUAL = 3, FUSED_DUAL_SHARED = 5 };
 
 template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT, int NC8>
 __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
@@ -227,17 +232,31 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
 // the remainder to variant 2; the refill after the last pair re-reads that pair), so the scheduler can place one
 // tile's ReLUNorm VALU work between the other tile's MFMAs.  Weights stay in registers once for both tiles.
 //
-template <int M1, int M2, int M3, int M4, bool DBL, int NC8>
-__global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const int8_t *__restrict__ images, uint64_t n,
+template <int M1, int M2, int M3, int M4, bool DBL, int NC8, int WPB = FUSED_WPB>
+__global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                           const i32x4 *__restrict__ frags,
                                                                           uint32_t n_classes, uint32_t *__restrict__ cls_out,
                                                                           int32_t *__restrict__ logits_out,
                                                                           uint64_t src_wrap) {
     constexpr int KT0 = 8;
-    __shared__ __attribute__((aligned(1024))) char smem[FUSED_WPB * 2 * FUSED_TILE_BYTES];
+    constexpr bool SHARED = WPB == 8;          // one workgroup per CU, pairs handed out from s_next
+    __shared__ __attribute__((aligned(1024))) char smem[WPB * 2 * FUSED_TILE_BYTES];
+    __shared__ uint32_t s_next;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
+    if constexpr (SHARED) {
+        if (threadIdx.x == 0) s_next = 0;
+        __syncthreads();
+    }
+    // the workgroup's m-th pair is pair m * gridDim.x + blockIdx.x; ONE lane performs the LDS atomic (with all 64 lanes on the
+    // same word it occupied the LDS pipe for 64 cycles per iteration, a quarter of what the tile traffic itself needs)
+    auto take = [&]() -> uint64_t {
+        uint32_t m = 0;
+        if (lane == 0) m = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+        return (uint64_t)m * gridDim.x + blockIdx.x;
+    };
 
     AFrags<M1, KT0> A1;
     AFrags<M2, M1> A2;
@@ -250,8 +269,8 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
     if constexpr (M4 > 0) A4.load(fp, lane);
 
     const uint64_t n_pairs = n >> 6;            // the launcher guarantees n % 64 == 0
-    const uint64_t stride = (uint64_t)gridDim.x * FUSED_WPB;
-    uint64_t pair = (uint64_t)blockIdx.x * FUSED_WPB + wave;
+    const uint64_t stride = (uint64_t)gridDim.x * WPB;
+    uint64_t pair = SHARED ? take() : (uint64_t)blockIdx.x * WPB + wave;
 
     uint32_t voff[4];
 #pragma unroll
@@ -294,9 +313,10 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
     uint64_t t_wait_a = 0, t_wait_b = 0, t_iters = 0;
     const uint64_t t_start = __builtin_readcyclecounter();
 #endif
-    for (; pair < n_pairs; pair += stride) {
+    while (pair < n_pairs) {
         // the refill after the last pair re-reads that pair (keeps the wait counts constant and the body branch-free)
-        const uint64_t next = pair + stride < n_pairs ? pair + stride : pair;
+        const uint64_t cand = SHARED ? take() : pair + stride;
+        const uint64_t next = cand < n_pairs ? cand : pair;
         // outstanding, oldest first: slot 0 (8 pieces), [the deferred store], slot 1 (8 pieces).
         // Loads retire in order among themselves, so "<= 8 left" implies slot 0 has landed.
 #ifdef BNM_DIAG_TIMING
@@ -369,13 +389,14 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_dual_kernel(const 
         // one 256-byte store per pair, issued in the next iteration (or after the loop)
         img_prev = h ? imgB : imgA;
         cls_prev = h ? clsB : clsA;
+        pair = cand;
     }
     if (any) cls_out[img_prev] = cls_prev;
     bnm_wait_vmcnt<0>();   // LDS-DMA still in flight must not outlive the workgroup's LDS allocation
 #ifdef BNM_DIAG_TIMING
     // the logits buffer is reused as the record array: 4 x uint64 per wave {loop cycles, wait A, wait B, iterations}
     if (logits_out && lane == 0) {
-        uint64_t *rec = (uint64_t *)logits_out + 4ull * ((uint64_t)blockIdx.x * FUSED_WPB + (uint64_t)wave);
+        uint64_t *rec = (uint64_t *)logits_out + 4ull * ((uint64_t)blockIdx.x * WPB + (uint64_t)wave);
         rec[0] = __builtin_readcyclecounter() - t_start;
         rec[1] = t_wait_a;
         rec[2] = t_wait_b;
@@ -399,12 +420,16 @@ struct FusedEntry {
     FUSED(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR, 2), FUSED(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR, 0)
 const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
+    { {8, {2, 2, 2, 1}, false, true, 2}, FUSED_DUAL_SHARED, fused_fc_dual_kernel<2, 2, 2, 1, true, 2, 8> },
+    { {8, {2, 2, 2, 1}, false, true, 0}, FUSED_DUAL_SHARED, fused_fc_dual_kernel<2, 2, 2, 1, true, 0, 8> },
     { {8, {2, 2, 2, 1}, false, true, 2}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, true, 2> },
     { {8, {2, 2, 2, 1}, false, true, 0}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, true, 0> },
     FUSED_ANY_AND_10(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA2),
     FUSED_ANY_AND_10(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA),
     FUSED(8, 2, 2, 2, 1, false, true, FUSED_DIRECT, 0),
     // same shape with codecs whose weights cannot be doubled in int8 (8-bit two's complement, FP1.3.0 without +128)
+    { {8, {2, 2, 2, 1}, false, false, 2}, FUSED_DUAL_SHARED, fused_fc_dual_kernel<2, 2, 2, 1, false, 2, 8> },
+    { {8, {2, 2, 2, 1}, false, false, 0}, FUSED_DUAL_SHARED, fused_fc_dual_kernel<2, 2, 2, 1, false, 0, 8> },
     { {8, {2, 2, 2, 1}, false, false, 2}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, false, 2> },
     { {8, {2, 2, 2, 1}, false, false, 0}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, false, 0> },
     FUSED_ANY_AND_10(8, 2, 2, 2, 1, false, false, FUSED_LDSDMA2),
@@ -413,6 +438,7 @@ const FusedEntry kFused[] = {
     // (FP1.3.0 models that really contain a +128 weight need a second weight plane: 2 x the A fragments do not fit the
     // register file without spilling, so those go to the generic kernel, whose weights live in LDS)
     // FC 256-16-16-10 2bitsym (mcu/BitNetMCU_model_1k.h)
+    { {8, {1, 1, 1, 0}, false, true, 2}, FUSED_DUAL_SHARED, fused_fc_dual_kernel<1, 1, 1, 0, true, 2, 8> },
     { {8, {1, 1, 1, 0}, false, true, 2}, FUSED_DUAL, fused_fc_dual_kernel<1, 1, 1, 0, true, 2> },
     FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA2, 0),
     FUSED_ANY_AND_10(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA),
@@ -453,13 +479,15 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
     const FusedEntry *e = find_fused(sh, variant);
     if (!e) return hipErrorInvalidValue;
     if (a.n == 0) return hipSuccess;
-    if (variant == FUSED_DUAL) {
+    if (variant == FUSED_DUAL || variant == FUSED_DUAL_SHARED) {
         // whole 64-image pairs go to the dual-tile kernel, the remainder (< 64 images) to variant 2
         const uint64_t n_main = a.n & ~63ull;
         if (n_main) {
-            uint64_t want = ((n_main >> 6) + FUSED_WPB - 1) / FUSED_WPB;
-            uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * 2ull;
-            e->fn<<<dim3((unsigned)(want < cap ? want : cap)), dim3(64 * FUSED_WPB), 0, s>>>(
+            // fixed stride: two 4-wave workgroups per CU; shared counter: ONE 8-wave workgroup per CU
+            const uint64_t wpb = variant == FUSED_DUAL_SHARED ? 8 : FUSED_WPB;
+            uint64_t want = ((n_main >> 6) + wpb - 1) / wpb;
+            uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * (variant == FUSED_DUAL_SHARED ? 1ull : 2ull);
+            e->fn<<<dim3((unsigned)(want < cap ? want : cap)), dim3((unsigned)(64 * wpb)), 0, s>>>(
                 a.images, n_main, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap);
             hipError_t err = hipGetLastError();
             if (err != hipSuccess) return err;

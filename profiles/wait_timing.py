@@ -29,7 +29,7 @@ def main():
     n = int(os.environ.get("N", 100_000_000))
     model = util.load_golden_model("fc_4bitsym_64")
     ctx = b.Context(model)
-    ctx.set_tuning(variant=3)
+    ctx.set_tuning(variant=int(os.environ.get("VARIANT", 3)))
     imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
     synth.fill_device(imgs, first=0, dist=b.DIST_U)
     cls = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -42,7 +42,7 @@ def main():
     ctx.infer_device(imgs, cls, rec)
     e1.record()
     torch.cuda.synchronize()
-    waves = 2 * 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    waves = 2 * 4 * torch.cuda.get_device_properties(0).multi_processor_count   # both layouts: 8 waves per CU
     r = rec.view(-1)[: waves * 8].cpu().numpy().view(np.uint64).reshape(waves, 4).astype(np.float64)
     r = r[r[:, 3] > 0]
     loop, wa, wb, it = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
