@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--cnn-variant", type=int, default=-1, help="CNN front end: 1 conv1 on MFMA (default), 0 all-VALU kernel of round 1")
     ap.add_argument("--ternary-variant", type=int, default=-1,
                     help="ternary ALU kernel: 2 streamed weights, two images per lane (default), 1 one image per lane, 0 round 1's kernel")
+    ap.add_argument("--work-batch", type=int, default=0, help="generic fused kernel: tiles per take from the work counter (0 = default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -227,6 +228,8 @@ def main():
         ctx.set_cnn_variant(a.cnn_variant)
     if a.ternary_variant >= 0:
         ctx.set_ternary_variant(a.ternary_variant)
+    if a.work_batch > 0:
+        ctx.set_work_batch(a.work_batch)
 
     # ---- resident workload: this rank's shard of the global synthetic image stream --------------------
     if a.scaling == "weak":

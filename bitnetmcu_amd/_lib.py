@@ -58,6 +58,7 @@ PROTOTYPES = {
     "bnm_ctx_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
     "bnm_ctx_set_cnn_variant": (C.c_int, [_vp, C.c_int]),
     "bnm_ctx_set_ternary_variant": (C.c_int, [_vp, C.c_int]),
+    "bnm_ctx_set_work_batch": (C.c_int, [_vp, C.c_int]),
     "bnm_ctx_set_host_tuning": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "bnm_infer_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "bnm_infer_host": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),

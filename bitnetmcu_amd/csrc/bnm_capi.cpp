@@ -166,6 +166,7 @@ struct bnm_ctx {
     uint32_t *counters = nullptr;
     uint32_t counter_next = 0;
     bool tern_dynamic = true;
+    uint32_t work_batch = 0;      // tiles / pairs a wave of the fused kernels takes from the work counter at a time (0 = kernel default)
     uint32_t *next_counter() { return counters ? counters + 16u * (counter_next++ % 64u) : nullptr; }
     // fused MFMA path: shape-specialised kernels (register-resident weights, bnm_fused_fc.hip) and / or the generic
     // kernel (run-time widths, weights in LDS, bnm_fused_generic.hip; variant id BNM_FUSED_GENERIC)
@@ -415,7 +416,8 @@ int ctx_build(bnm_ctx *c) {
 // ---- whole-model launches on device data -----------------------------------------------------------
 int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32_t *d_logits, hipStream_t s) {
     if (c->variant == BNM_FUSED_GENERIC) {
-        HIP_TRY(bnmk_fused_generic(c->gdesc, c->shape.dbl, c->grid_blocks, d_in, n, c->gfrags, d_cls, d_logits, s));
+        HIP_TRY(bnmk_fused_generic(c->gdesc, c->shape.dbl, c->grid_blocks, d_in, n, c->gfrags, d_cls, d_logits, c->next_counter(),
+                                   c->work_batch, s));
         return BNM_OK;
     }
     BnmFusedArgs a{};
@@ -664,6 +666,13 @@ int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
     std::lock_guard<std::mutex> g(c->mu);
     c->cnn_variant = variant == 0 ? 0 : 1;
     c->cnn_grab = variant == 2 ? 0u : variant > 100 ? (uint32_t)(variant - 100) : 8u;
+    return BNM_OK;
+}
+
+int bnm_ctx_set_work_batch(bnm_ctx *c, int tiles) {
+    if (!c || tiles < 0 || tiles > 4096) return fail(BNM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->work_batch = (uint32_t)tiles;
     return BNM_OK;
 }
 

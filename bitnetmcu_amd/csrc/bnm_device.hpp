@@ -88,3 +88,20 @@ BNM_DEVICE int decode_weight(const void *packed, int bpw, uint32_t n_input, uint
     return decode_field(bpw, f);
 }
 
+
+// =================================================================================================
+// Device-wide work counter for persistent kernels, on the SCALAR unit.
+// Why: the SIMD arbiter favours its oldest wave, so waves with equal fixed shares finish one after the other and the end of a
+// launch runs at one wave per SIMD ("work distribution").  Handing the work out from a counter keeps every wave
+// busy until the work runs out.  s_atomic_add ... glc returns the counter's previous value in a scalar register: no VGPR, no
+// EXEC change, no entry in the vmcnt queue that the LDS-DMA kernels count by hand.  profiles/probes/s_atomic_probe.hip: on
+// gfx950 it is coherent across the whole device (512 workgroups x 8 waves x 64 takes on one word: no duplicate, none lost).
+// The take is split into issue and wait so that its round trip (1-2 us) runs under the caller's arithmetic; in between the
+// result register must not move, so both statements name the SAME fixed register (s95; the streamed ternary kernels use the
+// same technique for their weight buffers).  The compiler's own lgkmcnt waits merely become conservative while the take is
+// outstanding (the counter is shared with LDS operations).  The counter word is zeroed by the launcher ahead of every launch.
+// =================================================================================================
+BNM_DEVICE void work_take_issue(uint32_t &r, uint32_t *counter, uint32_t amount) {
+    asm volatile("s_mov_b32 %0, %2\n\ts_atomic_add %0, %1, 0x0 glc" : "=&{s95}"(r) : "s"(counter), "s"(amount) : "memory");
+}
+BNM_DEVICE void work_take_wait(uint32_t &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+{s95}"(r)::"memory"); }

@@ -5,7 +5,8 @@
 
 #define DECL(NAME)                                                                                                       \
     hipError_t NAME(uint32_t kt0, uint32_t sp, bool dbl, unsigned blocks, unsigned threads, unsigned lds, hipStream_t s,   \
-                    const int8_t *images, uint64_t n, const void *frags, const BnmGenericDesc &d, uint32_t *cls, int32_t *logits)
+                    const int8_t *images, uint64_t n, const void *frags, const BnmGenericDesc &d, uint32_t *cls, int32_t *logits, \
+                    uint32_t *counter, uint32_t batch)
 DECL(bnmk_generic_launch_m2);
 DECL(bnmk_generic_launch_m4);
 DECL(bnmk_generic_launch_m8);
@@ -14,7 +15,7 @@ DECL(bnmk_generic_launch_m8);
 namespace {
 constexpr uint32_t kLdsBytes = 160u * 1024u;
 typedef hipError_t (*launch_fn)(uint32_t, uint32_t, bool, unsigned, unsigned, unsigned, hipStream_t, const int8_t *, uint64_t,
-                                const void *, const BnmGenericDesc &, uint32_t *, int32_t *);
+                                const void *, const BnmGenericDesc &, uint32_t *, int32_t *, uint32_t *, uint32_t);
 struct ClassInfo {
     launch_fn launch;
 };
@@ -63,20 +64,24 @@ bool bnmk_generic_supported(const BnmGenericDesc &d, bool dbl) {
     if (d.sp == 2 && dbl) return false;
     ClassInfo c;
     if (!class_of(d.mmax, c)) return false;
-    if (c.launch(d.KT0, d.sp, dbl, 0, 0, 0, nullptr, nullptr, 0, nullptr, d, nullptr, nullptr) != hipSuccess) return false;
+    if (c.launch(d.KT0, d.sp, dbl, 0, 0, 0, nullptr, nullptr, 0, nullptr, d, nullptr, nullptr, nullptr, 1) != hipSuccess) return false;
     return generic_waves(c, d) >= 4;
 }
 
 hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int grid_blocks, const int8_t *images, uint64_t n,
-                              const void *frags, uint32_t *cls, int32_t *logits, hipStream_t s) {
+                              const void *frags, uint32_t *cls, int32_t *logits, uint32_t *counter, uint32_t batch, hipStream_t s) {
     ClassInfo c;
     if (!class_of(d.mmax, c)) return hipErrorInvalidValue;
     const uint32_t waves = generic_waves(c, d);
     if (waves < 4) return hipErrorInvalidValue;
     if (!n) return hipSuccess;
+    if (n >= (1ull << 36) || !counter) return hipErrorInvalidValue;      // 32-bit tile indices in the kernel
+    if (!batch) batch = 16;     // one word serves ~87 M takes per second device-wide: 3.1 M tiles per 1e8 images in >= 16s stay well below it
     const uint32_t lds = d.w_bytes + waves * 1024u * d.KT0;
     const uint64_t n_tiles = (n + 31ull) / 32ull;
-    uint64_t want = (n_tiles + waves - 1) / waves;
+    uint64_t want = (n_tiles + (uint64_t)waves * batch - 1) / ((uint64_t)waves * batch);
     uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus();   // one workgroup per CU
-    return c.launch(d.KT0, d.sp, dbl, (unsigned)(want < cap ? want : cap), 64u * waves, lds, s, images, n, frags, d, cls, logits);
+    if (hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), s); e != hipSuccess) return e;
+    return c.launch(d.KT0, d.sp, dbl, (unsigned)(want < cap ? want : cap), 64u * waves, lds, s, images, n, frags, d, cls, logits,
+                    counter, batch);
 }

@@ -175,7 +175,8 @@ template <int MMAX, int KT0, int SP, bool DBL, int WPS>
 __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                      const i32x4 *__restrict__ frags, BnmGenericDesc d,
                                                                      uint32_t *__restrict__ cls_out,
-                                                                     int32_t *__restrict__ logits_out) {
+                                                                     int32_t *__restrict__ logits_out, uint32_t *__restrict__ counter,
+                                                                     uint32_t batch) {
     using G = RowGeom<32 * KT0>;
     constexpr int ROW = 32 * KT0;
     constexpr int KC = KT0 < 8 ? KT0 : 8;          // layer-1 K-steps held in VGPRs at a time
@@ -194,12 +195,12 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
     // DMA piece t, lane l: LDS byte 1024t + 16l = row t*RPP + rl, slot c'; source slot c = c' ^ mask(row)
     // B operand of K-step s: image j, global slot 2s+h -> LDS slot (2s+h) ^ mask(j): XOR 32*s into the byte offset (rd_off)
 
-    const uint64_t n_tiles = (n + 31ull) >> 5;
+    const uint32_t n_tiles = (uint32_t)((n + 31ull) >> 5);       // the launcher refuses n >= 2^36
     // (the per-use copies below keep hipcc from hoisting dozens of derived per-piece / per-K-step address registers out of
     // the persistent loop, where they would only raise the register pressure of the arithmetic)
-    auto dma_tile = [&](uint64_t t) {
-        const int8_t *base = images + t * (uint64_t)G::TILE;
-        const uint64_t first = t << 5;
+    auto dma_tile = [&](uint32_t t) {
+        const int8_t *base = images + (uint64_t)t * (uint64_t)G::TILE;
+        const uint64_t first = (uint64_t)t << 5;
         uint32_t l = (uint32_t)lane;
         asm volatile("" : "+v"(l));
         const uint32_t rl = (16u * l) / (uint32_t)ROW, cs = l & (uint32_t)(G::SLOTS - 1);
@@ -227,18 +228,23 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         }
     };
 
-    const uint64_t stride = (uint64_t)gridDim.x * nwaves;
-    uint64_t tile = (uint64_t)blockIdx.x * nwaves + wave;
+    // ---- tiles in batches of `batch` consecutive ones: a wave's first batch is static, every later one comes from the
+    // device-wide counter (work_take_*; the wave that runs out of batch asks while it still has one tile to go)
+    const uint32_t total_waves = gridDim.x * nwaves;
+    uint32_t tile = (blockIdx.x * nwaves + wave) * batch, left = batch - 1u;      // `left`: tiles of the batch after this one
+    uint32_t taken = 0;
     if (tile < n_tiles) dma_tile(tile);
 
     const uint32_t M1 = d.M[0], M2 = d.M[1], M3 = d.M[2], M4 = d.M[3];
     const uint32_t K2 = d.KTP[1], K3 = d.KTP[2], K4 = d.KTP[3];
-    for (; tile < n_tiles; tile += stride) {
+    while (tile < n_tiles) {
+        if (left == 0u) work_take_issue(taken, counter, batch);
         bnm_wait_vmcnt<0>();
         // every per-lane quantity of the iteration is re-derived from this copy of the lane id (a handful of VALU per tile):
         // nothing but the lane id itself stays live across iterations, and hipcc cannot hoist derived addresses
         uint32_t lv = (uint32_t)lane;
         asm volatile("" : "+v"(lv));
+        uint32_t next_tile = tile + 1u, next_left = left - 1u;
         const int j = (int)(lv & 31u), h = (int)(lv >> 5);
         const uint32_t lane16 = 16u * lv;
         const uint32_t rd_off = tile_off + (uint32_t)j * (uint32_t)ROW + 16u * ((uint32_t)h ^ G::mask((uint32_t)j));
@@ -256,7 +262,12 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
                     for (int s = 0; s < KC; s++) b0[s] = *(const i32x4 *)(smem + (rd_off ^ (32u * (uint32_t)(ch * KC + s))));
                     if constexpr (ch == KT0 / KC - 1) {
                         retire_lds_reads();
-                        if (tile + stride < n_tiles) dma_tile(tile + stride);
+                        if (left == 0u) {
+                            work_take_wait(taken);
+                            next_tile = total_waves * batch + taken;
+                            next_left = batch - 1u;
+                        }
+                        if (next_tile < n_tiles) dma_tile(next_tile);
                     }
                     mma_stream<mt, KC, KT0, SP, ch == 0, KC>(smem + (d.frag_off[0] + (uint32_t)(ch * KC * 1024) + lane16), b0, acc);
                 });
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
             }
         });
         hidden_layer<MMAX, SP, DBL>(smem, lane16, d.frag_off[1], M2, K2, pa, pb, h);
-        const uint64_t img = (tile << 5) + (uint64_t)j;
+        const uint64_t img = ((uint64_t)tile << 5) + (uint64_t)j;
         int32_t *lrow = (logits_out && img < n) ? logits_out + img * d.n_classes : nullptr;
         // per-iteration copy: keeps the (row < n_classes) predicates of every accumulator register of every block from being
         // hoisted out of the persistent loop as hundreds of live 64-bit masks
@@ -280,6 +291,8 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
             cls = final_layer<MMAX, SP>(smem, lane16, d.frag_off[2], M3, K3, pb, h, lrow, nc);
         }
         if (h == 0 && img < n) cls_out[img] = cls;
+        tile = next_tile;
+        left = next_left;
     }
     bnm_wait_vmcnt<0>();   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
@@ -296,8 +309,8 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
 #define BNM_GENERIC_LAUNCHER(NAME, MMAX)                                                                               \
     hipError_t NAME(uint32_t kt0, uint32_t sp, bool dbl, unsigned blocks, unsigned threads, unsigned lds, hipStream_t s,     \
                     const int8_t *images, uint64_t n, const void *frags, const BnmGenericDesc &d, uint32_t *cls,            \
-                    int32_t *logits) {                                                                                       \
-        typedef void (*fn_t)(const int8_t *, uint64_t, const i32x4 *, BnmGenericDesc, uint32_t *, int32_t *);              \
+                    int32_t *logits, uint32_t *counter, uint32_t batch) {                                                    \
+        typedef void (*fn_t)(const int8_t *, uint64_t, const i32x4 *, BnmGenericDesc, uint32_t *, int32_t *, uint32_t *, uint32_t); \
         fn_t fn = nullptr;                                                                                                   \
         BNM_GENERIC_PICK(MMAX, 2) BNM_GENERIC_PICK(MMAX, 4) BNM_GENERIC_PICK(MMAX, 8) BNM_GENERIC_PICK(MMAX, 16)             \
         if (!fn) return hipErrorInvalidValue;                                                                                \
@@ -305,6 +318,6 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         /* opt in to > 64 KiB of dynamic LDS (a per-device function attribute; a host call of about a microsecond) */        \
         hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
         if (err != hipSuccess) return err;                                                                                   \
-        fn<<<dim3(blocks), dim3(threads), lds, s>>>(images, n, (const i32x4 *)frags, d, cls, logits);                        \
+        fn<<<dim3(blocks), dim3(threads), lds, s>>>(images, n, (const i32x4 *)frags, d, cls, logits, counter, batch);        \
         return hipGetLastError();                                                                                            \
     }

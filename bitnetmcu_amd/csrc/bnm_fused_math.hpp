@@ -105,14 +105,21 @@ template <int MT, int NC8>
 BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h) {
     constexpr int G = NC8 > 0 ? NC8 : 4 * MT;
     int best = INT_MIN;
+    // the low byte 255 - row is assembled per 32-row tile: 31 - (row in tile) is an inline constant of the per-value
+    // v_lshl_or_b32, the tile's 224 - 32 m is added once to the tile's maximum.  (Written as 255 - row per value, every row
+    // needs its own constant above 64 in a register: dozens of registers in the kernels that serve up to 256 classes.)
 #pragma unroll
-    for (int m = 0; m < MT; m++)
+    for (int m = 0; m < MT; m++) {
+        if (4 * m >= G) continue;
+        int bm = INT_MIN;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             if (4 * m + (r >> 2) >= G) continue;
-            const uint32_t rowbase = 32u * m + (r & 3) + 8u * (r >> 2);   // row of the h = 0 half; h = 1: +4
-            best = max(best, (int)(((uint32_t)acc[m][r] << 8) | (255u - rowbase)));
+            const uint32_t rb = (r & 3) + 8u * (r >> 2);          // row within the tile for the h = 0 half; h = 1: +4
+            bm = max(bm, (int)(((uint32_t)acc[m][r] << 8) | (31u - rb)));
         }
+        best = max(best, bm + (224 - 32 * m));
+    }
     best = max_with_partner32(best - 4 * h);
     return 255u - ((uint32_t)best & 255u);
 }

@@ -70,8 +70,10 @@ constexpr int bnmk_generic_wps(int mmax, int kt0, int sp) {
 enum { BNM_FUSED_GENERIC = 4 };
 bool bnmk_generic_plan(BnmGenericDesc &d, const uint32_t m_real[4]);   // fills mmax, M, KTP, frag_off, w_bytes from KT0, sp
 bool bnmk_generic_supported(const BnmGenericDesc &d, bool dbl);
+// d_counter: a device word of the caller's (the launcher zeroes it); batch: tiles per take from it (0 = default)
 hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int grid_blocks, const int8_t *d_images, uint64_t n,
-                              const void *d_frags, uint32_t *d_cls, int32_t *d_logits, hipStream_t s);
+                              const void *d_frags, uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t batch,
+                              hipStream_t s);
 
 // ---- layer-wise ALU kernels (bit-serial unpack + wave-shuffle reduction) ----------------------
 hipError_t bnmk_fc_layer(const int8_t *d_act, uint32_t act_stride, const void *d_packed, int32_t bpw,

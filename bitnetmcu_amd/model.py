@@ -130,6 +130,10 @@ class Context:
     def set_tuning(self, variant=-1, grid_blocks=0):
         L.check(self._lib, self._lib.bnm_ctx_set_tuning(self._h, variant, grid_blocks), "bnm_ctx_set_tuning")
 
+    def set_work_batch(self, tiles):
+        """generic fused kernel: tiles per take from the device-wide work counter (0 = default)"""
+        L.check(self._lib, self._lib.bnm_ctx_set_work_batch(self._h, tiles), "bnm_ctx_set_work_batch")
+
     def set_ternary_variant(self, variant):
         """Ternary ALU kernel: 2 streamed weights + two images per lane (default), 1 one image per lane, 0 round 1's."""
         L.check(self._lib, self._lib.bnm_ctx_set_ternary_variant(self._h, variant), "bnm_ctx_set_ternary_variant")
