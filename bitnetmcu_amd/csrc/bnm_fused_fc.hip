@@ -470,6 +470,9 @@ bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fu
 // 4.40-4.55 vs 4.63-4.70 ms per 1e8 images; the 16-wide 1k model: 4.29 vs 4.33 ms), then two tiles in flight for
 // shapes whose tiles carry real work, else the plain one-ahead loop
 int bnmk_fused_default_variant(const BnmFusedShape &sh) {
+    // round 2: the dual-tile loop with the CU's waves sharing a work counter is 2.5-3 % ahead of the fixed stride on the
+    // same box (profiles/r02/headline_ab_r02v_variants_3_4_5.log)
+    if (find_fused(sh, FUSED_DUAL_SHARED)) return FUSED_DUAL_SHARED;
     if (find_fused(sh, FUSED_DUAL)) return FUSED_DUAL;
     if (sh.M[0] >= 2 && find_fused(sh, FUSED_LDSDMA2)) return FUSED_LDSDMA2;
     return find_fused(sh, FUSED_LDSDMA) ? FUSED_LDSDMA : FUSED_DIRECT;
