@@ -1107,9 +1107,8 @@ void processfclayer(int8_t *activations, const uint32_t *weights, int32_t bpw, u
     std::lock_guard<std::mutex> g(g_mu);
     if (!n_output) return;
     uint64_t cnt = bnm_fc_weight_count(bpw, n_input, n_output);
-    if (!bnm_codec_known(bpw) || n_input > 1024) {
-        // BitNetMCU_inference.c:202: no branch taken -> sum stays 0 (too-wide layers are outside the MCU format)
-        if (bnm_codec_known(bpw)) { g_err = "processfclayer: n_input > 1024 unsupported"; die("processfclayer"); }
+    if (!bnm_codec_known(bpw)) {
+        // BitNetMCU_inference.c:202: no branch taken -> sum stays 0
         std::memset(output, 0, sizeof(int32_t) * n_output);
         return;
     }
@@ -1127,7 +1126,6 @@ void processfclayer(int8_t *activations, const uint32_t *weights, int32_t bpw, u
 uint32_t ReLUNorm(int32_t *input, int8_t *output, uint32_t n_input) {
     std::lock_guard<std::mutex> g(g_mu);
     if (!n_input) return 255;
-    if (n_input > 1024) { g_err = "ReLUNorm: n_input > 1024 unsupported"; die("ReLUNorm"); }
     if (g_so.ensure((size_t)n_input * 4) || g_sb.ensure(n_input) || g_sarg.ensure(4)) die("ReLUNorm");
     uint32_t pos = 255;
     bool ok = hipMemcpy(g_so.p, input, (size_t)n_input * 4, hipMemcpyHostToDevice) == hipSuccess;
@@ -1141,7 +1139,7 @@ uint32_t ReLUNorm(int32_t *input, int8_t *output, uint32_t n_input) {
 
 int32_t *processconv33ReLU(int32_t *activations, const int8_t *weights, uint32_t xy, uint32_t n_shift, int32_t *output) {
     std::lock_guard<std::mutex> g(g_mu);
-    if (xy < 3 || xy > 64) { g_err = "processconv33ReLU: xy_input outside [3,64]"; die("processconv33ReLU"); }
+    if (xy < 3) return output;      // no output position exists (the reference's loops do not run either)
     uint32_t o = xy - 2;
     if (g_so.ensure((size_t)xy * xy * 4) || g_sw.ensure(16) || g_sa.ensure((size_t)o * o * 4)) die("processconv33ReLU");
     bool ok = hipMemcpy(g_so.p, activations, (size_t)xy * xy * 4, hipMemcpyHostToDevice) == hipSuccess;
@@ -1154,7 +1152,7 @@ int32_t *processconv33ReLU(int32_t *activations, const int8_t *weights, uint32_t
 
 int32_t *processmaxpool22(int32_t *activations, uint32_t xy, int32_t *output) {
     std::lock_guard<std::mutex> g(g_mu);
-    if (xy < 2 || xy > 64) { g_err = "processmaxpool22: xy_input outside [2,64]"; die("processmaxpool22"); }
+    if (xy < 2) return output;      // no output position exists
     uint32_t o = xy / 2;
     if (g_so.ensure((size_t)xy * xy * 4) || g_sa.ensure((size_t)o * o * 4)) die("processmaxpool22");
     bool ok = hipMemcpy(g_so.p, activations, (size_t)xy * xy * 4, hipMemcpyHostToDevice) == hipSuccess;

@@ -12,14 +12,17 @@
 // the fused table, and as an independent cross-check of the MFMA path.
 // =================================================================================================
 constexpr int LW_IMGS = 8;      // images per workgroup pass
-constexpr int LW_MAXIN = 1024;  // activations per vector
+constexpr int LW_MAXIN = 1024;  // activations per vector that relunorm_kernel holds in registers (longer vectors: relunorm_big_kernel)
+// activations per LDS pass of the FC kernel: a multiple of every codec's inputs-per-element (32, 16, 8, 4 per 32-bit word,
+// 10 per ternary chunk), so a pass always starts on an element boundary; longer rows take several passes
+constexpr int LW_KCHUNK = 960;
 
 __global__ __launch_bounds__(256) void fc_layer_bitserial_kernel(const int8_t *__restrict__ act, uint32_t act_stride,
                                                                  const void *__restrict__ packed, int bpw,
                                                                  uint32_t n_input, uint32_t n_output,
                                                                  int32_t *__restrict__ out, uint64_t batch) {
-    __shared__ __attribute__((aligned(16))) int8_t s_act[LW_IMGS][LW_MAXIN + 16];
-    __shared__ __attribute__((aligned(16))) uint32_t s_w[4][LW_MAXIN / 4 + 4];   // 4 neuron rows, <= 1 KiB each
+    __shared__ __attribute__((aligned(16))) int8_t s_act[LW_IMGS][LW_KCHUNK + 16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_w[4][LW_KCHUNK / 4 + 4];   // 4 neuron rows, one pass each
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t row = blockIdx.x * 4u + (uint32_t)wave;
@@ -27,37 +30,41 @@ __global__ __launch_bounds__(256) void fc_layer_bitserial_kernel(const int8_t *_
     const uint32_t per_word = fb ? 32u / (uint32_t)fb : 10u;
     // elements of the packed row: 32-bit words, or 16-bit chunks for ternary
     const uint32_t row_elems = bpw == 64 ? n_input / 10u : (fb ? (n_input + per_word - 1u) / per_word : 0u);
+    const uint32_t pass_elems = (uint32_t)LW_KCHUNK / per_word;
     const bool known = bpw == 64 || fb != 0;
-
-    // stage this wave's packed weight row
-    if (row < n_output && known) {
-        if (bpw == 64) {
-            const uint16_t *src = (const uint16_t *)packed + (size_t)row * row_elems;
-            for (uint32_t i = lane; i < row_elems; i += 64) s_w[wave][i] = src[i];
-        } else {
-            const uint32_t *src = (const uint32_t *)packed + (size_t)row * row_elems;
-            for (uint32_t i = lane; i < row_elems; i += 64) s_w[wave][i] = src[i];
-        }
-    }
+    const uint32_t n_pass = known && row_elems ? (row_elems + pass_elems - 1u) / pass_elems : 1u;
 
     for (uint64_t base = (uint64_t)blockIdx.y * LW_IMGS; base < batch; base += (uint64_t)gridDim.y * LW_IMGS) {
-        __syncthreads();
-        // stage up to LW_IMGS activation vectors (only bytes < n_input that exist: ternary pads are never read)
         const uint32_t nimg = (uint32_t)((batch - base) < LW_IMGS ? (batch - base) : LW_IMGS);
-        for (uint32_t i = threadIdx.x; i < nimg * act_stride; i += blockDim.x) {
-            uint32_t im = i / act_stride, k = i % act_stride;
-            if (k < LW_MAXIN) s_act[im][k] = act[(base + im) * act_stride + k];
-        }
-        __syncthreads();
-        if (row >= n_output) continue;
         int32_t sum[LW_IMGS];
 #pragma unroll
         for (int im = 0; im < LW_IMGS; im++) sum[im] = 0;
-        if (known) {
-            for (uint32_t e = lane; e < row_elems; e += 64) {
+        for (uint32_t pass = 0; pass < n_pass; pass++) {
+            const uint32_t e0 = pass * pass_elems, k0 = pass * (uint32_t)LW_KCHUNK;
+            const uint32_t ne = row_elems - e0 < pass_elems ? row_elems - e0 : pass_elems;
+            __syncthreads();
+            // stage this wave's slice of its packed weight row ...
+            if (row < n_output && known) {
+                if (bpw == 64) {
+                    const uint16_t *src = (const uint16_t *)packed + (size_t)row * row_elems + e0;
+                    for (uint32_t i = lane; i < ne; i += 64) s_w[wave][i] = src[i];
+                } else {
+                    const uint32_t *src = (const uint32_t *)packed + (size_t)row * row_elems + e0;
+                    for (uint32_t i = lane; i < ne; i += 64) s_w[wave][i] = src[i];
+                }
+            }
+            // ... and the same slice of up to LW_IMGS activation vectors (only bytes < act_stride exist: ternary pads are never read)
+            const uint32_t kn = act_stride > k0 ? (act_stride - k0 < (uint32_t)LW_KCHUNK ? act_stride - k0 : (uint32_t)LW_KCHUNK) : 0u;
+            for (uint32_t i = threadIdx.x; i < nimg * kn; i += blockDim.x) {
+                uint32_t im = i / kn, k = i % kn;
+                s_act[im][k] = act[(base + im) * act_stride + k0 + k];
+            }
+            __syncthreads();
+            if (row >= n_output || !known) continue;
+            for (uint32_t e = lane; e < ne; e += 64) {
                 uint32_t word = s_w[wave][e];
                 for (uint32_t f = 0; f < per_word; f++) {
-                    uint32_t k = e * per_word + f;
+                    uint32_t k = e * per_word + f;           // within the pass
                     int w;
                     if (bpw == 64) {
                         word *= 3u;                       // BitNetMCU_inference.c:121-134
@@ -68,13 +75,14 @@ __global__ __launch_bounds__(256) void fc_layer_bitserial_kernel(const int8_t *_
                         uint32_t field = (word >> (32u - (uint32_t)fb * (f + 1u))) & ((1u << fb) - 1u);
                         w = decode_field(bpw, field);
                     }
-                    if (w != 0 && k < act_stride) {
+                    if (w != 0 && k < kn) {
 #pragma unroll
                         for (int im = 0; im < LW_IMGS; im++) sum[im] += w * (int)s_act[im][k];
                     }
                 }
             }
         }
+        if (row >= n_output) continue;
 #pragma unroll
         for (int im = 0; im < LW_IMGS; im++) {
             int v = sum[im];
@@ -88,7 +96,6 @@ __global__ __launch_bounds__(256) void fc_layer_bitserial_kernel(const int8_t *_
 hipError_t bnmk_fc_layer(const int8_t *act, uint32_t act_stride, const void *packed, int32_t bpw, uint32_t n_input,
                          uint32_t n_output, int32_t *out, uint64_t batch, hipStream_t s) {
     if (!batch || !n_output) return hipSuccess;
-    if (n_input > LW_MAXIN + 15 || act_stride > LW_MAXIN) return hipErrorInvalidValue;
     uint64_t gy = (batch + LW_IMGS - 1) / LW_IMGS;
     if (gy > 8192) gy = 8192;
     fc_layer_bitserial_kernel<<<dim3((n_output + 3u) / 4u, (unsigned)gy), dim3(256), 0, s>>>(act, act_stride, packed, bpw,
@@ -136,10 +143,52 @@ __global__ __launch_bounds__(256) void relunorm_kernel(const int32_t *in, uint32
     }
 }
 
+// Vectors longer than LW_MAXIN: one workgroup per vector, two passes over global memory (maximum + first position, then the
+// outputs).  `out` must not alias `in` here (every caller passes its own device buffers).
+__global__ __launch_bounds__(256) void relunorm_big_kernel(const int32_t *__restrict__ in, uint32_t n, int8_t *__restrict__ out,
+                                                           uint32_t out_stride, uint32_t *__restrict__ argmax, uint64_t batch) {
+    __shared__ int s_v[4];
+    __shared__ uint32_t s_i[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint64_t v = blockIdx.x; v < batch; v += gridDim.x) {
+        const int32_t *src = in + v * n;
+        int bv = -INT_MAX;
+        uint32_t bi = 255;                  // ReLUNorm's "no maximum found" value (:25-37)
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+            if (src[i] > bv) { bv = src[i]; bi = i; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            int pv = __shfl_xor(bv, off);
+            uint32_t pi = (uint32_t)__shfl_xor((int)bi, off);
+            if (pv > bv || (pv == bv && pi < bi)) { bv = pv; bi = pi; }
+        }
+        __syncthreads();
+        if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+            if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
+        const int mx = max(bv, 0);
+        const uint32_t tt = (uint32_t)mx >> 7;
+        const int sh = tt ? 32 - __builtin_clz(tt) : 0;
+        const int rnd = (1 << sh) >> 1;
+        int8_t *dst = out + v * out_stride;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const int x = src[i];
+            dst[i] = (int8_t)(x < 0 ? 0 : min((x + rnd) >> sh, 127));
+        }
+        if (argmax && threadIdx.x == 0) argmax[v] = bi;
+    }
+}
+
 hipError_t bnmk_relunorm(const int32_t *in, uint32_t n, int8_t *out, uint32_t out_stride, uint32_t *argmax,
                          uint64_t batch, hipStream_t s) {
     if (!batch || !n) return hipSuccess;
-    if (n > LW_MAXIN) return hipErrorInvalidValue;
+    if (n > LW_MAXIN) {
+        if ((const void *)in == (const void *)out) return hipErrorInvalidValue;
+        relunorm_big_kernel<<<dim3((unsigned)(batch < 4096 ? batch : 4096)), dim3(256), 0, s>>>(in, n, out, out_stride, argmax, batch);
+        return hipGetLastError();
+    }
     uint64_t blocks = (batch + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     relunorm_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(in, n, out, out_stride, argmax, batch);
@@ -180,14 +229,53 @@ __global__ __launch_bounds__(256) void maxpool22_kernel(const int32_t *in, uint3
     }
 }
 
+// planes wider than 64: straight from global memory, many workgroups; `out` must not alias `in` (the host symbols copy the
+// caller's buffers into device buffers of their own, so the reference's in-place use still works at the symbol level)
+__global__ __launch_bounds__(256) void conv33_big_kernel(const int32_t *__restrict__ in, const int8_t *__restrict__ w, uint32_t xy,
+                                                         uint32_t n_shift, int32_t *__restrict__ out) {
+    int wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) wk[t] = w[t];
+    const uint64_t o = xy - 2u, total = o * o;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t y = i / o, x = i % o;
+        int s = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) s += wk[3 * dy + dx] * in[(y + dy) * xy + x + dx];
+        out[i] = s < 0 ? 0 : (s >> n_shift);
+    }
+}
+__global__ __launch_bounds__(256) void maxpool22_big_kernel(const int32_t *__restrict__ in, uint32_t xy, int32_t *__restrict__ out) {
+    const uint64_t o = xy / 2u, total = o * o;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t y = i / o, x = i % o;
+        const int32_t *p = in + 2u * y * xy + 2u * x;
+        out[i] = max(max(p[0], p[1]), max(p[xy], p[xy + 1]));
+    }
+}
+
 hipError_t bnmk_conv33(const int32_t *in, const int8_t *w, uint32_t xy, uint32_t n_shift, int32_t *out, hipStream_t s) {
-    if (xy < 3 || xy > 64) return hipErrorInvalidValue;
-    conv33_kernel<<<dim3(1), dim3(256), 0, s>>>(in, w, xy, n_shift, out);
+    if (xy < 3) return hipErrorInvalidValue;
+    if (xy > 64) {
+        if (in == out) return hipErrorInvalidValue;
+        const uint64_t total = (uint64_t)(xy - 2u) * (xy - 2u), blocks = (total + 255) / 256;
+        conv33_big_kernel<<<dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s>>>(in, w, xy, n_shift, out);
+    } else {
+        conv33_kernel<<<dim3(1), dim3(256), 0, s>>>(in, w, xy, n_shift, out);
+    }
     return hipGetLastError();
 }
 hipError_t bnmk_maxpool22(const int32_t *in, uint32_t xy, int32_t *out, hipStream_t s) {
-    if (xy < 2 || xy > 64) return hipErrorInvalidValue;
-    maxpool22_kernel<<<dim3(1), dim3(256), 0, s>>>(in, xy, out);
+    if (xy < 2) return hipErrorInvalidValue;
+    if (xy > 64) {
+        if (in == out) return hipErrorInvalidValue;
+        const uint64_t total = (uint64_t)(xy / 2u) * (xy / 2u), blocks = (total + 255) / 256;
+        maxpool22_big_kernel<<<dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s>>>(in, xy, out);
+    } else {
+        maxpool22_kernel<<<dim3(1), dim3(256), 0, s>>>(in, xy, out);
+    }
     return hipGetLastError();
 }
 

@@ -37,7 +37,11 @@ _workspaces = {}
 
 
 def _workspace(device, d, k):
-    key = (device.index, d, k)
+    # one workspace per (device, STREAM, shape): it carries the quantised weights from the weight-quant launch to the GEMM
+    # launch of the same call, so two streams (or two threads on different streams) must not share one
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream().cuda_stream
+    key = (device.index, stream, d, k)
     ws = _workspaces.get(key)
     if ws is None:
         nbytes = int(L.load().bnm_qat_workspace_bytes(d, k))
@@ -180,7 +184,11 @@ def ste_formula(x, w, s, quant_type, norm_type):
     if quant_type == "None":
         return F.linear(x_norm, w)
     if torch.is_tensor(s) and s.numel() > 1:
-        s = s.reshape(-1, 1)          # PerOutput: one clipping scalar per weight row
+        # PerOutput: one clipping scalar per weight ROW.  (Divergence from BitNetMCU.py:102-103: the reference's octav
+        # branch stacks the per-row scalars into shape [k], which broadcasts against w [k, d] along its LAST axis - an error
+        # unless k == d, and per COLUMN when k == d; its 'prop' branch (:107-108, keepdim) and the option's name say per
+        # row, which is what this mirror and the fused op apply for every shape.)
+        s = s.reshape(-1, 1)
     x_int, x_scale = activation_quant(x_norm)
     x_quant = x_norm + (x_int / x_scale - x_norm).detach()
     w_int, w_scale = weight_quant(w, s, quant_type)

@@ -2,7 +2,8 @@
  * the class histogram sums to N and the order-independent digest is identical for the two fused kernel variants
    (two different load paths) and for a sharded run (two halves, digests added) — the multi-GPU invariant;
  * a strided + head + tail sample is bit-exact against the oracle (class ids and logits);
- * inference is a pure per-image function: re-running a sub-range at a different tile alignment reproduces the ids."""
+ * inference is a pure per-image function: re-running a sub-range at a different tile alignment reproduces the ids;
+ * BASELINE configs[2] (ternary, N = 1e8) and configs[3] (CNN, several internal chunks): every kernel of the path agrees on all ids."""
 import os
 
 import numpy as np
@@ -39,7 +40,7 @@ def test_full_size_properties(gpu_ok, orc):
         d = synth.digest_device(cls, first=0, n_bins=10).cpu().numpy()
         assert int(d[1:].sum()) == n, "histogram does not sum to N"
         digests[variant] = d
-    for v in (1, 2, 3, 4):
+    for v in (1, 2, 3, 4, 5):
         assert np.array_equal(digests[0], digests[v]), f"kernel variant {v} disagrees with the direct-load kernel"
     if n == 100_000_000:
         # the oracle's digest of ALL 1e8 class ids of (fc_4bitsym_64, Dist-U, first = 0), computed on the host cores by
@@ -65,6 +66,73 @@ def test_full_size_properties(gpu_ok, orc):
     want_cls, want_lg = util.OracleModel(model, orc).infer(sample, logits=True)
     assert np.array_equal(cls[ti].cpu().numpy().astype(np.uint32), want_cls)
     lg = torch.empty((len(idx), 10), dtype=torch.int32, device="cuda")
+    ctx.infer_device(imgs[ti].contiguous(), torch.empty(len(idx), dtype=torch.int32, device="cuda"), lg)
+    assert np.array_equal(lg.cpu().numpy(), want_lg)
+    ctx.close()
+
+
+def test_ternary_full_size_all_kernels(gpu_ok, orc):
+    """BASELINE configs[2] at its stated N: the five ALU kernels (streamed weights with two / one image per lane, work counter /
+    fixed stride; round 1's kernel) and the MFMA path - independent implementations - give the same digest and histogram over
+    all N class ids; head / tail / strided sample and the first 10^6 images id for id against the oracle."""
+    import torch
+    model = util.load_golden_model("tern_96")
+    ctx = b.Context(model)
+    n = N_FULL
+    imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+    synth.fill_device(imgs, first=0, dist=DIST_U)
+    cls = torch.empty(n, dtype=torch.int32, device="cuda")
+    digests = {}
+    ctx.set_path(b.PATH_FUSED_MFMA)
+    ctx.infer_device(imgs, cls)
+    digests["mfma"] = synth.digest_device(cls, first=0, n_bins=10).cpu().numpy()
+    ctx.set_path(b.PATH_TERNARY_ALU)
+    for tv in (0, 11, 12, 1, 2):          # the default last: everything below runs on it
+        ctx.set_ternary_variant(tv)
+        cls.fill_(-1)
+        ctx.infer_device(imgs, cls)
+        digests[tv] = synth.digest_device(cls, first=0, n_bins=10).cpu().numpy()
+        assert int(digests[tv][1:].sum()) == n
+    for k, d in digests.items():
+        assert np.array_equal(d, digests[0]), f"ternary kernel {k} disagrees with round 1's ALU kernel"
+    idx = np.unique(np.concatenate([np.arange(0, 2000), np.arange(n - 2000, n), np.linspace(0, n - 1, 4000).astype(np.int64)]))
+    ti = torch.from_numpy(idx).cuda()
+    want_cls, want_lg = util.OracleModel(model, orc).infer(imgs[ti].cpu().numpy(), logits=True)
+    assert np.array_equal(cls[ti].cpu().numpy().astype(np.uint32), want_cls)
+    lg = torch.empty((len(idx), model.num_classes), dtype=torch.int32, device="cuda")
+    ctx.infer_device(imgs[ti].contiguous(), torch.empty(len(idx), dtype=torch.int32, device="cuda"), lg)
+    assert np.array_equal(lg.cpu().numpy(), want_lg)
+    m = min(n, 1_000_000)
+    assert np.array_equal(cls[:m].cpu().numpy().astype(np.uint32), _oracle_parallel(model, 0, m, DIST_U))
+    ctx.close()
+
+
+def test_cnn_many_chunks_all_kernels(gpu_ok, orc):
+    """BASELINE configs[3] across the front end's internal chunks (2^20 images each) and a ragged last chunk: the MFMA front end
+    with dynamic batches (default, and batches of 16), with fixed shares, and round 1's VALU kernel agree on every class id;
+    ids and logits around every chunk boundary, at the head / tail and on a strided sample equal the oracle's."""
+    import torch
+    model = util.load_golden_model("cnn_64")
+    ctx = b.Context(model)
+    n = int(os.environ.get("BNM_CNN_N", str(3 * (1 << 20) + 12345)))
+    imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+    synth.fill_device(imgs, first=0, dist=DIST_U)
+    cls = torch.empty(n, dtype=torch.int32, device="cuda")
+    ref = None
+    for variant in (0, 2, 116, 1):
+        ctx.set_cnn_variant(variant)
+        cls.fill_(-1)
+        ctx.infer_device(imgs, cls)
+        d = synth.digest_device(cls, first=0, n_bins=10).cpu().numpy()
+        assert int(d[1:].sum()) == n
+        ref = d if ref is None else ref
+        assert np.array_equal(d, ref), f"CNN front end variant {variant} disagrees with round 1's kernel"
+    edges = np.concatenate([np.arange(0)] + [np.arange(max(0, k * (1 << 20) - 40), min(n, k * (1 << 20) + 40)) for k in range(1, (n >> 20) + 1)])
+    idx = np.unique(np.concatenate([np.arange(0, 300), np.arange(n - 300, n), edges, np.linspace(0, n - 1, 1500).astype(np.int64)]))
+    ti = torch.from_numpy(idx).cuda()
+    want_cls, want_lg = util.OracleModel(model, orc).infer(imgs[ti].cpu().numpy(), logits=True)
+    assert np.array_equal(cls[ti].cpu().numpy().astype(np.uint32), want_cls)
+    lg = torch.empty((len(idx), model.num_classes), dtype=torch.int32, device="cuda")
     ctx.infer_device(imgs[ti].contiguous(), torch.empty(len(idx), dtype=torch.int32, device="cuda"), lg)
     assert np.array_equal(lg.cpu().numpy(), want_lg)
     ctx.close()

@@ -101,6 +101,33 @@ def test_reference_symbols_against_golden(gpu_ok, bnm):
             assert np.array_equal(f.maxpool22(k[f"pool{c}_in"], xy, inplace), k[f"pool{c}_out"])
 
 
+def test_reference_symbols_any_size(gpu_ok, bnm, orc):
+    """The reference's four functions take any size; so do the drop-in symbols: rows longer than one LDS pass (960 inputs), vectors
+    longer than a wave's registers (1024), planes wider than the LDS plane (64) - against the oracle port, incl. in-place use."""
+    f, o = util.Funcs(bnm), util.Funcs(orc, "orc_")
+    rng = np.random.default_rng(77)
+    for bpw, n_in, n_out in ((4, 2048, 9), (2, 1968, 5), (1, 4096, 3), (16, 1000, 6), (12, 1024, 4), (20, 3000, 2), (64, 2000, 7), (64, 970, 3)):
+        act = rng.integers(-128, 128, n_in).astype(np.int8)
+        if bpw == 64:
+            w = rng.integers(0, 59049, size=n_out * (n_in // 10)).astype(np.uint16)
+        else:
+            fb = {1: 1, 2: 2, 4: 4, 12: 4, 20: 4, 16: 8}[bpw]
+            w = rng.integers(0, 2**32, size=n_out * ((n_in * fb + 31) // 32), dtype=np.uint32)
+        assert np.array_equal(f.processfclayer(act, w, bpw, n_in, n_out), o.processfclayer(act, w, bpw, n_in, n_out)), (bpw, n_in, n_out)
+    for n in (1025, 3000, 70001):
+        x = rng.integers(-200000, 200000, n).astype(np.int32)
+        x[n // 3] = x[n // 2] = x.max() + 5           # two equal maxima: the first position wins
+        for fn in ("relunorm", "relunorm_inplace"):
+            got, want = getattr(f, fn)(x), getattr(o, fn)(x)
+            assert np.array_equal(got[0], want[0]) and got[1] == want[1], (n, fn)
+    for xy in (65, 100, 257):
+        plane = rng.integers(-3000, 3000, xy * xy).astype(np.int32)
+        w = rng.integers(-128, 128, 9).astype(np.int8)
+        for inplace in (True, False):
+            assert np.array_equal(f.conv33(plane, w, xy, 5, inplace), o.conv33(plane, w, xy, 5, inplace)), xy
+            assert np.array_equal(f.maxpool22(plane, xy, inplace), o.maxpool22(plane, xy, inplace)), xy
+
+
 @pytest.mark.parametrize("name", ["fc_4bitsym_64", "mcu_cnn_16small"])
 def test_reference_symbols_full_schedule(name, gpu_ok, bnm):
     """BitMnistInference's schedule executed call by call through OUR processfclayer/ReLUNorm/conv/pool symbols."""
