@@ -64,13 +64,15 @@ BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 
 //                 generic kernel's id).  The SIMD arbiter favours the older of a SIMD's two waves: with a fixed stride the
 //                 favoured waves finish after ~65 % of the launch and the rest of it runs at one wave per SIMD
 //                 (profiles/r02/wait_timing_hbm_r02s_fixed_stride.json: 4.6 M .. 7.2 M cycles for the same 763 iterations).
-enum { FUSED_DIRECT = 0, FUSED_LDSDMA = 1, FUSED_LDSDMA2 = 2, FUSED_DUAL = 3, FUSED_DUAL_SHARED = 5 };
+//   6  DUAL_DEVWIDE  the dual-tile loop (two 4-wave workgroups per CU) with batches of pairs from ONE device-wide counter
+enum { FUSED_DIRECT = 0, FUSED_LDSDMA = 1, FUSED_LDSDMA2 = 2, FUSED_DUAL = 3, FUSED_DUAL_SHARED = 5, FUSED_DUAL_DEVWIDE = 6 };
 
 template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT, int NC8>
 __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                      const i32x4 *__restrict__ frags, uint32_t n_classes,
                                                                      uint32_t *__restrict__ cls_out,
-                                                                     int32_t *__restrict__ logits_out, uint64_t src_wrap) {
+                                                                     int32_t *__restrict__ logits_out, uint64_t src_wrap,
+                                                                     uint32_t *__restrict__ work, uint32_t batch) {
     constexpr int SP = SPLIT ? 2 : 1;
     constexpr int ROW = 32 * KT0;
     constexpr bool LDSDMA = VARIANT != FUSED_DIRECT;
@@ -232,14 +234,16 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
 // the remainder to variant 2; the refill after the last pair re-reads that pair), so the scheduler can place one
 // tile's ReLUNorm VALU work between the other tile's MFMAs.  Weights stay in registers once for both tiles.
 //
-template <int M1, int M2, int M3, int M4, bool DBL, int NC8, int WPB = FUSED_WPB>
+template <int M1, int M2, int M3, int M4, bool DBL, int NC8, int WPB = FUSED_WPB, bool DW = false>
 __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                           const i32x4 *__restrict__ frags,
                                                                           uint32_t n_classes, uint32_t *__restrict__ cls_out,
                                                                           int32_t *__restrict__ logits_out,
-                                                                          uint64_t src_wrap) {
+                                                                          uint64_t src_wrap, uint32_t *__restrict__ work,
+                                                                          uint32_t batch) {
     constexpr int KT0 = 8;
     constexpr bool SHARED = WPB == 8;          // one workgroup per CU, pairs handed out from s_next
+    constexpr bool DEVWIDE = DW;   // 4-wave workgroups, batches of pairs from the device-wide counter work[0]
     __shared__ __attribute__((aligned(1024))) char smem[WPB * 2 * FUSED_TILE_BYTES];
     __shared__ uint32_t s_next;
     const int lane = threadIdx.x & 63;
@@ -270,7 +274,14 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
 
     const uint64_t n_pairs = n >> 6;            // the launcher guarantees n % 64 == 0
     const uint64_t stride = (uint64_t)gridDim.x * WPB;
-    uint64_t pair = SHARED ? take() : (uint64_t)blockIdx.x * WPB + wave;
+    // DEVWIDE: batches of `batch` (>= 2) consecutive pairs; a wave's first batch is static, later ones come from work[0] on the
+    // scalar unit (work_take_*).  The take is issued in EVERY iteration at the same place - behind the iteration's last LDS
+    // read, so that no lgkmcnt wait of the iteration covers it - and the loop body stays one basic block: in the iteration
+    // before a batch's last pair it adds `batch` to the counter, in all others it adds 0 to a word of the wave's own
+    // (work[16 (1 + wave id)]); scalar selects pick the address, the amount and, one iteration later, the result.
+    const uint32_t wave_id = blockIdx.x * WPB + (uint32_t)wave, total_waves = gridDim.x * WPB;
+    uint32_t left = DEVWIDE ? batch - 1u : 0u, taken = 0;
+    uint64_t pair = SHARED ? take() : DEVWIDE ? (uint64_t)wave_id * batch : (uint64_t)blockIdx.x * WPB + wave;
 
     uint32_t voff[4];
 #pragma unroll
@@ -315,7 +326,16 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
 #endif
     while (pair < n_pairs) {
         // the refill after the last pair re-reads that pair (keeps the wait counts constant and the body branch-free)
-        const uint64_t cand = SHARED ? take() : pair + stride;
+        uint64_t cand;
+        if constexpr (DEVWIDE) {
+            work_take_wait(taken);        // the take of the previous iteration (two thirds of an iteration old)
+            // (32-bit arithmetic - the launcher refuses 2^31 pairs - so that this is two scalar selects, not a branch)
+            // (the counter counts PAIRS: every take adds `batch`; the static first batches cover [0, total_waves * batch))
+            const uint32_t c32 = left != 0u ? (uint32_t)pair + 1u : total_waves * batch + taken;
+            cand = c32;
+        } else {
+            cand = SHARED ? take() : pair + stride;
+        }
         const uint64_t next = cand < n_pairs ? cand : pair;
         // outstanding, oldest first: slot 0 (8 pieces), [the deferred store], slot 1 (8 pieces).
         // Loads retire in order among themselves, so "<= 8 left" implies slot 0 has landed.
@@ -343,6 +363,15 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
         read_tile(1, bB);
         layer_mma<M1, KT0, false>(A1, bB, a1B);
         dma_tile(2ull * next + 1ull, 1);
+        if constexpr (DEVWIDE) {
+            // The statement names one accumulator register of each of tile B's layer-1 MFMA chains, so hipcc places it behind
+            // the last of those MFMAs - i.e. behind the iteration's last LDS operand wait; nothing after that point touches
+            // LDS until the next iteration, so no lgkmcnt wait sits on the take's round trip.
+            uint32_t *const addr = left == 1u ? work : work + 16u * (1u + wave_id);
+            const uint32_t amount = left == 1u ? batch : 0u;
+            asm volatile("s_mov_b32 %0, %2\n\ts_atomic_add %0, %1, 0x0 glc"
+                         : "=&{s95}"(taken) : "s"(addr), "s"(amount), "v"(a1B[0][15]), "v"(a1B[M1 - 1][15]) : "memory");
+        }
 
         i32x4 p1A[M1], p1B[M1];
         relunorm_pack<M1, DBL>(a1A, p1A, h);
@@ -390,6 +419,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
         img_prev = h ? imgB : imgA;
         cls_prev = h ? clsB : clsA;
         pair = cand;
+        if constexpr (DEVWIDE) left = left != 0u ? left - 1u : batch - 1u;
     }
     if (any) cls_out[img_prev] = cls_prev;
     bnm_wait_vmcnt<0>();   // LDS-DMA still in flight must not outlive the workgroup's LDS allocation
@@ -407,7 +437,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
 
 // ---- dispatch table: model shapes of the reference zoo (+ ternary) -----------------------------
 namespace {
-typedef void (*fused_fn)(const int8_t *, uint64_t, const i32x4 *, uint32_t, uint32_t *, int32_t *, uint64_t);
+typedef void (*fused_fn)(const int8_t *, uint64_t, const i32x4 *, uint32_t, uint32_t *, int32_t *, uint64_t, uint32_t *, uint32_t);
 struct FusedEntry {
     BnmFusedShape sh;
     int variant;
@@ -420,6 +450,8 @@ struct FusedEntry {
     FUSED(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR, 2), FUSED(KT0, M1, M2, M3, M4, SPLIT, DBL, VAR, 0)
 const FusedEntry kFused[] = {
     // FC 256-64-64-64-10 4bitsym (BitNetMCU_model_fc.h, mcu/BitNetMCU_model_12k.h) — the headline shape
+    { {8, {2, 2, 2, 1}, false, true, 2}, FUSED_DUAL_DEVWIDE, fused_fc_dual_kernel<2, 2, 2, 1, true, 2, 4, true> },
+    { {8, {2, 2, 2, 1}, false, true, 0}, FUSED_DUAL_DEVWIDE, fused_fc_dual_kernel<2, 2, 2, 1, true, 0, 4, true> },
     { {8, {2, 2, 2, 1}, false, true, 2}, FUSED_DUAL_SHARED, fused_fc_dual_kernel<2, 2, 2, 1, true, 2, 8> },
     { {8, {2, 2, 2, 1}, false, true, 0}, FUSED_DUAL_SHARED, fused_fc_dual_kernel<2, 2, 2, 1, true, 0, 8> },
     { {8, {2, 2, 2, 1}, false, true, 2}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, true, 2> },
@@ -428,6 +460,8 @@ const FusedEntry kFused[] = {
     FUSED_ANY_AND_10(8, 2, 2, 2, 1, false, true, FUSED_LDSDMA),
     FUSED(8, 2, 2, 2, 1, false, true, FUSED_DIRECT, 0),
     // same shape with codecs whose weights cannot be doubled in int8 (8-bit two's complement, FP1.3.0 without +128)
+    { {8, {2, 2, 2, 1}, false, false, 2}, FUSED_DUAL_DEVWIDE, fused_fc_dual_kernel<2, 2, 2, 1, false, 2, 4, true> },
+    { {8, {2, 2, 2, 1}, false, false, 0}, FUSED_DUAL_DEVWIDE, fused_fc_dual_kernel<2, 2, 2, 1, false, 0, 4, true> },
     { {8, {2, 2, 2, 1}, false, false, 2}, FUSED_DUAL_SHARED, fused_fc_dual_kernel<2, 2, 2, 1, false, 2, 8> },
     { {8, {2, 2, 2, 1}, false, false, 0}, FUSED_DUAL_SHARED, fused_fc_dual_kernel<2, 2, 2, 1, false, 0, 8> },
     { {8, {2, 2, 2, 1}, false, false, 2}, FUSED_DUAL, fused_fc_dual_kernel<2, 2, 2, 1, false, 2> },
@@ -438,6 +472,7 @@ const FusedEntry kFused[] = {
     // (FP1.3.0 models that really contain a +128 weight need a second weight plane: 2 x the A fragments do not fit the
     // register file without spilling, so those go to the generic kernel, whose weights live in LDS)
     // FC 256-16-16-10 2bitsym (mcu/BitNetMCU_model_1k.h)
+    { {8, {1, 1, 1, 0}, false, true, 2}, FUSED_DUAL_DEVWIDE, fused_fc_dual_kernel<1, 1, 1, 0, true, 2, 4, true> },
     { {8, {1, 1, 1, 0}, false, true, 2}, FUSED_DUAL_SHARED, fused_fc_dual_kernel<1, 1, 1, 0, true, 2, 8> },
     { {8, {1, 1, 1, 0}, false, true, 2}, FUSED_DUAL, fused_fc_dual_kernel<1, 1, 1, 0, true, 2> },
     FUSED(8, 1, 1, 1, 0, false, true, FUSED_LDSDMA2, 0),
@@ -472,6 +507,9 @@ bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fu
 int bnmk_fused_default_variant(const BnmFusedShape &sh) {
     // round 2: the dual-tile loop with the CU's waves sharing a work counter is 2.5-3 % ahead of the fixed stride on the
     // same box (profiles/r02/headline_ab_r02v_variants_3_4_5.log)
+    // ... and batches of 8 pairs from the device-wide counter another 2-5 % ahead of that (same-process interleaved A/B,
+    // profiles/headline_ab.py: profiles/r02/headline_ab_r02x.json, headline_ab_r02y.json)
+    if (find_fused(sh, FUSED_DUAL_DEVWIDE)) return FUSED_DUAL_DEVWIDE;
     if (find_fused(sh, FUSED_DUAL_SHARED)) return FUSED_DUAL_SHARED;
     if (find_fused(sh, FUSED_DUAL)) return FUSED_DUAL;
     if (sh.M[0] >= 2 && find_fused(sh, FUSED_LDSDMA2)) return FUSED_LDSDMA2;
@@ -482,16 +520,26 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
     const FusedEntry *e = find_fused(sh, variant);
     if (!e) return hipErrorInvalidValue;
     if (a.n == 0) return hipSuccess;
-    if (variant == FUSED_DUAL || variant == FUSED_DUAL_SHARED) {
+    if (variant == FUSED_DUAL || variant == FUSED_DUAL_SHARED || variant == FUSED_DUAL_DEVWIDE) {
         // whole 64-image pairs go to the dual-tile kernel, the remainder (< 64 images) to variant 2
         const uint64_t n_main = a.n & ~63ull;
         if (n_main) {
             // fixed stride: two 4-wave workgroups per CU; shared counter: ONE 8-wave workgroup per CU
             const uint64_t wpb = variant == FUSED_DUAL_SHARED ? 8 : FUSED_WPB;
-            uint64_t want = ((n_main >> 6) + wpb - 1) / wpb;
+            uint32_t batch = 1;
+            if (variant == FUSED_DUAL_DEVWIDE) {
+                // work[0]: the counter (zeroed here); work[16 (1 + w)]: wave w's own word for the zero-adds
+                if (!a.work || (n_main >> 6) >= (1ull << 31)) return hipErrorInvalidValue;
+                // 8: the counter word serves ~87 M takes/s, shared with the per-iteration zero-adds; batches of 4 are already
+                // bound by it (5.5 ms per 1e8 images), 6 is the fastest measured and 8 keeps a margin on faster boxes
+                batch = a.batch >= 2 ? a.batch : 8;
+                if (hipError_t err = hipMemsetAsync(a.work, 0, sizeof(uint32_t), s); err != hipSuccess) return err;
+            }
+            uint64_t want = ((n_main >> 6) + wpb * batch - 1) / (wpb * batch);
             uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * (variant == FUSED_DUAL_SHARED ? 1ull : 2ull);
+            if (variant == FUSED_DUAL_DEVWIDE && cap * wpb > BNM_WORK_DUMMY_WAVES) cap = BNM_WORK_DUMMY_WAVES / wpb;
             e->fn<<<dim3((unsigned)(want < cap ? want : cap)), dim3((unsigned)(64 * wpb)), 0, s>>>(
-                a.images, n_main, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap);
+                a.images, n_main, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap, a.work, batch);
             hipError_t err = hipGetLastError();
             if (err != hipSuccess) return err;
         }
@@ -509,7 +557,8 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
     // persistent grid: 8 resident waves per CU (2 workgroups x 4 waves; VGPRs and LDS allow no more)
     uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * 2ull;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
-    e->fn<<<dim3(blocks), dim3(64 * FUSED_WPB), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap);
+    e->fn<<<dim3(blocks), dim3(64 * FUSED_WPB), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap,
+                                                       nullptr, 0);
     return hipGetLastError();
 }
 

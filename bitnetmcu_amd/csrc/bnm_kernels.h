@@ -43,7 +43,10 @@ struct BnmFusedArgs {
     uint32_t *cls;          // [n]
     int32_t *logits;        // [n][n_classes] or nullptr
     uint64_t src_wrap = 0;  // diagnostic library only (BNM_DIAG): read tile (t mod src_wrap); ignored by the product build
+    uint32_t *work = nullptr;   // variant 6: device words [16 * (1 + BNM_WORK_DUMMY_WAVES)]: the work counter + one word per wave
+    uint32_t batch = 0;         // variant 6: pairs per take (0 = default)
 };
+constexpr uint32_t BNM_WORK_DUMMY_WAVES = 4096;
 // variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (256-byte rows only), 2 = LDS-DMA with two
 // tiles in flight per wave, 3 = two tiles computed per wave per iteration (default where instantiated)
 bool bnmk_fused_supported(const BnmFusedShape &sh, int variant);

@@ -31,16 +31,16 @@ def test_full_size_properties(gpu_ok, orc):
     cls = torch.empty(n, dtype=torch.int32, device="cuda")
     digests = {}
     default_variant = ctx.variant
-    assert default_variant == 5, "the timed kernel of bench.py is the dual-tile kernel with the shared work counter (variant 5)"
+    assert default_variant == 6, "the timed kernel of bench.py is the dual-tile kernel with the device-wide work counter (variant 6)"
     # every kernel variant, the default (= what bench.py times) LAST so that everything below runs on it
-    for variant in (4, 3, 2, 1, 0, default_variant):
+    for variant in (5, 4, 3, 2, 1, 0, default_variant):
         ctx.set_tuning(variant=variant)
         cls.fill_(-1)
         ctx.infer_device(imgs, cls)
         d = synth.digest_device(cls, first=0, n_bins=10).cpu().numpy()
         assert int(d[1:].sum()) == n, "histogram does not sum to N"
         digests[variant] = d
-    for v in (1, 2, 3, 4, 5):
+    for v in (1, 2, 3, 4, 5, 6):
         assert np.array_equal(digests[0], digests[v]), f"kernel variant {v} disagrees with the direct-load kernel"
     if n == 100_000_000:
         # the oracle's digest of ALL 1e8 class ids of (fc_4bitsym_64, Dist-U, first = 0), computed on the host cores by
@@ -200,7 +200,7 @@ def test_full_1e8_digest_and_histogram_equal_the_oracle(gpu_ok):
         c = _oracle_parallel(model, s, min(step, n - s), DIST_U)
         want_digest = (want_digest + synth.class_digest(c, s)) & 0xFFFFFFFFFFFFFFFF
         hist += np.bincount(c, minlength=10)
-    assert ctx.variant == 5
+    assert ctx.variant == 6
     assert int(d[0].astype(np.uint64)) == want_digest
     assert d[1:].tolist() == hist.tolist()
     if n == 100_000_000:

@@ -19,7 +19,7 @@ def paths_for(ctx):
     """(label, setup) for every kernel path this model can run."""
     out = [("auto", lambda c: c.set_path(b.PATH_AUTO))]
     out.append(("layerwise", lambda c: c.set_path(b.PATH_LAYERWISE_ALU)))
-    for v in (0, 1, 2, 3, 4, 5):       # 4 = the generic kernel (run-time widths, weights in LDS), 5 = dual-tile loop with a shared work counter
+    for v in (0, 1, 2, 3, 4, 5, 6):    # 4 = the generic kernel (run-time widths, weights in LDS), 5 / 6 = dual-tile loop with a CU-shared / device-wide work counter
         def fused(c, v=v):
             c.set_path(b.PATH_FUSED_MFMA)
             c.set_tuning(variant=v)

@@ -39,7 +39,7 @@ def near_tie(v):
 
 def gpu_levels(d, k):
     """the weight levels the kernel actually used: workspace starts with uT [dpad][kpad]"""
-    ws = qat._workspaces[(torch.cuda.current_device(), d, k)]
+    ws = qat._workspaces[(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, d, k)]
     dpad, kpad = (d + 1) & ~1, (k + 31) & ~31
     return ws[: dpad * kpad].reshape(dpad, kpad)[:d, :k].t().cpu().numpy().astype(np.float64)
 
