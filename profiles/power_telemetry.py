@@ -174,10 +174,13 @@ def main():
     th.join()
     res["idle"] = idle.summary()
     ctx = b.Context(model)
-    res["fused_dual_hbm"] = arm("fused", lambda: ctx.infer_device(imgs, cls), seconds)
-    ctx.set_tuning(variant=2)
-    res["fused_variant2_hbm"] = arm("fused2", lambda: ctx.infer_device(imgs, cls), seconds)
-    ctx.set_tuning(variant=3)
+    default_variant = ctx.variant
+    res["default_variant"] = default_variant
+    res["fused_dual_hbm"] = arm("fused", lambda: ctx.infer_device(imgs, cls), seconds)       # the default kernel (= bench.py)
+    for v in (3, 2, 4):          # dual-tile loop with a fixed stride, one tile per iteration, the generic kernel
+        ctx.set_tuning(variant=v)
+        res[f"fused_variant{v}_hbm"] = arm(f"fused{v}", lambda: ctx.infer_device(imgs, cls), seconds)
+    ctx.set_tuning(variant=default_variant)
     if hasattr(lib, "bnm_diag_set_src_wrap"):
         L.check(lib, lib.bnm_diag_set_src_wrap(ctx._h, 256))
         res["fused_dual_cache_resident"] = arm("fused_wrap", lambda: ctx.infer_device(imgs, cls), seconds)
