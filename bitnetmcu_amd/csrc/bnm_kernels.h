@@ -139,8 +139,10 @@ hipError_t bnmk_qat_bitlinear_forward(const float *d_x, uint64_t n, uint32_t d, 
                                       const float *d_s, uint32_t s_count, int quant_type, int norm_type, float *d_y,
                                       float *d_workspace, float *d_x_int_out, float *d_x_scale_out, float *d_w_deq_out,
                                       hipStream_t s);
-// BitConv2d forward: stride 1, one input channel per group (cin == 1 with groups == 1, or depthwise), zero padding `pad`.
-// workspace: bnmk_qat_workspace_bytes(kh * kw, cout) bytes.
+// BitConv2d forward: any groups / stride, zero padding `pad`, PerTensor clipping scalar.
+// workspace: bnmk_qat_workspace_bytes((cin / groups) * kh * kw, cout) bytes; dynamic LDS: bnmk_qat_bitconv2d_lds_bytes (<= 160 KiB).
+size_t bnmk_qat_bitconv2d_lds_bytes(uint32_t cin, uint32_t h, uint32_t w, uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad,
+                                    uint32_t groups);
 hipError_t bnmk_qat_bitconv2d_forward(const float *d_x, uint64_t n, uint32_t cin, uint32_t h, uint32_t w, const float *d_w,
-                                      uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad, const float *d_s, int quant_type,
-                                      int norm_type, float *d_y, float *d_workspace, hipStream_t s);
+                                      uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad, uint32_t stride, uint32_t groups,
+                                      const float *d_s, int quant_type, int norm_type, float *d_y, float *d_workspace, hipStream_t s);

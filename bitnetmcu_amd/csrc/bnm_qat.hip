@@ -243,77 +243,90 @@ __global__ __launch_bounds__(64 * QAT_WAVES) void qat_bitlinear_fwd_kernel(
     }
 }
 
-// BitConv2d forward (BitNetMCU.py:264-322) for the reference's use of it (models.py:111-116): stride 1, one input
-// channel per group (a single-channel first layer with groups = 1, or depthwise groups = channels), square-ish kh x kw
-// kernels, symmetric zero padding.  One workgroup per (image, input channel) plane:
-//   phase 1  plane -> LDS; Normalize ('RMS' over the plane, :306-308, or 'None'); activation_quant per image ROW
-//            (max over the last dimension, :125-127); the LDS plane holds x_int / x_scale inside a zero border
-//   phase 2  every thread produces outputs  sum_taps plane[...] * (w_int / w_scale)  for the output channels fed by
-//            this input channel
-// dynamic LDS: (h + 2p) x (w + 2p) plane + cpi x kh x kw dequantised taps
+// BitConv2d forward (BitNetMCU.py:264-322): any group structure (groups = 1, depthwise, anything between), any stride, kh x kw
+// kernels, symmetric zero padding.  One workgroup per (image, group):
+//   phase 1  the group's cin/groups input planes -> LDS, each inside a zero border; Normalize ('RMS' over each plane, :306-308,
+//            or 'None'); activation_quant per image ROW of each plane (max over the last dimension, :125-127): the LDS planes
+//            hold x_int / x_scale
+//   phase 2  every thread produces outputs  sum_{plane, taps} plane[...] * (w_int / w_scale)  for the group's output channels
+// dynamic LDS: cig x (h + 2p) x (w + 2p) planes + cog x cig x kh x kw dequantised taps
 __global__ __launch_bounds__(256) void qat_bitconv2d_fwd_kernel(const float *__restrict__ x, uint32_t cin, uint32_t h,
                                                                 uint32_t wd, const float *__restrict__ uT,
                                                                 const float *__restrict__ w_scale, uint32_t cout,
                                                                 uint32_t kpad, uint32_t kh, uint32_t kw, uint32_t pad,
-                                                                int qt, int nt, float *__restrict__ y) {
+                                                                uint32_t stride, uint32_t groups, int qt, int nt,
+                                                                float *__restrict__ y) {
     extern __shared__ float lds[];
     __shared__ float red[4];
-    const uint32_t img = blockIdx.x / cin, ci = blockIdx.x % cin;
+    const uint32_t img = blockIdx.x / groups, g = blockIdx.x % groups;
+    const uint32_t cig = cin / groups, cog = cout / groups;     // input / output channels of one group
     const uint32_t hp = h + 2u * pad, wp = wd + 2u * pad;
-    const uint32_t ho = hp - kh + 1u, wo = wp - kw + 1u;
-    const uint32_t cpi = cout / cin;                  // output channels per input channel
-    float *plane = lds;
-    float *taps = lds + hp * wp;
+    const uint32_t ho = (hp - kh) / stride + 1u, wo = (wp - kw) / stride + 1u;
+    const uint32_t d = cig * kh * kw;                 // one output channel's weights: [cig][kh][kw]
+    float *planes = lds;
+    float *taps = lds + cig * hp * wp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float *xp = x + ((uint64_t)img * cin + ci) * h * wd;
 
-    for (uint32_t i = threadIdx.x; i < hp * wp; i += 256u) plane[i] = 0.0f;
-    for (uint32_t i = threadIdx.x; i < cpi * kh * kw; i += 256u) {
-        const uint32_t co = ci * cpi + i / (kh * kw), tap = i % (kh * kw);
-        const float u = uT[(uint64_t)tap * kpad + co];
+    for (uint32_t i = threadIdx.x; i < cig * hp * wp; i += 256u) planes[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < cog * d; i += 256u) {
+        const uint32_t co = g * cog + i / d, t = i % d;
+        const float u = uT[(uint64_t)t * kpad + co];
         taps[i] = qt == BNM_QAT_NONE ? u : __fdiv_rn(u, w_scale[co]);
     }
-    float den = 1.0f;
-    if (nt == BNM_QAT_NORM_RMS) {
-        float a = 0.0f;
-        for (uint32_t i = threadIdx.x; i < h * wd; i += 256u) a += xp[i] * xp[i];
-        a = wave_sum(a);
-        if (lane == 0) red[wave] = a;
-        __syncthreads();
-        den = sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)(h * wd));
-    }
-    __syncthreads();
-    for (uint32_t r = wave; r < h; r += 4u) {
-        float *pr = plane + (r + pad) * wp + pad;
-        float mx = 0.0f;
-        for (uint32_t c = lane; c < wd; c += 64u) {
-            float v = xp[r * wd + c];
-            if (nt == BNM_QAT_NORM_RMS) v = __fdiv_rn(v, den);
-            pr[c] = v;
-            mx = fmaxf(mx, fabsf(v));
+    for (uint32_t c = 0; c < cig; c++) {
+        const float *xp = x + ((uint64_t)img * cin + g * cig + c) * h * wd;
+        float *plane = planes + c * hp * wp;
+        float den = 1.0f;
+        __syncthreads();                              // the zero fill (c = 0) / the previous plane's use of red[]
+        if (nt == BNM_QAT_NORM_RMS) {
+            float a = 0.0f;
+            for (uint32_t i = threadIdx.x; i < h * wd; i += 256u) a += xp[i] * xp[i];
+            a = wave_sum(a);
+            if (lane == 0) red[wave] = a;
+            __syncthreads();
+            den = sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)(h * wd));
         }
-        if (qt == BNM_QAT_NONE) continue;
-        mx = wave_max(mx);
-        const float sc = __fdiv_rn(127.0f, fmaxf(mx, 1e-5f));
-        for (uint32_t c = lane; c < wd; c += 64u)
-            pr[c] = __fdiv_rn(fminf(fmaxf(rintf(__fmul_rn(pr[c], sc)), -128.0f), 127.0f), sc);
+        for (uint32_t r = wave; r < h; r += 4u) {
+            float *pr = plane + (r + pad) * wp + pad;
+            float mx = 0.0f;
+            for (uint32_t cc = lane; cc < wd; cc += 64u) {
+                float v = xp[r * wd + cc];
+                if (nt == BNM_QAT_NORM_RMS) v = __fdiv_rn(v, den);
+                pr[cc] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
+            if (qt == BNM_QAT_NONE) continue;
+            mx = wave_max(mx);
+            const float sc = __fdiv_rn(127.0f, fmaxf(mx, 1e-5f));
+            for (uint32_t cc = lane; cc < wd; cc += 64u)
+                pr[cc] = __fdiv_rn(fminf(fmaxf(rintf(__fmul_rn(pr[cc], sc)), -128.0f), 127.0f), sc);
+        }
     }
     __syncthreads();
     const uint32_t per = ho * wo;
-    for (uint32_t i = threadIdx.x; i < cpi * per; i += 256u) {
+    for (uint32_t i = threadIdx.x; i < cog * per; i += 256u) {
         const uint32_t cl = i / per, oy = (i % per) / wo, ox = i % wo;
-        const float *t = taps + cl * kh * kw;
+        const float *t = taps + cl * d;
         float acc = 0.0f;
-        for (uint32_t dy = 0; dy < kh; dy++)
-            for (uint32_t dx = 0; dx < kw; dx++) acc = fmaf(plane[(oy + dy) * wp + ox + dx], t[dy * kw + dx], acc);
-        y[(((uint64_t)img * cout + ci * cpi + cl) * ho + oy) * wo + ox] = acc;
+        for (uint32_t c = 0; c < cig; c++) {
+            const float *plane = planes + c * hp * wp + (oy * stride) * wp + ox * stride;
+            for (uint32_t dy = 0; dy < kh; dy++)
+                for (uint32_t dx = 0; dx < kw; dx++) acc = fmaf(plane[dy * wp + dx], t[(c * kh + dy) * kw + dx], acc);
+        }
+        y[(((uint64_t)img * cout + g * cog + cl) * ho + oy) * wo + ox] = acc;
     }
 }
 
+size_t bnmk_qat_bitconv2d_lds_bytes(uint32_t cin, uint32_t h, uint32_t wd, uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad,
+                                    uint32_t groups) {
+    const size_t cig = cin / groups, cog = cout / groups;
+    return (cig * (size_t)(h + 2u * pad) * (wd + 2u * pad) + cog * cig * kh * kw) * sizeof(float);
+}
+
 hipError_t bnmk_qat_bitconv2d_forward(const float *x, uint64_t n, uint32_t cin, uint32_t h, uint32_t wd, const float *w,
-                                      uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad, const float *s, int qt, int nt,
-                                      float *y, float *workspace, hipStream_t st) {
-    const uint32_t d = kh * kw, dpad = (d + 1u) & ~1u, kpad = (cout + 31u) & ~31u;
+                                      uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad, uint32_t stride, uint32_t groups,
+                                      const float *s, int qt, int nt, float *y, float *workspace, hipStream_t st) {
+    const uint32_t d = (cin / groups) * kh * kw, dpad = (d + 1u) & ~1u, kpad = (cout + 31u) & ~31u;
     float *uT = workspace;
     float *w_scale = uT + (size_t)dpad * kpad;
     float *stats = w_scale + kpad;
@@ -324,9 +337,13 @@ hipError_t bnmk_qat_bitconv2d_forward(const float *x, uint64_t n, uint32_t cin, 
     if (qt == BNM_QAT_TERNARY || qt == BNM_QAT_BINARY) qat_weight_stats_kernel<<<dim3(1), dim3(1024), 0, st>>>(w, cnt, stats);
     qat_weight_quant_kernel<<<dim3((unsigned)((cnt + 255u) / 256u)), dim3(256), 0, st>>>(w, cout, d, s, 1u, qt, stats, kpad, uT,
                                                                                    w_scale, nullptr);
-    const size_t lds_bytes = ((size_t)(h + 2u * pad) * (wd + 2u * pad) + (size_t)(cout / cin) * d) * sizeof(float);
-    qat_bitconv2d_fwd_kernel<<<dim3((unsigned)(n * cin)), dim3(256), lds_bytes, st>>>(x, cin, h, wd, uT, w_scale, cout, kpad, kh, kw,
-                                                                                     pad, qt, nt, y);
+    const size_t lds_bytes = bnmk_qat_bitconv2d_lds_bytes(cin, h, wd, cout, kh, kw, pad, groups);
+    if (lds_bytes > 64u * 1024u) {
+        e = hipFuncSetAttribute((const void *)qat_bitconv2d_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    qat_bitconv2d_fwd_kernel<<<dim3((unsigned)(n * groups)), dim3(256), lds_bytes, st>>>(x, cin, h, wd, uT, w_scale, cout, kpad, kh, kw,
+                                                                                        pad, stride, groups, qt, nt, y);
     return hipGetLastError();
 }
 

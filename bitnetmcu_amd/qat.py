@@ -12,9 +12,8 @@ What is and is not native:
     (`ste_backward`); BitConv2d's backward re-runs the restated expression `ste_conv_formula` under autograd.  Neither
     is a hand-written HIP kernel (training is minutes-long on MNIST; row 4 is the lowest-ranked "next" item);
   * CPU tensors: refused.  There is no CPU implementation of the op in the product path.
-  * `BitConv2d` (BitNetMCU.py:264-322): forward native for the configuration the reference's CNN uses
-    (models.py:111-116: stride 1, one input channel per group — single-channel input or depthwise); other group
-    structures are refused.
+  * `BitConv2d` (BitNetMCU.py:264-322): forward native for any group structure and stride (the reference's CNN uses
+    stride 1 with a single-channel first layer and depthwise groups, models.py:111-116); PerTensor clipping scalar.
 """
 import ctypes as C
 
@@ -88,12 +87,15 @@ def _pair(v):
 
 
 def bitconv2d_forward(x, w, s, quant_type, norm_type, stride=1, padding=0, groups=1):
-    """y = F.conv2d(act_quant(Normalize(x)), weight_quant(w)) on the GPU for stride 1 and one input channel per group.
-    x [n,cin,h,w], w [cout,1,kh,kw], s the PerTensor clipping scalar; float32 CUDA tensors."""
+    """y = F.conv2d(act_quant(Normalize(x)), weight_quant(w), stride, padding, groups) on the GPU: any group structure, any
+    (square) stride, symmetric zero padding.  x [n,cin,h,w], w [cout,cin/groups,kh,kw], s the PerTensor clipping scalar; float32
+    CUDA tensors.  (PerOutput clipping is not offered for the convolution: the reference's own PerOutput scalars do not broadcast
+    against a 4-D weight, BitNetMCU.py:102-108 / :136-148.)"""
     if not (x.is_cuda and w.is_cuda):
         raise RuntimeError("bitconv2d_forward is a GPU op: x and w must be CUDA tensors (there is no CPU path)")
-    if _pair(stride) != (1, 1):
-        raise NotImplementedError("bitconv2d_forward: stride 1 only")
+    sh, sw = _pair(stride)
+    if sh != sw:
+        raise NotImplementedError("bitconv2d_forward: square stride only")
     ph, pw = _pair(padding)
     if ph != pw:
         raise NotImplementedError("bitconv2d_forward: symmetric padding only")
@@ -102,17 +104,17 @@ def bitconv2d_forward(x, w, s, quant_type, norm_type, stride=1, padding=0, group
     w4 = w.contiguous().float()
     n, cin, h, wd = x4.shape
     cout, cpg, kh, kw = w4.shape
-    if cpg != 1:
-        raise NotImplementedError("bitconv2d_forward: one input channel per group only")
+    if cin % groups or cout % groups or cpg != cin // groups:
+        raise ValueError("w must be [cout, cin / groups, kh, kw] with cin and cout multiples of groups")
     s2 = torch.as_tensor(s, dtype=torch.float32, device=x.device).reshape(-1).contiguous()
     if s2.numel() != 1:
         raise NotImplementedError("bitconv2d_forward: PerTensor clipping scalar only")
-    y = torch.empty((n, cout, h + 2 * ph - kh + 1, wd + 2 * ph - kw + 1), dtype=torch.float32, device=x.device)
-    ws = _workspace(x.device, kh * kw, cout)
+    y = torch.empty((n, cout, (h + 2 * ph - kh) // sh + 1, (wd + 2 * ph - kw) // sh + 1), dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device, cpg * kh * kw, cout)
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream().cuda_stream
         L.check(lib, lib.bnm_qat_bitconv2d_forward_device(
-            C.c_void_p(x4.data_ptr()), n, cin, h, wd, C.c_void_p(w4.data_ptr()), cout, kh, kw, ph, groups,
+            C.c_void_p(x4.data_ptr()), n, cin, h, wd, C.c_void_p(w4.data_ptr()), cout, kh, kw, ph, sh, groups,
             C.c_void_p(s2.data_ptr()), QUANT_TYPES[quant_type], NORM_TYPES[norm_type], C.c_void_p(y.data_ptr()),
             C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.c_void_p(stream)), "bnm_qat_bitconv2d_forward_device")
     return y
@@ -334,7 +336,7 @@ class BitLinear(nn.Linear):
 
 class BitConv2d(nn.Conv2d):
     """Stand-in for the reference's BitConv2d (BitNetMCU.py:264-322): same constructor and attributes; forward runs
-    the fused HIP op on CUDA inputs (stride 1, one input channel per group)."""
+    the fused HIP op on CUDA inputs (any groups / stride)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding, groups=1, QuantType="4bitsym",
                  WScale="PerTensor", NormType="RMS"):

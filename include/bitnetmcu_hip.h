@@ -224,16 +224,15 @@ BNM_API int bnm_qat_bitlinear_forward_device(const float *d_x, uint64_t n, uint3
                                              float *d_x_int_out, float *d_x_scale_out, float *d_w_deq_out,
                                              void *stream);
 
-/* BitConv2d forward (BitNetMCU.py:264-322) in the configuration the reference's CNN uses (models.py:111-116):
- * stride 1, ONE input channel per group — either in_channels == 1 with groups == 1, or depthwise
- * (groups == in_channels, out_channels a multiple of it) — kernel kh x kw, symmetric zero padding `pad`,
- * PerTensor clipping scalar.  d_x [n][cin][h][w], d_w [cout][1][kh][kw], d_y [n][cout][h+2p-kh+1][w+2p-kw+1], float32.
- * norm_type: BNM_QAT_NORM_RMS (over each plane) or BNM_QAT_NORM_NONE.  Activations are quantised per image row
- * (the reference's max over the last dimension).  workspace: bnm_qat_workspace_bytes(kh*kw, cout) bytes.
- * Other group structures return BNM_EUNSUPPORTED. */
+/* BitConv2d forward (BitNetMCU.py:264-322): any group structure (groups = 1, depthwise as in models.py:111-116, anything
+ * between), any stride, kernel kh x kw, symmetric zero padding `pad`, PerTensor clipping scalar.
+ * d_x [n][cin][h][w], d_w [cout][cin/groups][kh][kw], d_y [n][cout][(h+2p-kh)/stride+1][(w+2p-kw)/stride+1], float32.
+ * norm_type: BNM_QAT_NORM_RMS (over each plane) or BNM_QAT_NORM_NONE.  Activations are quantised per image row of each plane
+ * (the reference's max over the last dimension).  workspace: bnm_qat_workspace_bytes((cin/groups)*kh*kw, cout) bytes.
+ * BNM_EUNSUPPORTED when one group's input planes + weights exceed 160 KiB of LDS. */
 BNM_API int bnm_qat_bitconv2d_forward_device(const float *d_x, uint64_t n, uint32_t cin, uint32_t h, uint32_t w,
                                              const float *d_w, uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad,
-                                             uint32_t groups, const float *d_s, int quant_type, int norm_type,
+                                             uint32_t stride, uint32_t groups, const float *d_s, int quant_type, int norm_type,
                                              float *d_y, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* ---- synthetic workload + digests ---------------------------------------- */

@@ -72,10 +72,12 @@ def test_qat_entry_points_validate_arguments_before_touching_the_device(bnm):
     assert b"workspace" in bnm.bnm_last_error() or b"null" in bnm.bnm_last_error()
     conv = bnm.bnm_qat_bitconv2d_forward_device
     wsc = bnm.bnm_qat_workspace_bytes(9, 8)
-    assert conv(p, 1, 4, 8, 8, p, 8, 3, 3, 0, 2, p, 10, 4, p, p, wsc, None) == EUNSUP           # two channels per group
-    assert conv(p, 1, 1, 2, 2, p, 8, 3, 3, 0, 1, p, 10, 4, p, p, wsc, None) == EINVAL           # kernel larger than the plane
-    assert conv(p, 1, 1, 8, 8, p, 8, 3, 3, 0, 1, p, 10, 3, p, p, wsc, None) == EINVAL           # LayerNorm is not a conv NormType
-    assert conv(p, 1, 1, 300, 300, p, 8, 3, 3, 0, 1, p, 10, 4, p, p, wsc, None) == EUNSUP       # plane exceeds the LDS tile
+    assert conv(p, 1, 4, 8, 8, p, 8, 3, 3, 0, 1, 3, p, 10, 4, p, p, wsc, None) == EINVAL        # channels not a multiple of groups
+    assert conv(p, 1, 1, 2, 2, p, 8, 3, 3, 0, 1, 1, p, 10, 4, p, p, wsc, None) == EINVAL        # kernel larger than the plane
+    assert conv(p, 1, 1, 8, 8, p, 8, 3, 3, 0, 1, 1, p, 10, 3, p, p, wsc, None) == EINVAL        # LayerNorm is not a conv NormType
+    assert conv(p, 1, 1, 8, 8, p, 8, 3, 3, 0, 0, 1, p, 10, 4, p, p, wsc, None) == EINVAL        # stride 0
+    assert conv(p, 1, 1, 300, 300, p, 8, 3, 3, 0, 1, 1, p, 10, 4, p, p, wsc, None) == EUNSUP    # plane exceeds 160 KiB of LDS
+    assert conv(p, 1, 4, 8, 8, p, 8, 3, 3, 0, 1, 2, p, 10, 4, p, p, 16, None) == EINVAL         # workspace too small for d = 2 * 9
 
 
 def test_header_is_plain_c_and_the_c_example_links(tmp_path):

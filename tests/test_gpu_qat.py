@@ -18,6 +18,7 @@ import numpy as np
 import pytest
 import torch
 
+import bitnetmcu_amd as b
 from bitnetmcu_amd import qat
 from util import GOLDEN
 
@@ -165,6 +166,37 @@ def test_bitconv2d_forward(tag, cfg, gpu_ok):
     assert (rel < 2e-5).mean() > 0.995 and rel.max() < 2e-2, (tag, rel.max(), (rel < 2e-5).mean())
 
 
+GENERAL_CONV = [("g2", 3, 1, 1, 2, "4bitsym", "RMS"), ("full", 3, 1, 0, 1, "8bit", "None"), ("dw_s2", 3, 2, 1, 6, "4bitsym", "RMS"),
+                ("g2_s2", 3, 2, 0, 2, "Ternary", "RMS"), ("k5", 5, 1, 2, 1, "2bitsym", "None"), ("k1_s3", 1, 3, 0, 4, "8bit", "RMS")]
+GC = np.load(os.path.join(GOLDEN, "qat_bitconv2d_general.npz"))
+
+
+@pytest.mark.parametrize("tag,ks,stride,pad,groups,qt,nt", GENERAL_CONV)
+def test_bitconv2d_general_forward_and_module(tag, ks, stride, pad, groups, qt, nt, gpu_ok):
+    """BitConv2d beyond the reference CNN's two layer kinds: groups between 1 and depthwise, stride 2 / 3, 5 x 5 and 1 x 1 kernels,
+    a non-square plane - forward against the reference module's y (same tolerance as above), the drop-in module's gradients
+    against the reference's."""
+    gd = lambda k: torch.from_numpy(GC[k]).cuda()
+    y = qat.bitconv2d_forward(gd(f"{tag}/x"), gd(f"{tag}/w"), gd(f"{tag}/s"), qt, nt, stride, (pad, pad), groups)
+    ref = GC[f"{tag}/y"]
+    assert tuple(y.shape) == ref.shape
+    rel = np.abs(y.cpu().numpy() - ref) / np.abs(ref).max()
+    assert (rel < 2e-5).mean() > 0.995 and rel.max() < 2e-2, (tag, rel.max(), (rel < 2e-5).mean())
+    cout, cpg = GC[f"{tag}/w"].shape[:2]
+    layer = qat.BitConv2d(cpg * groups, cout, kernel_size=ks, stride=stride, padding=(pad, pad), groups=groups, QuantType=qt, NormType=nt).cuda()
+    with torch.no_grad():
+        layer.weight.copy_(gd(f"{tag}/w"))
+    layer.update_clipping_scalar(layer.weight.data, "prop", 0.25)
+    assert np.allclose(layer.s.detach().cpu().numpy().reshape(-1), GC[f"{tag}/s"], rtol=1e-6)
+    x = gd(f"{tag}/x").requires_grad_(True)
+    ym = layer(x)
+    (ym * gd(f"{tag}/gy")).sum().backward()
+    relm = np.abs(ym.detach().cpu().numpy() - ref) / np.abs(ref).max()      # (the module's own s may differ from the fixture's in the last ulp)
+    assert (relm < 2e-5).mean() > 0.995 and relm.max() < 2e-2
+    assert np.abs(x.grad.cpu().numpy() - GC[f"{tag}/gx"]).max() <= 1e-3 * np.abs(GC[f"{tag}/gx"]).max()
+    assert np.abs(layer.weight.grad.cpu().numpy() - GC[f"{tag}/gw"]).max() <= 1e-3 * np.abs(GC[f"{tag}/gw"]).max()
+
+
 def test_bitconv2d_module_forward_backward_and_refusals(gpu_ok):
     for tag, (cin, cout, groups, qt, nt, pad) in (CONV_CASES[0], CONV_CASES[2]):
         layer = qat.BitConv2d(cin, cout, kernel_size=3, stride=1, padding=(pad, pad), groups=groups, QuantType=qt, NormType=nt).cuda()
@@ -180,8 +212,10 @@ def test_bitconv2d_module_forward_backward_and_refusals(gpu_ok):
         assert np.abs(x.grad.cpu().numpy() - G[f"{tag}/gx"]).max() <= 1e-3 * np.abs(G[f"{tag}/gx"]).max()
         assert np.abs(layer.weight.grad.cpu().numpy() - G[f"{tag}/gw"]).max() <= 1e-3 * np.abs(G[f"{tag}/gw"]).max()
     x = torch.randn(2, 4, 8, 8, device="cuda")
-    with pytest.raises(NotImplementedError):
-        qat.bitconv2d_forward(x, torch.randn(8, 2, 3, 3, device="cuda"), torch.ones(1), "8bit", "None", 1, 0, 2)
-    with pytest.raises(NotImplementedError):
-        qat.bitconv2d_forward(x, torch.randn(4, 1, 3, 3, device="cuda"), torch.ones(1), "8bit", "None", 2, 0, 4)
+    with pytest.raises(ValueError):          # weight shape does not match the group structure
+        qat.bitconv2d_forward(x, torch.randn(8, 1, 3, 3, device="cuda"), torch.ones(1), "8bit", "None", 1, 0, 2)
+    with pytest.raises(NotImplementedError):  # PerOutput clipping scalars
+        qat.bitconv2d_forward(x, torch.randn(4, 1, 3, 3, device="cuda"), torch.ones(4), "8bit", "None", 1, 0, 4)
+    with pytest.raises(b.BnmError):           # one group's planes do not fit 160 KiB of LDS
+        qat.bitconv2d_forward(torch.randn(1, 64, 40, 40, device="cuda"), torch.randn(8, 64, 3, 3, device="cuda"), torch.ones(1), "8bit", "None", 1, 0, 1)
     assert qat.bitconv2d_forward(x[:0], torch.randn(4, 1, 3, 3, device="cuda"), torch.ones(1), "8bit", "None", 1, 0, 4).shape == (0, 4, 6, 6)

@@ -101,6 +101,24 @@ def test_conv_formula_equals_reference(tag, cfg):
         assert torch.equal(gx, t(f"{tag}/gx")) and torch.equal(gw, t(f"{tag}/gw"))
 
 
+GENERAL_CONV = [("g2", 3, 1, 1, 2, "4bitsym", "RMS"), ("full", 3, 1, 0, 1, "8bit", "None"), ("dw_s2", 3, 2, 1, 6, "4bitsym", "RMS"),
+                ("g2_s2", 3, 2, 0, 2, "Ternary", "RMS"), ("k5", 5, 1, 2, 1, "2bitsym", "None"), ("k1_s3", 1, 3, 0, 4, "8bit", "RMS")]
+
+
+@pytest.mark.parametrize("tag,ks,stride,pad,groups,qt,nt", GENERAL_CONV)
+def test_general_conv_formula_equals_reference(tag, ks, stride, pad, groups, qt, nt):
+    """any groups / stride / kernel size: the restated expression (the module's backward) reproduces the reference module's outputs
+    and gradients bit for bit (fixtures: tests/golden/make_qat_conv_general_golden.py)"""
+    g = np.load(os.path.join(GOLDEN, "qat_bitconv2d_general.npz"))
+    tt = lambda k: torch.from_numpy(g[k])
+    x = tt(f"{tag}/x").clone().requires_grad_(True)
+    w = tt(f"{tag}/w").clone().requires_grad_(True)
+    y = qat.ste_conv_formula(x, w, tt(f"{tag}/s")[0], qt, nt, stride, (pad, pad), groups)
+    assert torch.equal(y, tt(f"{tag}/y"))
+    gx, gw = torch.autograd.grad(y, (x, w), tt(f"{tag}/gy"))
+    assert torch.equal(gx, tt(f"{tag}/gx")) and torch.equal(gw, tt(f"{tag}/gw"))
+
+
 def test_conv_module_mirrors_reference_constructor():
     layer = qat.BitConv2d(16, 16, kernel_size=3, stride=1, padding=(0, 0), groups=16, QuantType="8bit", NormType="None")
     assert layer.weight.shape == (16, 1, 3, 3) and layer.bias is None and layer.bpw == 8 and not layer.s.requires_grad
