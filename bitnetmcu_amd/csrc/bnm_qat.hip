@@ -13,7 +13,10 @@
 //                             and the per-output scale w_scale [kpad]
 //   qat_batch_stats_kernel    per-feature mean and sqrt(var + 1e-5) over the batch (NormType BatchNorm only)
 //   qat_bitlinear_fwd_kernel  32 rows per workgroup: normalise + quantise each row into an LDS tile (one
-//                             wavefront per row), then Y^T[32 outs x 32 rows] tiles on v_mfma_f32_32x32x2_f32
+//                             wavefront per row), then Y^T[32 outs x 32 rows] tiles on the matrix cores:
+//                             v_mfma_i32_32x32x32_i8 when the weight levels (x2 for half-integer types) fit int8 - Binary,
+//                             BinarySym, Ternary, 2bitsym, 4bitsym, 5bitsym, 8bit: the integer sums are the same exact values
+//                             the fp32 path produces, 16 K-steps per instruction instead of 1 - else v_mfma_f32_32x32x2_f32
 #include "bnm_device.hpp"
 #include "../../include/bitnetmcu_hip.h"
 
@@ -54,6 +57,21 @@ BNM_DEVICE float qat_weight_scale(int qt, float s, float mean_abs) {
 }
 
 BNM_DEVICE float sign_of(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+// int8 matrix path: factor f such that f * level is an integer in [-128, 127] for every level of the type; 0 = not eligible
+// (FP130 reaches +-128 -> +128 does not fit; 4bit's levels carry +0.01; NF4's are not dyadic; None has no levels)
+__host__ __device__ inline int qat_i8_factor(int qt) {
+    switch (qt) {
+        case BNM_QAT_BINARY:
+        case BNM_QAT_BINARYSYM:
+        case BNM_QAT_TERNARY:
+        case BNM_QAT_8BIT: return 1;
+        case BNM_QAT_2BITSYM:
+        case BNM_QAT_4BITSYM:
+        case BNM_QAT_5BITSYM: return 2;
+    }
+    return 0;
+}
 
 // weight_quant's level for one weight (BitNetMCU.py:150-177).  Explicit __fmul_rn/__fsub_rn: the reference rounds
 // after the multiply, so the compiler must not contract w*scale - 0.5 into one fma.
@@ -121,13 +139,15 @@ __global__ __launch_bounds__(256) void qat_weight_quant_kernel(const float *__re
                                                                const float *__restrict__ s, uint32_t s_count, int qt,
                                                                const float *__restrict__ stats, uint32_t kpad,
                                                                float *__restrict__ uT, float *__restrict__ w_scale,
-                                                               float *__restrict__ w_deq_out) {
+                                                               float *__restrict__ w_deq_out, int8_t *__restrict__ u8,
+                                                               uint32_t d8) {
     const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (idx >= (uint64_t)k * d) return;
     const uint32_t row = (uint32_t)(idx / d), col = (uint32_t)(idx % d);
     const float sc = qat_weight_scale(qt, s[s_count > 1 ? row : 0], stats[0]);
     const float u = qat_weight_level(qt, w[idx], sc, stats[1]);
     uT[(uint64_t)col * kpad + row] = u;
+    if (u8) u8[(uint64_t)row * d8 + col] = (int8_t)(int)((float)qat_i8_factor(qt) * u);      // exact: an integer in [-128, 127]
     if (w_deq_out) w_deq_out[idx] = qt == BNM_QAT_NONE ? u : __fdiv_rn(u, sc);   // w_int / w_scale, the STE forward value
     if (col == 0) w_scale[row] = sc;
 }
@@ -155,11 +175,14 @@ __global__ __launch_bounds__(64 * QAT_WAVES) void qat_bitlinear_fwd_kernel(
     const float *__restrict__ x, uint64_t n, uint32_t d, uint32_t dpad, const float *__restrict__ uT,
     const float *__restrict__ w_scale, uint32_t k, uint32_t kpad, int qt, int nt, const float *__restrict__ bn_mean,
     const float *__restrict__ bn_den, float *__restrict__ y, float *__restrict__ x_int_out,
-    float *__restrict__ x_scale_out) {
+    float *__restrict__ x_scale_out, const int8_t *__restrict__ u8, uint32_t d8) {
     extern __shared__ float lds[];
     const uint32_t rs = dpad + 1u;
     float *q = lds;
     float *xs = lds + QAT_ROWS * rs;
+    // int8 path: the quantised activations once more as bytes, rows of d8 + 16 (K padded to 32 with zeros; +16: bank spread)
+    const uint32_t rs8 = d8 + 16u;
+    int8_t *q8 = (int8_t *)(xs + QAT_ROWS);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t row0 = (uint64_t)blockIdx.x * QAT_ROWS;
 
@@ -167,6 +190,8 @@ __global__ __launch_bounds__(64 * QAT_WAVES) void qat_bitlinear_fwd_kernel(
     for (int r = wave; r < QAT_ROWS; r += QAT_WAVES) {
         float *qr = q + r * rs;
         const uint64_t row = row0 + (uint64_t)r;
+        if (u8)
+            for (uint32_t c = lane; c < rs8 / 4u; c += 64) ((int *)(q8 + r * rs8))[c] = 0;        // zero K padding (and dead rows)
         if (row >= n) {
             for (uint32_t c = lane; c < rs; c += 64) qr[c] = 0.0f;
             if (lane == 0) xs[r] = 1.0f;
@@ -210,6 +235,7 @@ __global__ __launch_bounds__(64 * QAT_WAVES) void qat_bitlinear_fwd_kernel(
         for (uint32_t c = lane; c < d; c += 64) {
             float v = fminf(fmaxf(rintf(__fmul_rn(qr[c], sc)), -128.0f), 127.0f);
             qr[c] = v;
+            if (u8) q8[r * rs8 + c] = (int8_t)(int)v;
             if (x_int_out) x_int_out[row * d + c] = v;
         }
         if (lane == 0) {
@@ -222,12 +248,28 @@ __global__ __launch_bounds__(64 * QAT_WAVES) void qat_bitlinear_fwd_kernel(
     // ---- phase 2: Y^T tile = U[32 outs x K] * Q^T[K x 32 rows] on the fp32 matrix cores ----------------------
     const int i = lane & 31, h = lane >> 5;
     const uint32_t mtiles = kpad / 32u;
+    const float inv_f = u8 ? 1.0f / (float)qat_i8_factor(qt) : 1.0f;
     for (uint32_t m = wave; m < mtiles; m += QAT_WAVES) {
         f32x16 acc = {0};
-        const float *ap = uT + (uint64_t)h * kpad + 32u * m + i;   // A[out i][k = 2*s + h]
-        const float *bp = q + i * rs + h;                          // B[k = 2*s + h][row i]
-        for (uint32_t s2 = 0; s2 < dpad / 2u; s2++)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(uint64_t)2u * s2 * kpad], bp[2u * s2], acc, 0, 0, 0);
+        if (u8) {
+            // int8 matrix cores: A = 16 weight bytes of output 32m + i at K = 32s + 16h .., B = 16 activation bytes of row i.
+            // The int32 sums are exact, |sum| <= 1024 * 128 * 127 < 2^24, so the float conversion and the division by the
+            // factor are exact too: bit-identical to the fp32 path's sums.
+            i32x16 ai;
+#pragma unroll
+            for (int r = 0; r < 16; r++) ai[r] = 0;
+            const int8_t *ap8 = u8 + (uint64_t)(32u * m + (uint32_t)i) * d8 + 16u * (uint32_t)h;
+            const int8_t *bp8 = q8 + (uint32_t)i * rs8 + 16u * (uint32_t)h;
+            for (uint32_t s8 = 0; s8 < d8 / 32u; s8++)
+                ai = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const i32x4 *)(ap8 + 32u * s8), *(const i32x4 *)(bp8 + 32u * s8), ai, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = (float)ai[r] * inv_f;
+        } else {
+            const float *ap = uT + (uint64_t)h * kpad + 32u * m + i;   // A[out i][k = 2*s + h]
+            const float *bp = q + i * rs + h;                          // B[k = 2*s + h][row i]
+            for (uint32_t s2 = 0; s2 < dpad / 2u; s2++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(uint64_t)2u * s2 * kpad], bp[2u * s2], acc, 0, 0, 0);
+        }
         const uint64_t row = row0 + (uint64_t)i;
         if (row >= n) continue;
         const float xsc = xs[i];
@@ -336,7 +378,7 @@ hipError_t bnmk_qat_bitconv2d_forward(const float *x, uint64_t n, uint32_t cin, 
     const uint64_t cnt = (uint64_t)cout * d;
     if (qt == BNM_QAT_TERNARY || qt == BNM_QAT_BINARY) qat_weight_stats_kernel<<<dim3(1), dim3(1024), 0, st>>>(w, cnt, stats);
     qat_weight_quant_kernel<<<dim3((unsigned)((cnt + 255u) / 256u)), dim3(256), 0, st>>>(w, cout, d, s, 1u, qt, stats, kpad, uT,
-                                                                                   w_scale, nullptr);
+                                                                                   w_scale, nullptr, nullptr, 0u);
     const size_t lds_bytes = bnmk_qat_bitconv2d_lds_bytes(cin, h, wd, cout, kh, kw, pad, groups);
     if (lds_bytes > 64u * 1024u) {
         e = hipFuncSetAttribute((const void *)qat_bitconv2d_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -347,9 +389,10 @@ hipError_t bnmk_qat_bitconv2d_forward(const float *x, uint64_t n, uint32_t cin, 
     return hipGetLastError();
 }
 
+// float part: uT [dpad][kpad], w_scale [kpad], stats [4], BatchNorm mean / den [2 d]; then the int8 weight rows [kpad][d8]
 size_t bnmk_qat_workspace_bytes(uint32_t d, uint32_t k) {
-    const size_t dpad = (d + 1u) & ~1u, kpad = (k + 31u) & ~31u;
-    return (dpad * kpad + kpad + 4u + 2u * (size_t)d) * sizeof(float);
+    const size_t dpad = (d + 1u) & ~1u, kpad = (k + 31u) & ~31u, d8 = ((size_t)d + 31u) & ~(size_t)31u;
+    return (dpad * kpad + kpad + 4u + 2u * (size_t)d) * sizeof(float) + kpad * d8;
 }
 
 hipError_t bnmk_qat_bitlinear_forward(const float *x, uint64_t n, uint32_t d, const float *w, uint32_t k, const float *s,
@@ -360,23 +403,28 @@ hipError_t bnmk_qat_bitlinear_forward(const float *x, uint64_t n, uint32_t d, co
     float *w_scale = uT + (size_t)dpad * kpad;
     float *stats = w_scale + kpad;
     float *bn_mean = stats + 4, *bn_den = bn_mean + d;
+    const uint32_t d8 = (d + 31u) & ~31u;
+    // int8 matrix path for the types that allow it - unless the extra byte tile no longer fits beside the float tile (d > ~900)
+    const bool i8_fits = ((size_t)QAT_ROWS * (dpad + 1u) + QAT_ROWS) * sizeof(float) + (size_t)QAT_ROWS * (d8 + 16u) <= 160u * 1024u;
+    int8_t *u8 = (qat_i8_factor(qt) && i8_fits) ? (int8_t *)(bn_den + d) : nullptr;
     hipError_t e = hipMemsetAsync(workspace, 0, ((size_t)dpad * kpad + kpad + 4u) * sizeof(float), st);
     if (e != hipSuccess) return e;
+    if (u8 && (e = hipMemsetAsync(u8, 0, (size_t)kpad * d8, st)) != hipSuccess) return e;
     if (n == 0) return hipSuccess;
     if (qt == BNM_QAT_TERNARY || qt == BNM_QAT_BINARY)
         qat_weight_stats_kernel<<<dim3(1), dim3(1024), 0, st>>>(w, (uint64_t)k * d, stats);
     const uint64_t cnt = (uint64_t)k * d;
     qat_weight_quant_kernel<<<dim3((unsigned)((cnt + 255u) / 256u)), dim3(256), 0, st>>>(w, k, d, s, s_count, qt, stats, kpad, uT,
-                                                                                   w_scale, w_deq_out);
+                                                                                   w_scale, w_deq_out, u8, d8);
     if (nt == BNM_QAT_NORM_BATCHNORM)
         qat_batch_stats_kernel<<<dim3((d + 255u) / 256u), dim3(256), 0, st>>>(x, n, d, bn_mean, bn_den);
-    const size_t lds_bytes = ((size_t)QAT_ROWS * (dpad + 1u) + QAT_ROWS) * sizeof(float);
+    const size_t lds_bytes = ((size_t)QAT_ROWS * (dpad + 1u) + QAT_ROWS) * sizeof(float) + (u8 ? (size_t)QAT_ROWS * (d8 + 16u) : 0u);
     if (lds_bytes > 64u * 1024u) {
         e = hipFuncSetAttribute((const void *)qat_bitlinear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
     const uint64_t blocks = (n + QAT_ROWS - 1) / QAT_ROWS;
     qat_bitlinear_fwd_kernel<<<dim3((unsigned)blocks), dim3(64 * QAT_WAVES), lds_bytes, st>>>(
-        x, n, d, dpad, uT, w_scale, k, kpad, qt, nt, bn_mean, bn_den, y, x_int_out, x_scale_out);
+        x, n, d, dpad, uT, w_scale, k, kpad, qt, nt, bn_mean, bn_den, y, x_int_out, x_scale_out, u8, d8);
     return hipGetLastError();
 }
