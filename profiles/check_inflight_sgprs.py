@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Static check of the streamed ternary kernels (no GPU needed): between an asm-issued s_load_dwordx16 and the s_waitcnt
-lgkmcnt(0) that retires it, no instruction may read or write the destination scalar registers (a compiler copy or spill
-there would move a value that has not landed).  Reads bitnetmcu_amd/_build/bnm_ternary.o; exit status 1 on a violation."""
+"""Static checks of compiler-invisible scalar memory operations (no GPU needed): between an asm-issued s_load_dwordx16 (streamed
+ternary kernels) or s_atomic_add (work-counter takes of the fused kernels) and the s_waitcnt lgkmcnt(0) that retires it, no
+instruction may read or write the destination scalar registers (a compiler copy or spill there would move a value that has not
+landed).  Reads bitnetmcu_amd/_build/*.o; exit status 1 on a violation."""
 import os
 import re
 import subprocess
@@ -15,7 +16,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 def disasm(obj):
     with tempfile.TemporaryDirectory() as t:
         fat, co = os.path.join(t, "fat"), os.path.join(t, "k.co")
-        subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj])
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj], stderr=subprocess.DEVNULL)
         subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                                f"--input={fat}", f"--output={co}"])
         return subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
@@ -30,7 +31,44 @@ def sregs(text):
     return out
 
 
+def check_takes():
+    """work_take_issue / work_take_wait (bnm_device.hpp): between an s_atomic_add and the next s_waitcnt lgkmcnt(0) nothing may
+    read or write the atomic's result register."""
+    import glob
+    bad, takes = [], 0
+    for obj in sorted(glob.glob(os.path.join(REPO, "bitnetmcu_amd", "_build", "*.o"))):
+        try:
+            asm = disasm(obj)
+        except subprocess.CalledProcessError:
+            continue
+        kernel, reg = None, None
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                kernel, reg = m.group(1), None
+                continue
+            ins = line.split("//")[0].strip()
+            if not ins:
+                continue
+            m = re.match(r"s_atomic_add s(\d+),", ins)
+            if m:
+                reg = int(m.group(1))
+                takes += 1
+                continue
+            if ins.startswith("s_waitcnt") and "lgkmcnt(0)" in ins:
+                reg = None
+                continue
+            if reg is not None and reg in sregs(ins):
+                bad.append((os.path.basename(obj), (kernel or "")[:40], ins))
+    print(f"{takes} scalar work-counter takes checked, {len(bad)} instructions touch a result register in flight")
+    for b in bad[:20]:
+        print("  ", b)
+    return bad
+
+
 def main():
+    if check_takes():
+        return 1
     asm = disasm(os.path.join(REPO, "bitnetmcu_amd", "_build", "bnm_ternary.o"))
     bad, kernel, inflight, loads = [], None, set(), 0
     for line in asm.splitlines():
