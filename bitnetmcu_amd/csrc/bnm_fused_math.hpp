@@ -124,14 +124,28 @@ BNM_DEVICE uint32_t argmax_rows(const i32x16 (&acc)[MT], int h) {
     return 255u - ((uint32_t)best & 255u);
 }
 
+// A lane holds, per tile and per group q of four accumulator registers, the four CONSECUTIVE rows 32m + 8q + 4h .. +3 of its
+// image: they leave as one 16-byte store (8 bytes when exactly two of them are classes, e.g. rows 8-9 of 10), element-wise only
+// for other ragged ends.  (Sixteen predicated dword stores per tile cost the logits configuration ~10 % of its time.)
 template <int MT>
 BNM_DEVICE void store_logits(const i32x16 (&acc)[MT], int32_t *dst, int h, uint32_t n_classes) {
+    // (a logits row starts at 4 n_classes bytes x the image index: dword-aligned only, which is all a global b64 / b128 store needs)
+    typedef int v4a4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef int v2a4 __attribute__((ext_vector_type(2), aligned(4)));
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            uint32_t row = 32u * m + (r & 3) + 8u * (r >> 2) + 4u * h;
-            if (row < n_classes) dst[row] = acc[m][r];
+        for (int q = 0; q < 4; q++) {
+            const uint32_t row = 32u * m + 8u * q + 4u * (uint32_t)h;
+            if (row + 4u <= n_classes) {
+                *(v4a4 *)(dst + row) = v4a4{acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]};
+            } else if (row + 2u == n_classes) {
+                *(v2a4 *)(dst + row) = v2a4{acc[m][4 * q], acc[m][4 * q + 1]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (row + (uint32_t)e < n_classes) dst[row + e] = acc[m][4 * q + e];
+            }
         }
 }
 
