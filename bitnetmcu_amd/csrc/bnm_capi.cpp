@@ -211,6 +211,7 @@ struct bnm_ctx {
 namespace {
 
 constexpr uint64_t kChunk = 1ull << 20;   // images per internal chunk of the staged / layer-wise paths
+constexpr uint64_t kCnnChunk = 1ull << 22;   // images per launch of the CNN front end when the fused FC tail follows
 
 int resolve_path(bnm_ctx *c) {
     int want = c->requested_path;
@@ -510,12 +511,18 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
     const uint32_t W = c->channels * 4u;
     // act rows: 4*C bytes, padded to the generic kernel's row length when that kernel runs the FC tail
     const uint32_t AS = (path == BNM_PATH_FUSED_MFMA && c->variant == BNM_FUSED_GENERIC) ? c->gdesc.KT0 * 32u : W;
-    for (uint64_t off = 0; off < n; off += kChunk) {
-        uint64_t cn = n - off < kChunk ? n - off : kChunk;
+    // chunks: 2^22 images when the fused tail consumes the act rows directly (1 GiB of act rows; every launch has a ramp and a
+    // tail, so fewer, larger launches: +2 % over 2^20), 2^20 when the int32 features are needed as well (> 64 channels, taps)
+    // or the layer-wise tail runs (its scratch is sized for kChunk)
+    const bool need_feat = c->channels > 64 || d_acts_tap != nullptr;
+    const uint64_t chunk = (!need_feat && path == BNM_PATH_FUSED_MFMA) ? kCnnChunk : kChunk;
+    for (uint64_t off = 0; off < n; off += chunk) {
+        uint64_t cn = n - off < chunk ? n - off : chunk;
         // the FC tail reads act rows with 16-byte vector loads: keep the buffer padded
-        if (int e = c->cnn_feat.ensure((size_t)cn * W * 4 + (size_t)cn * AS + 64)) return e;
-        int32_t *feat = (c->channels > 64 || d_acts_tap) ? (int32_t *)c->cnn_feat.p : nullptr;
-        int8_t *acts = (int8_t *)c->cnn_feat.p + (size_t)cn * W * 4;
+        const size_t feat_bytes = need_feat ? (size_t)cn * W * 4 : 0;
+        if (int e = c->cnn_feat.ensure(feat_bytes + (size_t)cn * AS + 64)) return e;
+        int32_t *feat = need_feat ? (int32_t *)c->cnn_feat.p : nullptr;
+        int8_t *acts = (int8_t *)c->cnn_feat.p + feat_bytes;
         HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,
                                c->channels, 4, acts, AS, feat, c->next_counter(), c->cnn_grab, s));
         uint32_t *cls = d_cls + off;

@@ -108,13 +108,13 @@ def test_ternary_full_size_all_kernels(gpu_ok, orc):
 
 
 def test_cnn_many_chunks_all_kernels(gpu_ok, orc):
-    """BASELINE configs[3] across the front end's internal chunks (2^20 images each) and a ragged last chunk: the MFMA front end
+    """BASELINE configs[3] across the front end's internal chunks (2^22 images each with the fused tail) and a ragged last chunk: the MFMA front end
     with dynamic batches (default, and batches of 16), with fixed shares, and round 1's VALU kernel agree on every class id;
     ids and logits around every chunk boundary, at the head / tail and on a strided sample equal the oracle's."""
     import torch
     model = util.load_golden_model("cnn_64")
     ctx = b.Context(model)
-    n = int(os.environ.get("BNM_CNN_N", str(3 * (1 << 20) + 12345)))
+    n = int(os.environ.get("BNM_CNN_N", str(2 * (1 << 22) + 12345)))      # chunks of 2^22 images with the fused tail
     imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
     synth.fill_device(imgs, first=0, dist=DIST_U)
     cls = torch.empty(n, dtype=torch.int32, device="cuda")
