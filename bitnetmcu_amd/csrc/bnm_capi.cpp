@@ -165,7 +165,8 @@ struct bnm_ctx {
     // a ring of words, one per launch, so that launches queued on different streams never share one
     uint32_t *counters = nullptr;
     uint32_t counter_next = 0;
-    uint32_t *work_words = nullptr;   // fused variant 6: work counter + one word per resident wave (bnm_kernels.h)
+    uint32_t *work_words = nullptr;   // fused variant 6: 8 blocks of {work counter + one word per resident wave} (bnm_kernels.h)
+    uint32_t work_next = 0;
     bool tern_dynamic = true;
     uint32_t work_batch = 0;      // tiles / pairs a wave of the fused kernels takes from the work counter at a time (0 = kernel default)
     uint32_t *next_counter() { return counters ? counters + 16u * (counter_next++ % 64u) : nullptr; }
@@ -277,8 +278,8 @@ int ctx_build(bnm_ctx *c) {
         if (int e = dev_alloc(c, &q, 64 * 64)) return e;
         c->counters = (uint32_t *)q;
         q = nullptr;
-        if (int e = dev_alloc(c, &q, 64 * (1 + BNM_WORK_DUMMY_WAVES))) return e;
-        HIP_TRY(hipMemset(q, 0, 64 * (1 + BNM_WORK_DUMMY_WAVES)));
+        if (int e = dev_alloc(c, &q, (size_t)8 * 64 * (1 + BNM_WORK_DUMMY_WAVES))) return e;
+        HIP_TRY(hipMemset(q, 0, (size_t)8 * 64 * (1 + BNM_WORK_DUMMY_WAVES)));
         c->work_words = (uint32_t *)q;
     }
     const uint32_t in_width = width;
@@ -436,7 +437,8 @@ int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32
 #ifdef BNM_DIAG
     a.src_wrap = c->diag_src_wrap;   // diagnostic library only (bnm_diag_set_src_wrap)
 #endif
-    a.work = c->work_words;
+    // one counter block per launch out of a ring of 8, so that launches queued on different streams never share a counter
+    a.work = c->work_words ? c->work_words + (size_t)16u * (1u + BNM_WORK_DUMMY_WAVES) * (c->work_next++ % 8u) : nullptr;
     a.batch = c->work_batch;
     HIP_TRY(bnmk_fused_fc(c->shape, c->variant, c->grid_blocks, a, s));
     return BNM_OK;

@@ -191,6 +191,33 @@ def test_cnn_front_end_both_kernels(name, gpu_ok, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("variant", [6, 4, 3])
+def test_fc_context_on_two_streams(variant, gpu_ok):
+    """Launches of ONE fused-FC context queued on two streams at once (the work counters come from a ring, one per launch): every
+    result equals the single-stream result."""
+    import torch
+    model = util.load_golden_model("fc_4bitsym_64")
+    ctx = b.Context(model)
+    ctx.set_tuning(variant=variant)
+    n = 2_000_000 + 77
+    sets = []
+    for k in range(6):
+        x = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+        synth.fill_device(x, first=k * 10_000_019, dist=DIST_U)
+        want = torch.empty(n, dtype=torch.int32, device="cuda")
+        ctx.infer_device(x, want)
+        sets.append((x, want, torch.full((n,), -1, dtype=torch.int32, device="cuda")))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for k, (x, _, got) in enumerate(sets):
+        with torch.cuda.stream(streams[k & 1]):
+            ctx.infer_device(x, got)
+    torch.cuda.synchronize()
+    for k, (_, want, got) in enumerate(sets):
+        assert torch.equal(want, got), (variant, k)
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", ["fc_4bitsym_64", "tern_96", "cnn_64"])
 def test_ragged_and_empty_batches(name, gpu_ok, orc):
     model = util.load_golden_model(name)
