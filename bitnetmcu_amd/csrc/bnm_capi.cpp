@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -190,7 +191,13 @@ struct bnm_ctx {
     uint64_t diag_src_wrap = 0;
 #endif
     // scratch
-    DevBuf act_a, act_b, out32, argmax, cnn_feat, stage_img, stage_cls, stage_logits;
+    // scratch of the CNN and layer-wise paths, one set per stream the context has been used on (launches on different
+    // streams must not share feature rows / activation buffers)
+    struct StreamScratch {
+        DevBuf act_a, act_b, out32, cnn_feat;
+    };
+    std::map<hipStream_t, StreamScratch> scratch;
+    DevBuf argmax, stage_img, stage_cls, stage_logits;
     // host-pointer paths: zero-copy buffers of the latency path (n <= kLatencyMax) and the two slots of the pipelined path
     PinBuf lat_in, lat_cls, lat_logits;
     hipStream_t lat_stream = nullptr;
@@ -449,15 +456,16 @@ int run_layerwise(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, i
                   uint32_t tap_stride, uint32_t tap_off, hipStream_t s) {
     uint32_t maxw = 0;
     for (auto &l : c->fc) maxw = l.info.n_output > maxw ? l.info.n_output : maxw;
-    if (int e = c->act_a.ensure((size_t)n * maxw)) return e;
-    if (int e = c->act_b.ensure((size_t)n * maxw)) return e;
-    if (int e = c->out32.ensure((size_t)n * maxw * 4)) return e;
+    bnm_ctx::StreamScratch &sc = c->scratch[s];
+    if (int e = sc.act_a.ensure((size_t)n * maxw)) return e;
+    if (int e = sc.act_b.ensure((size_t)n * maxw)) return e;
+    if (int e = sc.out32.ensure((size_t)n * maxw * 4)) return e;
     const int8_t *act = d_in;
-    int8_t *bufs[2] = {(int8_t *)c->act_a.p, (int8_t *)c->act_b.p};
+    int8_t *bufs[2] = {(int8_t *)sc.act_a.p, (int8_t *)sc.act_b.p};
     for (size_t i = 0; i < c->fc.size(); i++) {
         const FcDev &d = c->fc[i];
         const bool last = i + 1 == c->fc.size();
-        int32_t *out = (last && d_logits) ? d_logits : (int32_t *)c->out32.p;
+        int32_t *out = (last && d_logits) ? d_logits : (int32_t *)sc.out32.p;
         HIP_TRY(bnmk_fc_layer(act, d.act_stride, d.packed, d.info.bits_per_weight, d.info.n_input, d.info.n_output, out, n, s));
         int8_t *nxt = bufs[i & 1];
         HIP_TRY(bnmk_relunorm(out, d.info.n_output, nxt, d.info.n_output, last ? d_cls : nullptr, n, s));
@@ -522,9 +530,10 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         uint64_t cn = n - off < chunk ? n - off : chunk;
         // the FC tail reads act rows with 16-byte vector loads: keep the buffer padded
         const size_t feat_bytes = need_feat ? (size_t)cn * W * 4 : 0;
-        if (int e = c->cnn_feat.ensure(feat_bytes + (size_t)cn * AS + 64)) return e;
-        int32_t *feat = need_feat ? (int32_t *)c->cnn_feat.p : nullptr;
-        int8_t *acts = (int8_t *)c->cnn_feat.p + feat_bytes;
+        DevBuf &cnn_feat = c->scratch[s].cnn_feat;
+        if (int e = cnn_feat.ensure(feat_bytes + (size_t)cn * AS + 64)) return e;
+        int32_t *feat = need_feat ? (int32_t *)cnn_feat.p : nullptr;
+        int8_t *acts = (int8_t *)cnn_feat.p + feat_bytes;
         HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,
                                c->channels, 4, acts, AS, feat, c->next_counter(), c->cnn_grab, s));
         uint32_t *cls = d_cls + off;
@@ -635,7 +644,9 @@ void bnm_ctx_destroy(bnm_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (void *p : c->owned) (void)hipFree(p);
-    for (DevBuf *b : {&c->act_a, &c->act_b, &c->out32, &c->argmax, &c->cnn_feat, &c->stage_img, &c->stage_cls, &c->stage_logits})
+    for (auto &kv : c->scratch)
+        for (DevBuf *b : {&kv.second.act_a, &kv.second.act_b, &kv.second.out32, &kv.second.cnn_feat}) b->release();
+    for (DevBuf *b : {&c->argmax, &c->stage_img, &c->stage_cls, &c->stage_logits})
         b->release();
     for (PinBuf *b : {&c->lat_in, &c->lat_cls, &c->lat_logits}) b->release();
     if (c->lat_stream) (void)hipStreamDestroy(c->lat_stream);

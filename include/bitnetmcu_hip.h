@@ -144,11 +144,10 @@ BNM_API int bnm_ctx_get_variant(const bnm_ctx *c);
 /* Whole-model batched inference, DEVICE pointers, asynchronous on `stream` (a hipStream_t;
  * NULL = default stream).  images: int8 [n][256]; cls: uint32 [n]; logits: int32
  * [n][num_classes] or NULL.  No host synchronisation is performed on the fused FC paths.
- * The fused FC paths keep no per-launch state besides a work counter, taken from a ring (8 for the dual-tile kernel, 64 for
- * the others), so a few launches of one context may be in flight on different streams.  The CNN and layer-wise paths keep
- * per-context scratch (feature rows, activation buffers) that a second launch reuses: there, calls on different streams must
- * be ordered by the caller (events), or use one context per stream; the first call of a larger batch than any before may
- * also grow that scratch (hipMalloc / hipFree: device-synchronising). */
+ * A few launches of one context may be in flight on different streams: work counters come from a ring (8 blocks for the
+ * dual-tile kernel, 64 words for the others), and the scratch of the CNN and layer-wise paths (feature rows, activation
+ * buffers) is kept per stream.  The first call on a stream, and a call with a larger batch than any before on it, allocates
+ * or grows that scratch (hipMalloc / hipFree: device-synchronising). */
 BNM_API int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls,
                              int32_t *d_logits, void *stream);
 /* Same with HOST pointers; synchronous.  Up to 64 images: zero-copy (page-locked buffers the GPU addresses directly, one launch,

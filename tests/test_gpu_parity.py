@@ -191,15 +191,16 @@ def test_cnn_front_end_both_kernels(name, gpu_ok, orc):
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", [6, 4, 3])
-def test_fc_context_on_two_streams(variant, gpu_ok):
-    """Launches of ONE fused-FC context queued on two streams at once (the work counters come from a ring, one per launch): every
-    result equals the single-stream result."""
+@pytest.mark.parametrize("name,variant,n", [("fc_4bitsym_64", 6, 2_000_077), ("fc_4bitsym_64", 4, 2_000_077), ("fc_4bitsym_64", 3, 2_000_077),
+                                            ("tern_96", -1, 1_000_033), ("cnn_64", -1, 200_011), ("mcu_cnn_16small", -1, 100_003)])
+def test_context_on_two_streams(name, variant, n, gpu_ok):
+    """Launches of ONE context queued on two streams at once (work counters come from a ring, one per launch; the CNN / layer-wise
+    scratch is kept per stream): every result equals the single-stream result."""
     import torch
-    model = util.load_golden_model("fc_4bitsym_64")
+    model = util.load_golden_model(name)
     ctx = b.Context(model)
-    ctx.set_tuning(variant=variant)
-    n = 2_000_000 + 77
+    if variant >= 0:
+        ctx.set_tuning(variant=variant)
     sets = []
     for k in range(6):
         x = torch.empty((n, 256), dtype=torch.int8, device="cuda")
@@ -214,7 +215,7 @@ def test_fc_context_on_two_streams(variant, gpu_ok):
             ctx.infer_device(x, got)
     torch.cuda.synchronize()
     for k, (_, want, got) in enumerate(sets):
-        assert torch.equal(want, got), (variant, k)
+        assert torch.equal(want, got), (name, variant, k)
     ctx.close()
 
 
