@@ -55,6 +55,8 @@ def objects(force=False, extra_flags=(), obj_dir=None, sources=SOURCES):
         s = os.path.join(CSRC, src)
         o = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         if force or newer([s] + hdrs, o):
+            if os.path.exists(o):
+                os.remove(o)          # a failed compile must not leave an older object behind for the link step
             cmd = [HIPCC, f"--offload-arch={ARCH}"] + CXXFLAGS + list(extra_flags) + list(file_flags) + ["-c", s, "-o", o]
             if not is_hip:
                 cmd.insert(1, "-x")

@@ -162,15 +162,16 @@ struct bnm_ctx {
     int *cnn_wtab = nullptr;       // per-channel weight table of the conv1-on-MFMA front end
     int cnn_variant = 1;           // 1: conv1 on the matrix cores (default), 0: the all-VALU kernel of round 1
     uint32_t cnn_grab = 8;         // images a wave of the MFMA front end takes from the work counter at a time (0: fixed shares)
-    // work counters of the persistent kernels that hand their work out dynamically (CNN front end, streamed ternary kernel):
-    // a ring of words, one per launch, so that launches queued on different streams never share one
+    // work counters of the persistent kernels that hand their work out dynamically (CNN front end, streamed ternary kernel,
+    // generic fused kernel): a ring of 8 blocks, one per launch, so that launches queued on different streams never share one
     uint32_t *counters = nullptr;
     uint32_t counter_next = 0;
     uint32_t *work_words = nullptr;   // fused variant 6: 8 blocks of {work counter + one word per resident wave} (bnm_kernels.h)
     uint32_t work_next = 0;
     bool tern_dynamic = true;
     uint32_t work_batch = 0;      // tiles / pairs a wave of the fused kernels takes from the work counter at a time (0 = kernel default)
-    uint32_t *next_counter() { return counters ? counters + 16u * (counter_next++ % 64u) : nullptr; }
+    // (blocks of 8 words, 64 bytes apart: the generic kernel splits its counter eight ways, the others use the first word)
+    uint32_t *next_counter() { return counters ? counters + 16u * 8u * (counter_next++ % 8u) : nullptr; }
     // fused MFMA path: shape-specialised kernels (register-resident weights, bnm_fused_fc.hip) and / or the generic
     // kernel (run-time widths, weights in LDS, bnm_fused_generic.hip; variant id BNM_FUSED_GENERIC)
     bool fused_ok = false;      // at least one of the two can run this model
@@ -285,8 +286,8 @@ int ctx_build(bnm_ctx *c) {
         if (int e = dev_alloc(c, &q, 64 * 64)) return e;
         c->counters = (uint32_t *)q;
         q = nullptr;
-        if (int e = dev_alloc(c, &q, (size_t)8 * 64 * (1 + BNM_WORK_DUMMY_WAVES))) return e;
-        HIP_TRY(hipMemset(q, 0, (size_t)8 * 64 * (1 + BNM_WORK_DUMMY_WAVES)));
+        if (int e = dev_alloc(c, &q, (size_t)8 * 64 * (8 + BNM_WORK_DUMMY_WAVES))) return e;
+        HIP_TRY(hipMemset(q, 0, (size_t)8 * 64 * (8 + BNM_WORK_DUMMY_WAVES)));
         c->work_words = (uint32_t *)q;
     }
     const uint32_t in_width = width;
@@ -445,7 +446,7 @@ int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32
     a.src_wrap = c->diag_src_wrap;   // diagnostic library only (bnm_diag_set_src_wrap)
 #endif
     // one counter block per launch out of a ring of 8, so that launches queued on different streams never share a counter
-    a.work = c->work_words ? c->work_words + (size_t)16u * (1u + BNM_WORK_DUMMY_WAVES) * (c->work_next++ % 8u) : nullptr;
+    a.work = c->work_words ? c->work_words + (size_t)16u * (8u + BNM_WORK_DUMMY_WAVES) * (c->work_next++ % 8u) : nullptr;
     a.batch = c->work_batch;
     HIP_TRY(bnmk_fused_fc(c->shape, c->variant, c->grid_blocks, a, s));
     return BNM_OK;

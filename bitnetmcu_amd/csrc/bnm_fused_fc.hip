@@ -240,8 +240,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
                                                                           uint32_t n_classes, uint32_t *__restrict__ cls_out,
                                                                           int32_t *__restrict__ logits_out,
                                                                           uint64_t src_wrap, uint32_t *__restrict__ work,
-                                                                          uint32_t batch) {
+                                                                          uint32_t batch_arg) {
     constexpr int KT0 = 8;
+    const uint32_t batch = batch_arg & 0xFFFFu;
     constexpr bool SHARED = WPB == 8;          // one workgroup per CU, pairs handed out from s_next
     constexpr bool DEVWIDE = DW;   // 4-wave workgroups, batches of pairs from the device-wide counter work[0]
     __shared__ __attribute__((aligned(1024))) char smem[WPB * 2 * FUSED_TILE_BYTES];
@@ -279,7 +280,19 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
     // read, so that no lgkmcnt wait of the iteration covers it - and the loop body stays one basic block: in the iteration
     // before a batch's last pair it adds `batch` to the counter, in all others it adds 0 to a word of the wave's own
     // (work[16 (1 + wave id)]); scalar selects pick the address, the amount and, one iteration later, the result.
+    // The counter is split into `words` words (8 when the wave count allows it): wave w takes from word w % words, which hands
+    // out the batches g = t * words + (w % words), t = 0, 1, ... - every word is shared by waves of ALL CUs, so the split keeps
+    // the balance device-wide while one word only sees an eighth of the takes (one word serves ~88 M takes/s, eight ~430 M/s:
+    // profiles/r02/s_atomic_rate_r02.log), which is what allows small batches.
     const uint32_t wave_id = blockIdx.x * WPB + (uint32_t)wave, total_waves = gridDim.x * WPB;
+    // (the launcher passes words in the upper half of `batch` and first_dyn = total_waves / words needs no division: both
+    // derived on the device they ended up on the vector unit, which the scalar asm operands below cannot take)
+    // (no selects here either: `words == 8 ? 3 : 0` is materialised with v_cndmask)
+    const uint32_t words = DEVWIDE ? batch_arg >> 16 : 1u, wshift = (uint32_t)__builtin_ctz(words | 0x100u);   // 8 -> 3, 1 -> 0
+    const uint32_t my_word = wave_id & (words - 1u), first_dyn = total_waves >> wshift;
+    // the real take happens in the iteration whose `left` equals `trigger`: 1 (the pair before a batch's last), or 0 for batches
+    // of ONE pair, where every iteration takes (and the take for the second pair is issued ahead of the loop)
+    const uint32_t trigger = min(batch - 1u, 1u);
     uint32_t left = DEVWIDE ? batch - 1u : 0u, taken = 0;
     uint64_t pair = SHARED ? take() : DEVWIDE ? (uint64_t)wave_id * batch : (uint64_t)blockIdx.x * WPB + wave;
 
@@ -310,6 +323,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
         dma_tile(2ull * pair, 0);
         dma_tile(2ull * pair + 1ull, 1);
     }
+    if constexpr (DEVWIDE) {
+        if (batch == 1u) work_take_issue(taken, work + 16u * my_word, 1u);
+    }
     // Class ids are stored HALF AN ITERATION LATE (after the next pair's second wait).  vmcnt counts stores too, and
     // "<= 8 outstanding" retires everything older than the newest 8 operations: a store issued at the end of the
     // body would sit between the two refills and the next pair's second wait would stall on its write
@@ -330,8 +346,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
         if constexpr (DEVWIDE) {
             work_take_wait(taken);        // the take of the previous iteration (two thirds of an iteration old)
             // (32-bit arithmetic - the launcher refuses 2^31 pairs - so that this is two scalar selects, not a branch)
-            // (the counter counts PAIRS: every take adds `batch`; the static first batches cover [0, total_waves * batch))
-            const uint32_t c32 = left != 0u ? (uint32_t)pair + 1u : total_waves * batch + taken;
+            // (a word counts its own BATCHES: every take adds 1; the static first batches are g = 0 .. total_waves - 1)
+            const uint32_t c32 = left != 0u ? (uint32_t)pair + 1u : (((first_dyn + taken) << wshift) + my_word) * batch;
             cand = c32;
         } else {
             cand = SHARED ? take() : pair + stride;
@@ -367,8 +383,12 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
             // The statement names one accumulator register of each of tile B's layer-1 MFMA chains, so hipcc places it behind
             // the last of those MFMAs - i.e. behind the iteration's last LDS operand wait; nothing after that point touches
             // LDS until the next iteration, so no lgkmcnt wait sits on the take's round trip.
-            uint32_t *const addr = left == 1u ? work : work + 16u * (1u + wave_id);
-            const uint32_t amount = left == 1u ? batch : 0u;
+            uint32_t *const addr = left == trigger ? work + 16u * my_word : work + 16u * (8u + wave_id);
+            // (an opaque scalar 1: written as `left == 1u ? 1u : 0u` hipcc materialises the comparison on the vector unit and
+            // the asm's scalar operand no longer is one)
+            uint32_t one = 1u;
+            asm volatile("" : "+s"(one));
+            const uint32_t amount = left == trigger ? one : 0u;
             asm volatile("s_mov_b32 %0, %2\n\ts_atomic_add %0, %1, 0x0 glc"
                          : "=&{s95}"(taken) : "s"(addr), "s"(amount), "v"(a1B[0][15]), "v"(a1B[M1 - 1][15]) : "memory");
         }
@@ -528,18 +548,20 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
             const uint64_t wpb = variant == FUSED_DUAL_SHARED ? 8 : FUSED_WPB;
             uint32_t batch = 1;
             if (variant == FUSED_DUAL_DEVWIDE) {
-                // work[0]: the counter (zeroed here); work[16 (1 + w)]: wave w's own word for the zero-adds
+                // work[16 k], k < 8: the counter words (zeroed here); work[16 (8 + w)]: wave w's own word for the zero-adds
                 if (!a.work || (n_main >> 6) >= (1ull << 31)) return hipErrorInvalidValue;
-                // 8: the counter word serves ~87 M takes/s, shared with the per-iteration zero-adds; batches of 4 are already
-                // bound by it (5.5 ms per 1e8 images), 6 is the fastest measured and 8 keeps a margin on faster boxes
-                batch = a.batch >= 2 ? a.batch : 8;
-                if (hipError_t err = hipMemsetAsync(a.work, 0, sizeof(uint32_t), s); err != hipSuccess) return err;
+                batch = a.batch >= 1 ? a.batch : BNM_DUAL_DEFAULT_BATCH;
+                if (hipError_t err = hipMemsetAsync(a.work, 0, 8 * 64, s); err != hipSuccess) return err;
             }
             uint64_t want = ((n_main >> 6) + wpb * batch - 1) / (wpb * batch);
             uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * (variant == FUSED_DUAL_SHARED ? 1ull : 2ull);
             if (variant == FUSED_DUAL_DEVWIDE && cap * wpb > BNM_WORK_DUMMY_WAVES) cap = BNM_WORK_DUMMY_WAVES / wpb;
-            e->fn<<<dim3((unsigned)(want < cap ? want : cap)), dim3((unsigned)(64 * wpb)), 0, s>>>(
-                a.images, n_main, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap, a.work, batch);
+            const uint64_t blocks = want < cap ? want : cap;
+            // variant 6: 8 counter words when the wave count is a multiple of 8 (else 1), in the upper half of the argument
+            const uint32_t words = (variant == FUSED_DUAL_DEVWIDE && ((blocks * wpb) & 7ull) == 0ull) ? 8u : 1u;
+            if (batch > 0xFFFFu) batch = 0xFFFFu;
+            e->fn<<<dim3((unsigned)blocks), dim3((unsigned)(64 * wpb)), 0, s>>>(
+                a.images, n_main, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap, a.work, batch | (words << 16));
             hipError_t err = hipGetLastError();
             if (err != hipSuccess) return err;
         }

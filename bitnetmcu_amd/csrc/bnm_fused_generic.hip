@@ -76,12 +76,17 @@ hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int grid_blocks
     if (waves < 4) return hipErrorInvalidValue;
     if (!n) return hipSuccess;
     if (n >= (1ull << 36) || !counter) return hipErrorInvalidValue;      // 32-bit tile indices in the kernel
-    if (!batch) batch = 16;     // one word serves ~87 M takes per second device-wide: 3.1 M tiles per 1e8 images in >= 16s stay well below it
+    // one word serves ~88 M takes per second device-wide, eight ~430 M/s (profiles/r02/s_atomic_rate_r02.log): with the counter
+    // split eight ways batches of 4 tiles (3.1 M tiles per 1e8 images -> 0.8 M takes per launch) stay far below it
+    if (!batch) batch = 4;
+    if (batch > 0xFFFFu) batch = 0xFFFFu;
     const uint32_t lds = d.w_bytes + waves * 1024u * d.KT0;
     const uint64_t n_tiles = (n + 31ull) / 32ull;
     uint64_t want = (n_tiles + (uint64_t)waves * batch - 1) / ((uint64_t)waves * batch);
     uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus();   // one workgroup per CU
-    if (hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), s); e != hipSuccess) return e;
-    return c.launch(d.KT0, d.sp, dbl, (unsigned)(want < cap ? want : cap), 64u * waves, lds, s, images, n, frags, d, cls, logits,
-                    counter, batch);
+    if (hipError_t e = hipMemsetAsync(counter, 0, 8 * 64, s); e != hipSuccess) return e;
+    const uint64_t blocks = want < cap ? want : cap;
+    const uint32_t words = ((blocks * waves) & 7ull) == 0ull ? 8u : 1u;
+    return c.launch(d.KT0, d.sp, dbl, (unsigned)blocks, 64u * waves, lds, s, images, n, frags, d, cls, logits, counter,
+                    batch | (words << 16));
 }

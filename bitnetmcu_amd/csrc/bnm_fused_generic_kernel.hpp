@@ -176,8 +176,9 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
                                                                      const i32x4 *__restrict__ frags, BnmGenericDesc d,
                                                                      uint32_t *__restrict__ cls_out,
                                                                      int32_t *__restrict__ logits_out, uint32_t *__restrict__ counter,
-                                                                     uint32_t batch) {
+                                                                     uint32_t batch_arg) {
     using G = RowGeom<32 * KT0>;
+    const uint32_t batch = batch_arg & 0xFFFFu;
     constexpr int ROW = 32 * KT0;
     constexpr int KC = KT0 < 8 ? KT0 : 8;          // layer-1 K-steps held in VGPRs at a time
     constexpr int MSTEP = MMAX == 8 ? 2 : 1;
@@ -230,15 +231,20 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
 
     // ---- tiles in batches of `batch` consecutive ones: a wave's first batch is static, every later one comes from the
     // device-wide counter (work_take_*; the wave that runs out of batch asks while it still has one tile to go)
-    const uint32_t total_waves = gridDim.x * nwaves;
-    uint32_t tile = (blockIdx.x * nwaves + wave) * batch, left = batch - 1u;      // `left`: tiles of the batch after this one
+    // The counter is split into `words` words (upper half of the argument: 8 when the wave count is a multiple of 8, else 1):
+    // wave w takes from word w % words, which hands out the batches g = t * words + w % words - every word is shared by waves
+    // of all CUs, so the balance stays device-wide while a word sees an eighth of the takes (work distribution).
+    const uint32_t total_waves = gridDim.x * nwaves, wave_id = blockIdx.x * nwaves + wave;
+    const uint32_t words = batch_arg >> 16, wshift = (uint32_t)__builtin_ctz(words | 0x100u);
+    const uint32_t my_word = wave_id & (words - 1u), first_dyn = total_waves >> wshift;
+    uint32_t tile = wave_id * batch, left = batch - 1u;      // `left`: tiles of the batch after this one
     uint32_t taken = 0;
     if (tile < n_tiles) dma_tile(tile);
 
     const uint32_t M1 = d.M[0], M2 = d.M[1], M3 = d.M[2], M4 = d.M[3];
     const uint32_t K2 = d.KTP[1], K3 = d.KTP[2], K4 = d.KTP[3];
     while (tile < n_tiles) {
-        if (left == 0u) work_take_issue(taken, counter, batch);
+        if (left == 0u) work_take_issue(taken, counter + 16u * my_word, 1u);
         bnm_wait_vmcnt<0>();
         // every per-lane quantity of the iteration is re-derived from this copy of the lane id (a handful of VALU per tile):
         // nothing but the lane id itself stays live across iterations, and hipcc cannot hoist derived addresses
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
                         retire_lds_reads();
                         if (left == 0u) {
                             work_take_wait(taken);
-                            next_tile = total_waves * batch + taken;
+                            next_tile = (((first_dyn + taken) << wshift) + my_word) * batch;
                             next_left = batch - 1u;
                         }
                         if (next_tile < n_tiles) dma_tile(next_tile);

@@ -43,10 +43,11 @@ struct BnmFusedArgs {
     uint32_t *cls;          // [n]
     int32_t *logits;        // [n][n_classes] or nullptr
     uint64_t src_wrap = 0;  // diagnostic library only (BNM_DIAG): read tile (t mod src_wrap); ignored by the product build
-    uint32_t *work = nullptr;   // variant 6: device words [16 * (1 + BNM_WORK_DUMMY_WAVES)]: the work counter + one word per wave
+    uint32_t *work = nullptr;   // variant 6: device words [16 * (8 + BNM_WORK_DUMMY_WAVES)]: 8 counter words + one word per wave
     uint32_t batch = 0;         // variant 6: pairs per take (0 = default)
 };
 constexpr uint32_t BNM_WORK_DUMMY_WAVES = 4096;
+constexpr uint32_t BNM_DUAL_DEFAULT_BATCH = 2;     // pairs per take of the dual-tile kernel (profiles/headline_ab.py sweeps)
 // variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (256-byte rows only), 2 = LDS-DMA with two
 // tiles in flight per wave, 3 = two tiles computed per wave per iteration (default where instantiated)
 bool bnmk_fused_supported(const BnmFusedShape &sh, int variant);
@@ -73,7 +74,7 @@ constexpr int bnmk_generic_wps(int mmax, int kt0, int sp) {
 enum { BNM_FUSED_GENERIC = 4 };
 bool bnmk_generic_plan(BnmGenericDesc &d, const uint32_t m_real[4]);   // fills mmax, M, KTP, frag_off, w_bytes from KT0, sp
 bool bnmk_generic_supported(const BnmGenericDesc &d, bool dbl);
-// d_counter: a device word of the caller's (the launcher zeroes it); batch: tiles per take from it (0 = default)
+// d_counter: 8 device words of the caller, 64 bytes apart (the launcher zeroes them); batch: tiles per take (0 = default)
 hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int grid_blocks, const int8_t *d_images, uint64_t n,
                               const void *d_frags, uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t batch,
                               hipStream_t s);

@@ -159,8 +159,8 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
  * 2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the all-VALU kernel
  * of round 1 (2, 100 + g and 0 are kept for A/B measurements). */
 BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
-/* Fused kernels that hand their work out from the device-wide counter: 32-image tiles (generic kernel, variant 4; default 16)
- * or 64-image pairs (dual-tile kernel, variant 6; default 8, at least 2) a wave takes at a time; 0 = default. */
+/* Fused kernels that hand their work out from the device-wide counter: 32-image tiles (generic kernel, variant 4; default 4)
+ * or 64-image pairs (dual-tile kernel, variant 6; default 2) a wave takes at a time; 0 = default. */
 BNM_API int bnm_ctx_set_work_batch(bnm_ctx *c, int tiles);
 /* Ternary ALU kernel: 2 (default) weights streamed through double-buffered scalar registers, two images per lane, image
  * groups handed out from a device-wide work counter; 1 the same with one image per lane; 12 / 11: as 2 / 1 with a fixed
