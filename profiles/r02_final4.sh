@@ -5,7 +5,7 @@
 #  3. counter passes (each in its own run): headline kernel (+ HBM traffic), streamed ternary kernel, CNN front end, generic
 #     kernel on the headline model and on the ternary model -> table.json per kernel
 set -u
-REPO=$(pwd); OUT=$REPO/gpurun_out/r02_final2; mkdir -p "$OUT"
+REPO=$(pwd); OUT=$REPO/gpurun_out/r02_final4; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats_headline" -o stats -- python $REPO/bench.py --no-cpu --no-extra > "$OUT/bench_headline_under_rocprof.json" 2> "$OUT/bench_headline_under_rocprof.err"
