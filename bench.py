@@ -101,6 +101,20 @@ def load_counters():
     return out
 
 
+def plain_stream_reference():
+    """Replayed, not measured by this run: profiles/ceiling_ab.py's same-box, same-process comparison of the default kernel with
+    plain 16 B/lane streaming loads of the same 25.6 GB (needs the diagnostic library, which bench.py never loads)."""
+    p = os.path.join(REPO, "profiles", "r02", "ceiling_ab_r02.json")
+    try:
+        t = open(p).read()
+        d = json.loads(t[t.index("{"):])
+        return {"plain_stream_ms": d["plain_stream"]["median_ms"], "kernel_ms_same_box": d["kernel"]["median_ms"],
+                "kernel_over_plain_stream_bytes_per_s": d["kernel_over_plain_stream_bytes_per_s"],
+                "source": "replayed from profiles/r02/ceiling_ab_r02.json (profiles/ceiling_ab.py on another box; not measured by this run)"}
+    except Exception:
+        return None
+
+
 def kernel_name(b, ctx, model):
     v = ctx.variant
     fused = {3: "fused_fc_dual_kernel", 5: "fused_fc_dual_kernel", 6: "fused_fc_dual_kernel", 4: "fused_fc_generic_kernel"}.get(v, "fused_fc_kernel")
@@ -316,6 +330,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "mfma_busy_frac": mfma_busy,
+                "plain_stream_reference": plain_stream_reference(),
                 "kernel": kname,
                 "avg_launch_ms": avg_ms,
                 "min_launch_ms": float(np.min(launch_ms)),
