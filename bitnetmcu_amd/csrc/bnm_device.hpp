@@ -96,7 +96,9 @@ BNM_DEVICE int decode_weight(const void *packed, int bpw, uint32_t n_input, uint
 // busy until the work runs out.  s_atomic_add ... glc returns the counter's previous value in a scalar register: no VGPR, no
 // EXEC change, no entry in the vmcnt queue that the LDS-DMA kernels count by hand.  profiles/probes/s_atomic_probe.hip: on
 // gfx950 it is coherent across the whole device (512 workgroups x 8 waves x 64 takes on one word: no duplicate, none lost).
-// The take is split into issue and wait so that its round trip (1-2 us) runs under the caller's arithmetic; in between the
+// One word serves ~88 M takes/s, eight words ~430 M/s, a word per wave 6 G/s at 341 ns per take (probes/s_atomic_rate.hip), so the
+// fused kernels split their counter eight ways (wave w takes from word w mod 8: every word is shared by waves of all CUs).
+// The take is split into issue and wait so that its round trip (0.3-2 us) runs under the caller's arithmetic; in between the
 // result register must not move, so both statements name the SAME fixed register (s95; the streamed ternary kernels use the
 // same technique for their weight buffers).  The compiler's own lgkmcnt waits merely become conservative while the take is
 // outstanding (the counter is shared with LDS operations).  The counter word is zeroed by the launcher ahead of every launch.

@@ -527,8 +527,8 @@ bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fu
 int bnmk_fused_default_variant(const BnmFusedShape &sh) {
     // round 2: the dual-tile loop with the CU's waves sharing a work counter is 2.5-3 % ahead of the fixed stride on the
     // same box (profiles/r02/headline_ab_r02v_variants_3_4_5.log)
-    // ... and batches of 8 pairs from the device-wide counter another 2-5 % ahead of that (same-process interleaved A/B,
-    // profiles/headline_ab.py: profiles/r02/headline_ab_r02x.json, headline_ab_r02y.json)
+    // ... and batches of 2 pairs from the device-wide counter (split eight ways) 6-7.5 % ahead of the fixed stride
+    // (same-process interleaved A/B, profiles/headline_ab.py: profiles/r02/headline_ab_r02x.json ... r02z4.json)
     if (find_fused(sh, FUSED_DUAL_DEVWIDE)) return FUSED_DUAL_DEVWIDE;
     if (find_fused(sh, FUSED_DUAL_SHARED)) return FUSED_DUAL_SHARED;
     if (find_fused(sh, FUSED_DUAL)) return FUSED_DUAL;
