@@ -753,7 +753,8 @@ static int infer_host_small(bnm_ctx *c, const int8_t *images, uint64_t n, uint32
     // class ids are <= 255: pre-set every slot to a sentinel and watch the page-locked words change — the kernel's stores to
     // fine-grained host memory are visible as soon as they are written, several microseconds before the stream's completion
     // signal has been processed.  (Each word is written exactly once, by the last instruction that touches the image, so a
-    // slot that changed also means its image has been read; logits have no spare value and take the stream wait.)
+    // slot that changed also means its image has been read - which is why the dual kernel's deferred store is masked off in a
+    // wave's first iteration instead of writing a placeholder; logits have no spare value and take the stream wait.)
     volatile uint32_t *out = (volatile uint32_t *)c->lat_cls.host;
     const bool spin = !logits && c->lat_spin;
     if (spin) for (uint64_t i = 0; i < n; i++) out[i] = 0xFFFFFFFFu;

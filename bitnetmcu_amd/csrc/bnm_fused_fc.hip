@@ -223,9 +223,51 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
             cls = argmax_rows<M3, NC8>(acc3, h);
             if (logits_out && img < n) store_logits<M3>(acc3, logits_out + img * n_classes, h, n_classes);
         }
-        if (h == 0 && img < n) cls_out[img] = cls;
+        if (h == 0 && img < n) __builtin_nontemporal_store(cls, cls_out + img);
     }
 }
+
+// The dual kernel's deferred class-id store: nontemporal, executed under `mask` (all lanes or none) without a branch.
+__device__ __forceinline__ void store_class_ids_masked(uint32_t *addr, uint32_t value, uint64_t mask) {
+    uint64_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, off nt\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "s"(mask), "v"(addr), "v"(value) : "memory", "scc");
+}
+
+#ifdef BNM_DIAG
+// diagnostic library only: the class-id store in several flavours (see diag_store_mode in the kernel)
+typedef uint32_t diag_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t diag_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void diag_store(uint32_t mode, uint32_t *__restrict__ cls_out, uint64_t img_prev, uint64_t pair_prev,
+                                           uint32_t cls_prev, uint32_t left, uint32_t batch, int lane, uint64_t mask) {
+    switch (mode) {
+    case 0: store_class_ids_masked(cls_out + img_prev, cls_prev, mask); break;   // the product's store
+    case 1: cls_out[img_prev] = cls_prev; break;                                  // plain store (the product's until r02)
+    case 2: asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(cls_out + img_prev), "v"(cls_prev) : "memory"); break;
+    case 3: cls_out[img_prev & 0xffffull] = cls_prev; break;                      // same instruction, cache-resident destination
+    case 4: ((uint8_t *)cls_out)[img_prev] = (uint8_t)cls_prev; break;            // same number of stores, a quarter of the bytes
+    case 5:                                                                       // one store per BATCH of 2 / 4 pairs, same bytes
+        if (left == 0u) {
+            const uint64_t first = (pair_prev & ~(uint64_t)(batch - 1u)) << 6;
+            if (batch == 2u) *(diag_u32x2 *)(cls_out + first + 2u * (uint32_t)lane) = diag_u32x2{cls_prev, cls_prev};
+            else *(diag_u32x4 *)(cls_out + first + 4u * (uint32_t)lane) = diag_u32x4{cls_prev, cls_prev, cls_prev, cls_prev};
+        }
+        break;
+    case 6: {                                                                     // through the scalar unit: 16 x s_store_dwordx4
+        uint32_t *const dst = cls_out + (pair_prev << 6);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            diag_u32x4 v = {(uint32_t)__builtin_amdgcn_readlane((int)cls_prev, 4 * q), (uint32_t)__builtin_amdgcn_readlane((int)cls_prev, 4 * q + 1),
+                            (uint32_t)__builtin_amdgcn_readlane((int)cls_prev, 4 * q + 2), (uint32_t)__builtin_amdgcn_readlane((int)cls_prev, 4 * q + 3)};
+            asm volatile("s_store_dwordx4 %0, %1, %2" ::"s"(v), "s"(dst), "n"(16 * q) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the data SGPRs are free again
+        break;
+    }
+    default: break;                                                               // 128..255: no store at all
+    }
+}
+#endif
 
 // ---- variant 3, DUAL: one wave carries TWO independent tiles (A, B) per iteration -----------------
 // Same LDS budget as variant 2 (one 8 KiB buffer per tile slot, refilled right after that slot's layer-1 MFMAs), but
@@ -305,7 +347,13 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
     // slot 0 holds tile 2p, slot 1 tile 2p+1.  Diagnostic library only: src_wrap (a power of two here) keeps the
     // source cache-resident; as a mask it costs one s_and and no branch.  The product build ignores the argument.
 #ifdef BNM_DIAG
-    const uint64_t wrap_mask = src_wrap ? src_wrap - 1ull : ~0ull;
+    // bits 56..63 of the argument select how the class ids are stored (profiles/slow_state_probe.py: what do the writes cost on
+    // this box, and which property of them - their number, their bytes, the vector memory pipe - is it?).  TIMING ONLY: every mode
+    // but 0 leaves the class buffer with wrong or partial contents.
+    const uint32_t diag_store_mode = (uint32_t)(src_wrap >> 56);
+    const uint64_t wrap_lo = src_wrap & ~(0xffull << 56);
+    uint64_t pair_prev = pair;
+    const uint64_t wrap_mask = wrap_lo ? wrap_lo - 1ull : ~0ull;
 #else
     constexpr uint64_t wrap_mask = ~0ull;
 #endif
@@ -330,11 +378,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
     // "<= 8 outstanding" retires everything older than the newest 8 operations: a store issued at the end of the
     // body would sit between the two refills and the next pair's second wait would stall on its write
     // acknowledgement (~1000 cycles per iteration while HBM is streaming; profiles/r01/conly_r01p...).  Deferred, the
-    // only store either wait can cover is a whole iteration old.  The first iteration's deferred store writes a
-    // placeholder to the wave's own first slot, which the real value overwrites later (same wave, same address,
-    // program order).
+    // only store either wait can cover is a whole iteration old.  The first iteration's deferred store runs with an
+    // empty exec mask (see store_class_ids_masked).
     uint64_t img_prev = (pair << 6) + (uint64_t)lane;
     uint32_t cls_prev = 0;
+    uint64_t store_mask = 0;      // exec mask of the deferred store: empty in a wave's first iteration
 #ifdef BNM_DIAG_TIMING
     // diagnostic build only (build.py --diag-timing; profiles/wait_timing.py): shader-clock stamps around the two waits
     uint64_t t_wait_a = 0, t_wait_b = 0, t_iters = 0;
@@ -375,7 +423,17 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
 #ifdef BNM_DIAG_TIMING
         t_wait_b += __builtin_readcyclecounter() - t2;
 #endif
-        cls_out[img_prev] = cls_prev;
+#ifdef BNM_DIAG
+        diag_store(diag_store_mode, cls_out, img_prev, pair_prev, cls_prev, left, batch, lane, store_mask);
+#else
+        // nontemporal: a plain store leaves its line dirty in L2 and the write-back lands between the reads whenever the stream
+        // evicts it; 0.11-0.16 ms of 4.1 on the fast boxes, 0.5 ms on the slow ones (profiles/r02/store_modes_ab_r02*.log).
+        // The first iteration has nothing to store yet: the store issues with an empty exec mask (one asm statement, so the loop
+        // body stays one basic block).  It must not write a placeholder that the real value overwrites later: the latency path of
+        // bnm_infer_host polls the class words in page-locked host memory and takes the first change of a word as its result
+        // (bnm_capi.cpp, infer_host_small) - every word is written exactly once.
+        store_class_ids_masked(cls_out + img_prev, cls_prev, store_mask);
+#endif
         read_tile(1, bB);
         layer_mma<M1, KT0, false>(A1, bB, a1B);
         dma_tile(2ull * next + 1ull, 1);
@@ -438,10 +496,17 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
         // one 256-byte store per pair, issued in the next iteration (or after the loop)
         img_prev = h ? imgB : imgA;
         cls_prev = h ? clsB : clsA;
+        store_mask = ~0ull;
+#ifdef BNM_DIAG
+        pair_prev = pair;
+#endif
         pair = cand;
         if constexpr (DEVWIDE) left = left != 0u ? left - 1u : batch - 1u;
     }
-    if (any) cls_out[img_prev] = cls_prev;
+    if (any) __builtin_nontemporal_store(cls_prev, cls_out + img_prev);
+#ifdef BNM_DIAG
+    if (diag_store_mode == 6u) asm volatile("s_dcache_wb" ::: "memory");
+#endif
     bnm_wait_vmcnt<0>();   // LDS-DMA still in flight must not outlive the workgroup's LDS allocation
 #ifdef BNM_DIAG_TIMING
     // the logits buffer is reused as the record array: 4 x uint64 per wave {loop cycles, wait A, wait B, iterations}

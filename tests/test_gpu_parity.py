@@ -236,6 +236,23 @@ def test_ragged_and_empty_batches(name, gpu_ok, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["fc_4bitsym_64", "tern_96"])
+def test_latency_path_words_written_once(name, gpu_ok, orc):
+    """n <= 64 host images, class ids only: bnm_infer_host polls the page-locked class words and takes the first change of a word as
+    the result, so no kernel may write a word twice (a placeholder store in the dual kernel's first iteration once did).  Different
+    images on every call, so a stale buffer cannot pass for a result."""
+    model = util.load_golden_model(name)
+    om = util.OracleModel(model, orc)
+    ctx = b.Context(model)
+    for k in range(12):
+        n = (64, 64, 33, 64, 1, 64)[k % 6]
+        x = synth.images(7000 + 977 * k, n, DIST_U if k & 1 else DIST_M)
+        want = om.infer(x)
+        for _ in range(3):
+            assert np.array_equal(ctx.infer(x), want), (name, k, n)
+    ctx.close()
+
+
 def test_device_pointer_api_does_not_touch_neighbours(gpu_ok, orc):
     """Ragged n on device buffers: nothing is written past cls[n] / logits[n]."""
     import torch
