@@ -104,13 +104,13 @@ def load_counters():
 def plain_stream_reference():
     """Replayed, not measured by this run: profiles/ceiling_ab.py's same-box, same-process comparison of the default kernel with
     plain 16 B/lane streaming loads of the same 25.6 GB (needs the diagnostic library, which bench.py never loads)."""
-    p = os.path.join(REPO, "profiles", "r02", "ceiling_ab_r02.json")
+    p = os.path.join(REPO, "profiles", "r02", "ceiling_ab_r02_final5.json")
     try:
         t = open(p).read()
         d = json.loads(t[t.index("{"):])
         return {"plain_stream_ms": d["plain_stream"]["median_ms"], "kernel_ms_same_box": d["kernel"]["median_ms"],
                 "kernel_over_plain_stream_bytes_per_s": d["kernel_over_plain_stream_bytes_per_s"],
-                "source": "replayed from profiles/r02/ceiling_ab_r02.json (profiles/ceiling_ab.py on another box; not measured by this run)"}
+                "source": "replayed from profiles/r02/ceiling_ab_r02_final5.json (profiles/ceiling_ab.py on another box; not measured by this run)"}
     except Exception:
         return None
 
