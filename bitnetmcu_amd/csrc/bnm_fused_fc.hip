@@ -227,6 +227,42 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
     }
 }
 
+// The dual kernel's logits of one pair (64 valid images): whole tiles through LDS (store_logits_tile) when a tile's rows fit the
+// staging area, else piecewise.  Diagnostic library: `mode` 1 = plain whole-tile stores, 2 = the piecewise stores (round 2's first form).
+#ifdef BNM_DIAG
+#define LOGITS_DIAG_ARG , diag_logits_mode
+#else
+#define LOGITS_DIAG_ARG
+#endif
+template <int MT, int NC8>
+__device__ __forceinline__ void store_logits_pair(const i32x16 (&a)[MT], const i32x16 (&b)[MT], int32_t *stage, int32_t *logits_out,
+                                                  uint64_t pair, int j, int h, int lane, uint32_t n_classes
+#ifdef BNM_DIAG
+                                                  , uint32_t mode
+#endif
+) {
+    int32_t *const tile_a = logits_out + (pair << 6) * n_classes, *const tile_b = tile_a + 32u * n_classes;
+#ifdef BNM_DIAG
+    if (mode == 1u && n_classes <= 16u) {
+        store_logits_tile<MT, NC8, 1>(a, stage, tile_a, j, h, lane, n_classes);
+        store_logits_tile<MT, NC8, 1>(b, stage, tile_b, j, h, lane, n_classes);
+        return;
+    }
+    if (mode == 2u) {
+        store_logits<MT>(a, tile_a + (uint32_t)j * n_classes, h, n_classes);
+        store_logits<MT>(b, tile_b + (uint32_t)j * n_classes, h, n_classes);
+        return;
+    }
+#endif
+    if (n_classes <= 16u) {
+        store_logits_tile<MT, NC8, 0>(a, stage, tile_a, j, h, lane, n_classes);
+        store_logits_tile<MT, NC8, 0>(b, stage, tile_b, j, h, lane, n_classes);
+    } else {
+        store_logits<MT>(a, tile_a + (uint32_t)j * n_classes, h, n_classes);
+        store_logits<MT>(b, tile_b + (uint32_t)j * n_classes, h, n_classes);
+    }
+}
+
 // The dual kernel's deferred class-id store: nontemporal, executed under `mask` (all lanes or none) without a branch.
 __device__ __forceinline__ void store_class_ids_masked(uint32_t *addr, uint32_t value, uint64_t mask) {
     uint64_t saved;
@@ -288,6 +324,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
     constexpr bool SHARED = WPB == 8;          // one workgroup per CU, pairs handed out from s_next
     constexpr bool DEVWIDE = DW;   // 4-wave workgroups, batches of pairs from the device-wide counter work[0]
     __shared__ __attribute__((aligned(1024))) char smem[WPB * 2 * FUSED_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) int32_t s_logits[WPB][32 * 16];      // store_logits_tile's staging area, 2 KiB per wave
     __shared__ uint32_t s_next;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -350,8 +387,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
     // bits 56..63 of the argument select how the class ids are stored (profiles/slow_state_probe.py: what do the writes cost on
     // this box, and which property of them - their number, their bytes, the vector memory pipe - is it?).  TIMING ONLY: every mode
     // but 0 leaves the class buffer with wrong or partial contents.
-    const uint32_t diag_store_mode = (uint32_t)(src_wrap >> 56);
-    const uint64_t wrap_lo = src_wrap & ~(0xffull << 56);
+    const uint32_t diag_store_mode = (uint32_t)(src_wrap >> 56), diag_logits_mode = (uint32_t)(src_wrap >> 48) & 0xffu;
+    const uint64_t wrap_lo = src_wrap & ~(0xffffull << 48);
     uint64_t pair_prev = pair;
     const uint64_t wrap_mask = wrap_lo ? wrap_lo - 1ull : ~0ull;
 #else
@@ -477,19 +514,13 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
             clsA = argmax_rows<M4, NC8>(a4A, h);
             clsB = argmax_rows<M4, NC8>(a4B, h);
 #ifndef BNM_DIAG_TIMING
-            if (logits_out) {
-                store_logits<M4>(a4A, logits_out + imgA * n_classes, h, n_classes);
-                store_logits<M4>(a4B, logits_out + imgB * n_classes, h, n_classes);
-            }
+            if (logits_out) store_logits_pair<M4, NC8>(a4A, a4B, s_logits[wave], logits_out, pair, j, h, lane, n_classes LOGITS_DIAG_ARG);
 #endif
         } else {
             clsA = argmax_rows<M3, NC8>(a3A, h);
             clsB = argmax_rows<M3, NC8>(a3B, h);
 #ifndef BNM_DIAG_TIMING
-            if (logits_out) {
-                store_logits<M3>(a3A, logits_out + imgA * n_classes, h, n_classes);
-                store_logits<M3>(a3B, logits_out + imgB * n_classes, h, n_classes);
-            }
+            if (logits_out) store_logits_pair<M3, NC8>(a3A, a3B, s_logits[wave], logits_out, pair, j, h, lane, n_classes LOGITS_DIAG_ARG);
 #endif
         }
         // both halves of the wave hold the result: lanes 0..31 keep tile A's classes, lanes 32..63 tile B's —

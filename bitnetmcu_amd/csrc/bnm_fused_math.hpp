@@ -149,3 +149,35 @@ BNM_DEVICE void store_logits(const i32x16 (&acc)[MT], int32_t *dst, int h, uint3
         }
 }
 
+// A WHOLE tile's logits (32 valid images, n_classes <= 16) through a per-wave LDS staging area laid out as the tile is in memory
+// (image-major, n_classes dwords per image): the tile then leaves as contiguous 16 B/lane stores, 1 KiB per instruction and every
+// 128-byte line written whole by one instruction - store_logits' 16-byte pieces at a 4 n_classes-byte stride fill a line from two
+// instructions, which only a write-back cache merges.  `stage` = 32 * 16 dwords of LDS owned by the wave (LDS executes a wave's
+// instructions in order: the reads below see the writes above, and the next tile's writes come after these reads).
+// MODE 0: nontemporal stores, 1: plain stores.
+template <int MT, int NC8, int MODE>
+BNM_DEVICE void store_logits_tile(const i32x16 (&acc)[MT], int32_t *stage, int32_t *tile_dst, int j, int h, int lane, uint32_t n_classes) {
+    int32_t *const mine = stage + (uint32_t)j * n_classes + 4u * (uint32_t)h;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (NC8 > 0 && 4 * m + q >= NC8) continue;      // rows 32m + 8q .. +7 lie beyond the classes
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t row = 32u * m + 8u * q + 4u * (uint32_t)h + (uint32_t)e;
+                if (row < n_classes) mine[32 * m + 8 * q + e] = acc[m][4 * q + e];
+            }
+        }
+    const uint32_t chunks = 8u * n_classes;                   // 16-byte pieces of the tile: 32 images x 4 n_classes bytes
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t c = (uint32_t)lane + 64u * r;
+        if (c < chunks) {
+            const i32x4 v = *(const i32x4 *)(stage + 4u * c);
+            if (MODE == 0) __builtin_nontemporal_store(v, (i32x4 *)(tile_dst + 4u * c));
+            else *(i32x4 *)(tile_dst + 4u * c) = v;
+        }
+    }
+}
+

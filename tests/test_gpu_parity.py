@@ -408,6 +408,29 @@ def test_random_models_every_codec_through_model_kernels(codecs, widths, gpu_ok,
     ctx.close()
 
 
+@pytest.mark.parametrize("n_classes", [1, 2, 7, 9, 16, 17, 32])
+def test_dual_kernel_logits_for_other_class_counts(n_classes, gpu_ok, orc):
+    """The dual-tile kernel stores a tile's logits through an LDS staging area when n_classes <= 16 (odd counts: rows that are only
+    dword-aligned) and piecewise above; every fused variant, whole pairs + ragged remainders, ids and logits against the oracle."""
+    rng = np.random.default_rng(9000 + n_classes)
+    model = b.Model.from_header_text(_random_model_text(rng, (4, 4, 4, 4), (64, 64, 64), n_classes))
+    om = util.OracleModel(model, orc)
+    x = np.concatenate([synth.images(21, 4000, DIST_U), synth.images(21, 300, DIST_M)])
+    want = om.infer(x, logits=True)
+    ctx = b.Context(model)
+    ran = []
+    for label, setup in paths_for(ctx):
+        if not label.startswith("fused"):
+            continue
+        setup(ctx)
+        for n in (len(x), 4096, 193, 128, 64, 63):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (n_classes, label, n)
+        ran.append(label)
+    assert "fused_v6" in ran and "fused_v3" in ran, ran
+    ctx.close()
+
+
 @pytest.mark.parametrize("signs", ["-+-+", "+-+-", "----", "++++", "dense"])
 def test_ternary_alu_kernels_extreme_sums(signs, gpu_ok, orc):
     """Ternary 256-96-96-96-10 models whose layers are all +1, all -1 or zero-free random trits, on all -128 / 127 / 0 / random
