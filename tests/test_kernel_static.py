@@ -24,3 +24,39 @@ def test_ternary_chunk_loads_untouched_in_flight():
     assert r.returncode == 0, r.stdout[-2000:]
     assert " 0 instructions touch registers of a load in flight" in r.stdout
     assert " 0 instructions touch a result register in flight" in r.stdout and " 0 scalar work-counter takes" not in r.stdout
+
+
+def _disassemble(obj):
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "k.co")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", obj], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--input={fat}", f"--output={co}", "--unbundle"], check=True)
+        return subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+
+
+def test_dual_kernel_stores_are_nontemporal_and_the_first_one_is_masked():
+    """The headline kernel's class-id store costs 3-11 % of its time as a plain store; and its first, empty issue must be
+    masked off, not a placeholder write (the latency path of bnm_infer_host takes a word's first change as the result)."""
+    text = _disassemble(os.path.join(BUILD, "bnm_fused_fc.o"))
+    kernels, cur = {}, None
+    for line in text.splitlines():
+        if line.endswith(">:") and "<" in line:
+            cur = line[line.index("<") + 1:-2]
+            kernels[cur] = []
+        elif cur is not None and "\t" in line:
+            kernels[cur].append(line.split("//")[0].strip())
+    dual = {k: v for k, v in kernels.items() if k.startswith("_Z20fused_fc_dual_kernel")}
+    assert len(dual) >= 12, list(kernels)[:5]
+    for name, ins in dual.items():
+        stores = [i for i in ins if i.startswith("global_store")]
+        masked = [k for k, i in enumerate(ins) if i.startswith("s_and_saveexec_b64") and k + 2 < len(ins)
+                  and ins[k + 1].startswith("global_store_dword ") and ins[k + 1].rstrip().endswith(" nt")
+                  and ins[k + 2].startswith("s_mov_b64 exec")]
+        assert len(masked) == 1, (name, len(masked))
+        # the loop's masked store + the store of the last pair after the loop; the whole-line logits stores (16 bytes per lane).
+        # (plain stores remain in the piecewise logits fallback for more than 16 classes)
+        assert sum(1 for i in stores if i.startswith("global_store_dword ") and i.rstrip().endswith(" nt")) >= 2, name
+        assert any(i.startswith("global_store_dwordx4") and i.rstrip().endswith(" nt") for i in stores), name
