@@ -296,7 +296,11 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         } else {
             cls = final_layer<MMAX, SP>(smem, lane16, d.frag_off[2], M3, K3, pb, h, lrow, nc);
         }
+#ifdef BNM_EXPERIMENT_PLAIN_CLASS_STORE
+        if (h == 0 && img < n) cls_out[img] = cls;
+#else
         if (h == 0 && img < n) __builtin_nontemporal_store(cls, cls_out + img);   // see bnm_fused_fc.hip's dual kernel
+#endif
         tile = next_tile;
         left = next_left;
     }
