@@ -28,6 +28,13 @@ def paths_for(ctx):
             out.append((f"fused_v{v}", fused))
         except b.BnmError:
             pass
+    if any(l == "fused_v6" for l, _ in out):
+        # small batches of variant 6 run the fixed-stride kernel (one dispatch); a grid of 1 workgroup = 4 resident waves keeps the
+        # work-counter kernel itself in the small-size tests
+        def fused6_small_grid(c):
+            c.set_path(b.PATH_FUSED_MFMA)
+            c.set_tuning(variant=6, grid_blocks=1)
+        out.append(("fused_v6_grid1", fused6_small_grid))
     try:
         ctx.set_path(b.PATH_TERNARY_ALU)
         for tv in (2, 1, 12, 11, 0):     # streamed weights (two / one image per lane; work counter / fixed stride), round 1's kernel
@@ -216,6 +223,40 @@ def test_context_on_two_streams(name, variant, n, gpu_ok):
     torch.cuda.synchronize()
     for k, (_, want, got) in enumerate(sets):
         assert torch.equal(want, got), (name, variant, k)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["fc_4bitsym_64", "tern_96", "cnn_64"])
+def test_infer_device_under_graph_capture(name, gpu_ok, orc):
+    """bnm_infer_device enqueues only stream work (counter memset + kernels; scratch is allocated per stream on first use), so a
+    launch-bound small-batch loop can be captured into a HIP graph once and replayed: warm up on the capture stream, capture,
+    replay on three different inputs, ids and logits against the oracle."""
+    import torch
+    model = util.load_golden_model(name)
+    om = util.OracleModel(model, orc)
+    ctx = b.Context(model)
+    n = 1000
+    x = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+    cls = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    lg = torch.empty((n, model.num_classes), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        synth.fill_device(x, first=0, dist=DIST_U)
+        ctx.infer_device(x, cls, lg)             # first use on this stream: allocations happen here, not under capture
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        ctx.infer_device(x, cls, lg)
+    for k in range(3):
+        xin = synth.images(31 + 4099 * k, n, DIST_M if k == 1 else DIST_U)
+        x.copy_(torch.from_numpy(xin).cuda())
+        cls.fill_(-1)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        want_cls, want_lg = om.infer(xin, logits=True)
+        assert np.array_equal(cls.cpu().numpy().astype(np.uint32), want_cls) and np.array_equal(lg.cpu().numpy(), want_lg), (name, k)
     ctx.close()
 
 
