@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void quantize_input_kernel(const float *__rest
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     for (uint64_t img = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); img < n; img += (uint64_t)gridDim.x * 4u) {
-        f32x4 v = *(const f32x4 *)(x + img * 256ull + 4u * lane);
+        f32x4 v = __builtin_nontemporal_load((const f32x4 *)(x + img * 256ull + 4u * lane));     // every byte is touched once
         float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void quantize_input_kernel(const float *__rest
             r = fminf(fmaxf(r, -128.0f), 127.0f);
             d |= (uint32_t)(uint8_t)(int8_t)(int)r << (8 * b);
         }
-        *(uint32_t *)(out + img * 256ull + 4u * lane) = d;
+        __builtin_nontemporal_store(d, (uint32_t *)(out + img * 256ull + 4u * lane));
     }
 }
 
