@@ -300,7 +300,7 @@ __device__ __forceinline__ void diag_store(uint32_t mode, uint32_t *__restrict__
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the data SGPRs are free again
         break;
     }
-    default: break;                                                               // 128..255: no store at all
+    default: break;                                                               // any other value (the scripts use 255): no store at all
     }
 }
 #endif
@@ -311,7 +311,7 @@ __device__ __forceinline__ void diag_store(uint32_t mode, uint32_t *__restrict__
 // block (no ragged / last-iteration branches: the launcher hands this kernel whole 64-image pairs only and gives
 // the remainder to variant 2; the refill after the last pair re-reads that pair), so the scheduler can place one
 // tile's ReLUNorm VALU work between the other tile's MFMAs.  Weights stay in registers once for both tiles.
-//
+// LDS per wave: two 8 KiB tile slots + 2 KiB staging for a tile's logits (store_logits_tile) = 72 KiB per 4-wave workgroup, two per CU.
 template <int M1, int M2, int M3, int M4, bool DBL, int NC8, int WPB = FUSED_WPB, bool DW = false>
 __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                           const i32x4 *__restrict__ frags,
