@@ -32,3 +32,16 @@ def test_product_never_imports_the_oracle():
                         if needle in text:
                             bad.append((os.path.join(dirpath, f), needle))
     assert not bad, bad
+
+
+def test_profile_scripts_compile():
+    """The measurement scripts only run on the GPU box; a syntax error there costs a box visit."""
+    import glob
+    import py_compile
+    scripts = sorted(glob.glob(os.path.join(REPO, "profiles", "*.py")))
+    assert len(scripts) >= 15
+    for p in scripts:
+        py_compile.compile(p, doraise=True)
+    for p in sorted(glob.glob(os.path.join(REPO, "profiles", "*.sh"))):
+        r = subprocess.run(["bash", "-n", p], capture_output=True, text=True)
+        assert r.returncode == 0, (p, r.stderr)
