@@ -147,7 +147,10 @@ BNM_API int bnm_ctx_get_variant(const bnm_ctx *c);
  * A few launches of one context may be in flight on different streams: work counters come from a ring (8 blocks for the
  * dual-tile kernel, 64 words for the others), and the scratch of the CNN and layer-wise paths (feature rows, activation
  * buffers) is kept per stream.  The first call on a stream, and a call with a larger batch than any before on it, allocates
- * or grows that scratch (hipMalloc / hipFree: device-synchronising). */
+ * or grows that scratch (hipMalloc / hipFree: device-synchronising).  Apart from that a call enqueues stream work only (a
+ * counter memset and one or two kernels), so after one eager call on the capturing stream it may be captured into a HIP graph
+ * and replayed.  Every class-id word is written exactly once per call (never a placeholder first): a host that maps d_cls in
+ * page-locked memory may poll a pre-set sentinel, as bnm_infer_host does for n <= 64. */
 BNM_API int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls,
                              int32_t *d_logits, void *stream);
 /* Same with HOST pointers; synchronous.  Up to 64 images: zero-copy (page-locked buffers the GPU addresses directly, one launch,
