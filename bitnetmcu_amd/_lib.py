@@ -61,6 +61,7 @@ PROTOTYPES = {
     "bnm_ctx_set_work_batch": (C.c_int, [_vp, C.c_int]),
     "bnm_ctx_set_host_tuning": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "bnm_infer_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "bnm_ctx_release_stream": (C.c_int, [_vp, _vp]),
     "bnm_infer_host": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "bnm_infer_host_activations": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint32]),
     "bnm_fc_layer_device": (C.c_int, [_vp, C.c_uint32, _vp, C.c_int32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp]),

@@ -590,6 +590,7 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         }
     }
     flush_pending();
+    if (counter != nullptr) work_block_leave_v(counter, nwaves);   // the last wave to leave zeroes the counter block
 #ifdef BNM_DIAG_TIMING
     if (g_cnn_rec && lane_now() == 0) {
         uint64_t *rec = g_cnn_rec + 8ull * wave_id;
@@ -643,14 +644,12 @@ hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, co
     // MFMA kernel: images [0, n-1) through the plain instantiation, the last one through the SAFE one (see the kernel)
     const uint64_t n_main = n - 1;
     const uint64_t tail_off = n_main * 256ull;
-    // MFMA kernel: batches of `grab` images from `counter` (zeroed ahead of every launch: the waves' first batches are
-    // static, the counter hands out what follows); counter == nullptr or grab == 0: fixed shares of single images
+    // MFMA kernel: batches of `grab` images from word 0 of the counter block (all zero between launches: the waves' first batches
+    // are static, the counter hands out what follows); counter == nullptr or grab == 0: fixed shares of single images
     if (!counter || !grab) { counter = nullptr; grab = 1; }
-    auto zero = [&]() -> hipError_t { return counter ? hipMemsetAsync(counter, 0, sizeof(uint32_t), s) : hipSuccess; };
     if (C <= 64) {
         if (wtab) {
             if (n_main) {
-                if (hipError_t e = zero(); e != hipSuccess) return e;
                 cnn_front_mfma_kernel<true, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, 0, n_shift, acts, acts_stride, feat, counter, grab);
             }
             cnn_front_mfma_kernel<true, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, C, 0, n_shift,
@@ -665,7 +664,6 @@ hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, co
     for (uint32_t c0 = 0; c0 < C; c0 += 64) {
         if (wtab) {
             if (n_main) {
-                if (hipError_t e = zero(); e != hipSuccess) return e;
                 cnn_front_mfma_kernel<false, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, c0, n_shift, acts, acts_stride, feat, counter, grab);
             }
             cnn_front_mfma_kernel<false, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, C, c0, n_shift,

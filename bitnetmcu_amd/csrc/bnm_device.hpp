@@ -101,9 +101,49 @@ BNM_DEVICE int decode_weight(const void *packed, int bpw, uint32_t n_input, uint
 // The take is split into issue and wait so that its round trip (0.3-2 us) runs under the caller's arithmetic; in between the
 // result register must not move, so both statements name the SAME fixed register (s95; the streamed ternary kernels use the
 // same technique for their weight buffers).  The compiler's own lgkmcnt waits merely become conservative while the take is
-// outstanding (the counter is shared with LDS operations).  The counter word is zeroed by the launcher ahead of every launch.
+// outstanding (the counter is shared with LDS operations).  The counter words are zero at every launch (work_block_leave_*).
 // =================================================================================================
 BNM_DEVICE void work_take_issue(uint32_t &r, uint32_t *counter, uint32_t amount) {
     asm volatile("s_mov_b32 %0, %2\n\ts_atomic_add %0, %1, 0x0 glc" : "=&{s95}"(r) : "s"(counter), "s"(amount) : "memory");
 }
 BNM_DEVICE void work_take_wait(uint32_t &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+{s95}"(r)::"memory"); }
+
+// =================================================================================================
+// A launch's counter BLOCK (BNM_WORK_BLOCK_WORDS device words owned by the launch's stream, bnm_capi.cpp): the counter words
+// at block[16 k], k < 8, and at block[BNM_WORK_EXIT_WORD] the number of waves that have left the kernel.  A block is all zero
+// between launches: nobody zeroes it ahead of a launch (that was a hipMemsetAsync per launch: a second dispatch, 2 us of a
+// launch-bound call's 6-9) - the LAST wave to leave puts it back.  A leaving wave first retires every take it still has in
+// flight (counter operations of one wave reach the memory side in no particular order), then counts itself out; the wave that
+// finds everybody else gone swaps zeros into the nine words.  Launches that share a block are ordered by their stream.
+// _s: kernels whose takes are scalar atomics (fused FC kernels); _v: kernels whose takes are vector atomics of lane 0.
+// =================================================================================================
+BNM_DEVICE void work_block_leave_s(uint32_t *block, uint32_t total_waves) {
+    uint32_t old;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+                 "s_mov_b32 %0, 1\n\t"
+                 "s_atomic_add %0, %1, %2 glc\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(old) : "s"(block), "n"(4 * BNM_WORK_EXIT_WORD) : "memory");
+    if (old + 1u == total_waves) {
+        uint32_t z0, z1, z2;
+        asm volatile("s_mov_b32 %0, 0\n\ts_mov_b32 %1, 0\n\ts_mov_b32 %2, 0\n\t"
+                     "s_atomic_swap %0, %3, 0x0 glc\n\ts_atomic_swap %1, %3, 0x40 glc\n\ts_atomic_swap %2, %3, 0x80 glc\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "s_mov_b32 %0, 0\n\ts_mov_b32 %1, 0\n\ts_mov_b32 %2, 0\n\t"
+                     "s_atomic_swap %0, %3, 0xc0 glc\n\ts_atomic_swap %1, %3, 0x100 glc\n\ts_atomic_swap %2, %3, 0x140 glc\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "s_mov_b32 %0, 0\n\ts_mov_b32 %1, 0\n\ts_mov_b32 %2, 0\n\t"
+                     "s_atomic_swap %0, %3, 0x180 glc\n\ts_atomic_swap %1, %3, 0x1c0 glc\n\ts_atomic_swap %2, %3, %4 glc\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(z0), "=&s"(z1), "=&s"(z2) : "s"(block), "n"(4 * BNM_WORK_EXIT_WORD) : "memory");
+    }
+}
+BNM_DEVICE void work_block_leave_v(uint32_t *block, uint32_t total_waves) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(block + BNM_WORK_EXIT_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+    if (old + 1u == total_waves && lane < 9u)
+        (void)__hip_atomic_exchange(block + 16u * lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}

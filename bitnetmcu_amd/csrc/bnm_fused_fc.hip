@@ -72,7 +72,8 @@ __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_
                                                                      const i32x4 *__restrict__ frags, uint32_t n_classes,
                                                                      uint32_t *__restrict__ cls_out,
                                                                      int32_t *__restrict__ logits_out, uint64_t src_wrap,
-                                                                     uint32_t *__restrict__ work, uint32_t batch) {
+                                                                     uint32_t *__restrict__ work, uint32_t *__restrict__ idle,
+                                                                     uint32_t batch) {
     constexpr int SP = SPLIT ? 2 : 1;
     constexpr int ROW = 32 * KT0;
     constexpr bool LDSDMA = VARIANT != FUSED_DIRECT;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
                                                                           uint32_t n_classes, uint32_t *__restrict__ cls_out,
                                                                           int32_t *__restrict__ logits_out,
                                                                           uint64_t src_wrap, uint32_t *__restrict__ work,
-                                                                          uint32_t batch_arg) {
+                                                                          uint32_t *__restrict__ idle, uint32_t batch_arg) {
     constexpr int KT0 = 8;
     const uint32_t batch = batch_arg & 0xFFFFu;
     constexpr bool SHARED = WPB == 8;          // one workgroup per CU, pairs handed out from s_next
@@ -357,8 +358,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
     // DEVWIDE: batches of `batch` (>= 2) consecutive pairs; a wave's first batch is static, later ones come from work[0] on the
     // scalar unit (work_take_*).  The take is issued in EVERY iteration at the same place - behind the iteration's last LDS
     // read, so that no lgkmcnt wait of the iteration covers it - and the loop body stays one basic block: in the iteration
-    // before a batch's last pair it adds `batch` to the counter, in all others it adds 0 to a word of the wave's own
-    // (work[16 (1 + wave id)]); scalar selects pick the address, the amount and, one iteration later, the result.
+    // before a batch's last pair it adds 1 to its counter word, in all others it adds 0 to a word of the wave's own
+    // (idle[16 wave id]); scalar selects pick the address, the amount and, one iteration later, the result.
     // The counter is split into `words` words (8 when the wave count allows it): wave w takes from word w % words, which hands
     // out the batches g = t * words + (w % words), t = 0, 1, ... - every word is shared by waves of ALL CUs, so the split keeps
     // the balance device-wide while one word only sees an eighth of the takes (one word serves ~88 M takes/s, eight ~430 M/s:
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
             // The statement names one accumulator register of each of tile B's layer-1 MFMA chains, so hipcc places it behind
             // the last of those MFMAs - i.e. behind the iteration's last LDS operand wait; nothing after that point touches
             // LDS until the next iteration, so no lgkmcnt wait sits on the take's round trip.
-            uint32_t *const addr = left == trigger ? work + 16u * my_word : work + 16u * (8u + wave_id);
+            uint32_t *const addr = left == trigger ? work + 16u * my_word : idle + 16u * wave_id;
             // (an opaque scalar 1: written as `left == 1u ? 1u : 0u` hipcc materialises the comparison on the vector unit and
             // the asm's scalar operand no longer is one)
             uint32_t one = 1u;
@@ -534,11 +535,15 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
         pair = cand;
         if constexpr (DEVWIDE) left = left != 0u ? left - 1u : batch - 1u;
     }
+    // the loop's final take is still in flight: retire it before its result register can be given to anything else
+    if constexpr (DEVWIDE) work_take_wait(taken);
     if (any) __builtin_nontemporal_store(cls_prev, cls_out + img_prev);
 #ifdef BNM_DIAG
     if (diag_store_mode == 6u) asm volatile("s_dcache_wb" ::: "memory");
 #endif
     bnm_wait_vmcnt<0>();   // LDS-DMA still in flight must not outlive the workgroup's LDS allocation
+    // the launch's counter block goes back to all-zero with the last wave to leave
+    if constexpr (DEVWIDE) work_block_leave_s(work, total_waves);
 #ifdef BNM_DIAG_TIMING
     // the logits buffer is reused as the record array: 4 x uint64 per wave {loop cycles, wait A, wait B, iterations}
     if (logits_out && lane == 0) {
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
 
 // ---- dispatch table: model shapes of the reference zoo (+ ternary) -----------------------------
 namespace {
-typedef void (*fused_fn)(const int8_t *, uint64_t, const i32x4 *, uint32_t, uint32_t *, int32_t *, uint64_t, uint32_t *, uint32_t);
+typedef void (*fused_fn)(const int8_t *, uint64_t, const i32x4 *, uint32_t, uint32_t *, int32_t *, uint64_t, uint32_t *, uint32_t *, uint32_t);
 struct FusedEntry {
     BnmFusedShape sh;
     int variant;
@@ -651,10 +656,10 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
             const uint64_t wpb = variant == FUSED_DUAL_SHARED ? 8 : FUSED_WPB;
             uint32_t batch = 1;
             if (variant == FUSED_DUAL_DEVWIDE) {
-                // work[16 k], k < 8: the counter words (zeroed here); work[16 (8 + w)]: wave w's own word for the zero-adds
-                if (!a.work || (n_main >> 6) >= (1ull << 31)) return hipErrorInvalidValue;
+                // work[16 k], k < 8: the counter words (all zero between launches: the kernel's last wave puts them back, so
+                // the launch is ONE dispatch); idle[16 w]: wave w's own word for the zero-adds
+                if (!a.work || !a.idle || (n_main >> 6) >= (1ull << 31)) return hipErrorInvalidValue;
                 batch = a.batch >= 1 ? a.batch : BNM_DUAL_DEFAULT_BATCH;
-                if (hipError_t err = hipMemsetAsync(a.work, 0, 8 * 64, s); err != hipSuccess) return err;
             }
             uint64_t want = ((n_main >> 6) + wpb * batch - 1) / (wpb * batch);
             uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * (variant == FUSED_DUAL_SHARED ? 1ull : 2ull);
@@ -664,7 +669,7 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
             const uint32_t words = (variant == FUSED_DUAL_DEVWIDE && ((blocks * wpb) & 7ull) == 0ull) ? 8u : 1u;
             if (batch > 0xFFFFu) batch = 0xFFFFu;
             e->fn<<<dim3((unsigned)blocks), dim3((unsigned)(64 * wpb)), 0, s>>>(
-                a.images, n_main, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap, a.work, batch | (words << 16));
+                a.images, n_main, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap, a.work, a.idle, batch | (words << 16));
             hipError_t err = hipGetLastError();
             if (err != hipSuccess) return err;
         }
@@ -683,7 +688,7 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
     uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * 2ull;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     e->fn<<<dim3(blocks), dim3(64 * FUSED_WPB), 0, s>>>(a.images, a.n, (const i32x4 *)a.frags, a.n_classes, a.cls, a.logits, a.src_wrap,
-                                                       nullptr, 0);
+                                                       nullptr, nullptr, 0);
     return hipGetLastError();
 }
 

@@ -84,7 +84,6 @@ hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int grid_blocks
     const uint64_t n_tiles = (n + 31ull) / 32ull;
     uint64_t want = (n_tiles + (uint64_t)waves * batch - 1) / ((uint64_t)waves * batch);
     uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus();   // one workgroup per CU
-    if (hipError_t e = hipMemsetAsync(counter, 0, 8 * 64, s); e != hipSuccess) return e;
     const uint64_t blocks = want < cap ? want : cap;
     const uint32_t words = ((blocks * waves) & 7ull) == 0ull ? 8u : 1u;
     return c.launch(d.KT0, d.sp, dbl, (unsigned)blocks, 64u * waves, lds, s, images, n, frags, d, cls, logits, counter,

@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         left = next_left;
     }
     bnm_wait_vmcnt<0>();   // no LDS-DMA may outlive the workgroup's LDS allocation
+    work_block_leave_s(counter, total_waves);   // the last wave to leave puts the counter block back to all-zero
 }
 
 // ---- per-class launcher: each tile class is its own translation unit (bnm_fused_generic_m{2,4,8}.hip) so that the

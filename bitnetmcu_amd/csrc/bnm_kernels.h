@@ -43,10 +43,16 @@ struct BnmFusedArgs {
     uint32_t *cls;          // [n]
     int32_t *logits;        // [n][n_classes] or nullptr
     uint64_t src_wrap = 0;  // diagnostic library only (BNM_DIAG): read tile (t mod src_wrap); ignored by the product build
-    uint32_t *work = nullptr;   // variant 6: device words [16 * (8 + BNM_WORK_DUMMY_WAVES)]: 8 counter words + one word per wave
+    uint32_t *work = nullptr;   // variant 6: the launch's counter block (BNM_WORK_BLOCK_WORDS words, all zero between launches)
+    uint32_t *idle = nullptr;   // variant 6: device words [16 * BNM_WORK_DUMMY_WAVES], one per wave, for the zero-adds (shared by all launches)
     uint32_t batch = 0;         // variant 6: pairs per take (0 = default)
 };
 constexpr uint32_t BNM_WORK_DUMMY_WAVES = 4096;
+// A counter block: counter words at [16 k], k < 8 (64 bytes apart), the leave count at [BNM_WORK_EXIT_WORD].  Owned by one stream
+// (bnm_capi.cpp); all zero between launches - the last wave of a launch to leave puts it back (bnm_device.hpp, work_block_leave_*),
+// so no launch is preceded by a memset.
+constexpr uint32_t BNM_WORK_BLOCK_WORDS = 256;
+constexpr uint32_t BNM_WORK_EXIT_WORD = 128;
 constexpr uint32_t BNM_DUAL_DEFAULT_BATCH = 2;     // pairs per take of the dual-tile kernel (profiles/headline_ab.py sweeps)
 // variant: 0 = direct global->VGPR image loads, 1 = LDS-DMA staged (256-byte rows only), 2 = LDS-DMA with two
 // tiles in flight per wave, 3 = two tiles computed per wave per iteration (default where instantiated)
@@ -74,7 +80,7 @@ constexpr int bnmk_generic_wps(int mmax, int kt0, int sp) {
 enum { BNM_FUSED_GENERIC = 4 };
 bool bnmk_generic_plan(BnmGenericDesc &d, const uint32_t m_real[4]);   // fills mmax, M, KTP, frag_off, w_bytes from KT0, sp
 bool bnmk_generic_supported(const BnmGenericDesc &d, bool dbl);
-// d_counter: 8 device words of the caller, 64 bytes apart (the launcher zeroes them); batch: tiles per take (0 = default)
+// d_counter: a counter block of the caller (BNM_WORK_BLOCK_WORDS words, all zero; the kernel leaves it all zero); batch: tiles per take (0 = default)
 hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int grid_blocks, const int8_t *d_images, uint64_t n,
                               const void *d_frags, uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t batch,
                               hipStream_t s);
@@ -95,8 +101,8 @@ hipError_t bnmk_maxpool22(const int32_t *d_in, uint32_t xy, int32_t *d_out, hipS
 // acts_stride: bytes between consecutive images' act rows (>= 4*C; bytes past 4*C are left untouched)
 // d_wtab: the per-channel weight table of the conv1-on-MFMA kernel (bnm_cnn_weight_table, uploaded by the caller) — or
 // nullptr to run the all-VALU kernel of round 1 (kept for A/B measurements, bnm_ctx_set_cnn_variant)
-// d_counter / grab: the MFMA kernel's waves take batches of `grab` images from this device word (zeroed by the launcher);
-// nullptr / 0: a fixed share per wave
+// d_counter / grab: the MFMA kernel's waves take batches of `grab` images from word 0 of this counter block (all zero on entry,
+// left all zero); nullptr / 0: a fixed share per wave
 hipError_t bnmk_cnn_front(const int8_t *d_images, uint64_t n, const int8_t *d_w1, const int8_t *d_w2,
                           const int8_t *d_w3, const int *d_wtab, uint32_t C, uint32_t n_shift, int8_t *d_acts,
                           uint32_t acts_stride, int32_t *d_feat, uint32_t *d_counter, uint32_t grab, hipStream_t s);
@@ -116,7 +122,7 @@ struct BnmTernArgs {
     int32_t *logits;
     const int *wstream;     // bnmk_ternary_stream_build's output (variants 1, 2)
     int variant;            // 0: round 1's kernel; 1: streamed weights, one image per lane; 2: two images per lane
-    uint32_t *counter;      // device word the streamed kernels hand image groups out from (zeroed by the launcher); nullptr: fixed stride
+    uint32_t *counter;      // counter block (word 0 hands the image groups out; all zero on entry, left all zero); nullptr: fixed stride
 };
 uint32_t bnmk_ternary_stream_dwords(const uint32_t n_out[4]);
 hipError_t bnmk_ternary_stream_build(const BnmTernArgs &a, int *d_stream, hipStream_t s);

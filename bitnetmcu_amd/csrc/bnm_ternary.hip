@@ -310,12 +310,15 @@ void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const 
     __shared__ uint32_t s_col[G * QL * 2 * 64];
     const int lane = threadIdx.x;
     uint32_t *col = s_col + lane;
-    // Groups of 64 G images: a wave's first group is static, every later one comes from a device-wide counter (zeroed by the
-    // launcher).  With a fixed stride the two waves of a SIMD do not finish together - the arbiter favours the older one -
+    // Groups of 64 G images: a wave's first group is static, every later one comes from a device-wide counter (word 0 of the
+    // launch's counter block, zero on entry).  With a fixed stride the two waves of a SIMD do not finish together - the arbiter favours the older one -
     // and the tail of the launch runs at one wave per SIMD; counter == nullptr keeps the fixed stride.
     const uint64_t stride = (uint64_t)gridDim.x * (64ull * G);
     uint64_t base = (uint64_t)blockIdx.x * (64ull * G);
-    if (base >= n) return;
+    if (base >= n) {      // (the launcher starts no such wave; a wave that leaves must count itself out all the same)
+        if (counter != nullptr) work_block_leave_v(counter, gridDim.x);
+        return;
+    }
     int nxt_v = 0;
 
     int x0[G][64];
@@ -401,6 +404,7 @@ void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const 
         }
         base = next_base;
     }
+    if (counter != nullptr) work_block_leave_v(counter, gridDim.x);   // the last wave to leave zeroes the counter block
 }
 
 // ---- weight stream of the streamed kernel -----------------------------------------------------------------------
@@ -455,8 +459,6 @@ hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s
                                                                            a.stride[3], a.n_out[3], a.cls, a.logits);
     } else {
         if (!a.wstream || want >= (1ull << 32)) return hipErrorInvalidValue;
-        if (a.counter)
-            if (hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s); e != hipSuccess) return e;
         if (G == 2)
             ternary_stream_kernel<2, 96, 96, 96, 20><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.wstream, a.n_out[3],
                                                                                          a.cls, a.logits, a.counter);

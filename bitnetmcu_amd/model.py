@@ -145,6 +145,10 @@ class Context:
         L.check(self._lib, self._lib.bnm_ctx_set_cnn_variant(self._h, variant), "bnm_ctx_set_cnn_variant")
         self.cnn_variant = 0 if variant == 0 else 1
 
+    def release_stream(self, stream):
+        """Drop the scratch buffers and the counter block the context keeps for `stream` (a torch.cuda.Stream); synchronises it."""
+        L.check(self._lib, self._lib.bnm_ctx_release_stream(self._h, stream.cuda_stream), "bnm_ctx_release_stream")
+
     def set_host_tuning(self, mode=0, copy_threads=0, spin=True):
         L.check(self._lib, self._lib.bnm_ctx_set_host_tuning(self._h, mode, copy_threads, 1 if spin else 0), "bnm_ctx_set_host_tuning")
 

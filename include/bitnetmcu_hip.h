@@ -126,7 +126,7 @@ BNM_API void bnm_ctx_destroy(bnm_ctx *c);
 BNM_API int bnm_ctx_device(const bnm_ctx *c);
 
 /* Kernel selection for the whole-model path. */
-#define BNM_PATH_AUTO 0      /* fused MFMA kernel where the codec decodes to int8, else ALU */
+#define BNM_PATH_AUTO 0      /* the fastest bit-exact kernel: fused MFMA wherever the model fits it (ternary included), else ALU */
 #define BNM_PATH_FUSED_MFMA 1
 #define BNM_PATH_LAYERWISE_ALU 2   /* one bit-serial kernel per layer (the reference's structure) */
 #define BNM_PATH_TERNARY_ALU 3     /* fused sign-accumulate kernel, no MFMA (ternary models) */
@@ -144,15 +144,21 @@ BNM_API int bnm_ctx_get_variant(const bnm_ctx *c);
 /* Whole-model batched inference, DEVICE pointers, asynchronous on `stream` (a hipStream_t;
  * NULL = default stream).  images: int8 [n][256]; cls: uint32 [n]; logits: int32
  * [n][num_classes] or NULL.  No host synchronisation is performed on the fused FC paths.
- * A few launches of one context may be in flight on different streams: work counters come from a ring (8 blocks for the
- * dual-tile kernel, 64 words for the others), and the scratch of the CNN and layer-wise paths (feature rows, activation
- * buffers) is kept per stream.  The first call on a stream, and a call with a larger batch than any before on it, allocates
- * or grows that scratch (hipMalloc / hipFree: device-synchronising).  Apart from that a call enqueues stream work only (a
- * counter memset and one or two kernels), so after one eager call on the capturing stream it may be captured into a HIP graph
- * and replayed.  Every class-id word is written exactly once per call (never a placeholder first): a host that maps d_cls in
+ * ANY number of launches of one context may be in flight on ANY number of streams: the work counters of the persistent kernels
+ * and the scratch of the CNN and layer-wise paths (feature rows, activation buffers) are kept per stream, and a kernel leaves
+ * its counters zeroed for the stream's next launch - no memset precedes a launch, so a fused-FC call is exactly one dispatch.
+ * The first call on a stream, and a call with a larger batch than any before on it, allocates or grows that scratch
+ * (hipMalloc / hipFree: device-synchronising); a context that has seen 32 streams drops what it keeps for the others
+ * (device-synchronising; bnm_ctx_release_stream does it for one stream explicitly).  Apart from that a call enqueues stream
+ * work only, so after one eager call on the capturing stream it may be captured into a HIP graph and replayed on any stream,
+ * next to eager launches: a captured launch gets counters of its own (up to 256 captured launches per context).
+ * Every class-id word is written exactly once per call (never a placeholder first): a host that maps d_cls in
  * page-locked memory may poll a pre-set sentinel, as bnm_infer_host does for n <= 64. */
 BNM_API int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls,
                              int32_t *d_logits, void *stream);
+/* Drop what the context keeps for `stream` (scratch buffers, counter block) - call it before destroying a stream the context
+ * was used on.  Synchronises the stream. */
+BNM_API int bnm_ctx_release_stream(bnm_ctx *c, void *stream);
 /* Same with HOST pointers; synchronous.  Up to 64 images: zero-copy (page-locked buffers the GPU addresses directly, one launch,
  * results polled in place) — the path behind Inference().  Larger batches: two page-locked staging slots on two streams,
  * host copy threads, H2D / compute / D2H of consecutive chunks overlapped. */

@@ -201,8 +201,8 @@ def test_cnn_front_end_both_kernels(name, gpu_ok, orc):
 @pytest.mark.parametrize("name,variant,n", [("fc_4bitsym_64", 6, 2_000_077), ("fc_4bitsym_64", 4, 2_000_077), ("fc_4bitsym_64", 3, 2_000_077),
                                             ("tern_96", -1, 1_000_033), ("cnn_64", -1, 200_011), ("mcu_cnn_16small", -1, 100_003)])
 def test_context_on_two_streams(name, variant, n, gpu_ok):
-    """Launches of ONE context queued on two streams at once (work counters come from a ring, one per launch; the CNN / layer-wise
-    scratch is kept per stream): every result equals the single-stream result."""
+    """Launches of ONE context queued on two streams at once (counter blocks and the CNN / layer-wise scratch are kept per
+    stream): every result equals the single-stream result."""
     import torch
     model = util.load_golden_model(name)
     ctx = b.Context(model)
@@ -226,9 +226,97 @@ def test_context_on_two_streams(name, variant, n, gpu_ok):
     ctx.close()
 
 
+def _setup(ctx, path, variant):
+    if path:
+        ctx.set_path(path)
+    if variant >= 0:
+        ctx.set_tuning(variant=variant)
+
+
+@pytest.mark.parametrize("name,path,variant,n", [("fc_4bitsym_64", 0, 6, 300_007), ("fc_4bitsym_64", 0, 4, 300_007),
+                                                 ("tern_96", 3, -1, 150_001), ("tern_96", 1, -1, 150_001), ("cnn_64", 0, -1, 60_013)])
+def test_many_launches_on_three_streams(name, path, variant, n, gpu_ok):
+    """120 launches of ONE context queued on three streams at once, far more than any ring could hold: every stream owns its counter
+    block, and every kernel leaves it zeroed for the stream's next launch (no memset between launches).  A launch that found a dirty
+    or shared counter would skip or repeat tiles; every result must equal the single-stream result."""
+    import torch
+    model = util.load_golden_model(name)
+    ctx = b.Context(model)
+    _setup(ctx, path, variant)
+    inputs = []
+    for k in range(4):
+        x = torch.empty((n - 1000 * k, 256), dtype=torch.int8, device="cuda")
+        synth.fill_device(x, first=k * 10_000_019, dist=DIST_U)
+        want = torch.empty(len(x), dtype=torch.int32, device="cuda")
+        ctx.infer_device(x, want)
+        inputs.append((x, want))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = []
+    for k in range(120):
+        x, want = inputs[(k * 7) % 4]
+        got = torch.full((len(x),), -1, dtype=torch.int32, device="cuda")
+        with torch.cuda.stream(streams[k % 3]):
+            ctx.infer_device(x, got)
+        outs.append((want, got))
+    torch.cuda.synchronize()
+    for k, (want, got) in enumerate(outs):
+        assert torch.equal(want, got), (name, path, variant, k)
+    # a released stream's block returns to the pool; the context keeps working on that stream afterwards
+    ctx.release_stream(streams[0])
+    x, want = inputs[0]
+    got = torch.full((len(x),), -1, dtype=torch.int32, device="cuda")
+    with torch.cuda.stream(streams[0]):
+        ctx.infer_device(x, got)
+    torch.cuda.synchronize()
+    assert torch.equal(want, got)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,path,variant,n", [("fc_4bitsym_64", 0, 6, 300_007), ("fc_4bitsym_64", 0, 4, 100_003), ("cnn_64", 0, -1, 30_011)])
+def test_graph_replays_next_to_eager_launches(name, path, variant, n, gpu_ok):
+    """A captured launch keeps a counter block of its own: the graph replayed on one stream while eager launches of the same
+    context run on the CAPTURING stream and on a third one - 30 rounds, every result equal to the single-stream result."""
+    import torch
+    model = util.load_golden_model(name)
+    ctx = b.Context(model)
+    _setup(ctx, path, variant)
+    xg = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+    xe = torch.empty((n + 777, 256), dtype=torch.int8, device="cuda")
+    synth.fill_device(xg, first=5, dist=DIST_U)
+    synth.fill_device(xe, first=77_000_000, dist=DIST_U)
+    want_g = torch.empty(n, dtype=torch.int32, device="cuda")
+    want_e = torch.empty(n + 777, dtype=torch.int32, device="cuda")
+    ctx.infer_device(xg, want_g)
+    ctx.infer_device(xe, want_e)
+    cap, other, third = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    got_g = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    with torch.cuda.stream(cap):
+        ctx.infer_device(xg, got_g)              # first use on the capturing stream: scratch is allocated here, not under capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap):
+        ctx.infer_device(xg, got_g)
+    torch.cuda.synchronize()
+    for k in range(30):
+        got_g.fill_(-1)
+        e1 = torch.full((n + 777,), -1, dtype=torch.int32, device="cuda")
+        e2 = torch.full((n + 777,), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(other):
+            g.replay()
+        with torch.cuda.stream(cap):
+            ctx.infer_device(xe, e1)
+        with torch.cuda.stream(third):
+            ctx.infer_device(xe, e2)
+        torch.cuda.synchronize()
+        assert torch.equal(got_g, want_g) and torch.equal(e1, want_e) and torch.equal(e2, want_e), (name, variant, k)
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", ["fc_4bitsym_64", "tern_96", "cnn_64"])
 def test_infer_device_under_graph_capture(name, gpu_ok, orc):
-    """bnm_infer_device enqueues only stream work (counter memset + kernels; scratch is allocated per stream on first use), so a
+    """bnm_infer_device enqueues only stream work (kernels; scratch is allocated per stream on first use), so a
     launch-bound small-batch loop can be captured into a HIP graph once and replayed: warm up on the capture stream, capture,
     replay on three different inputs, ids and logits against the oracle."""
     import torch
