@@ -2,19 +2,27 @@
 """Headline benchmark: BASELINE.json's metric — 16x16 int8 inferences/s on MI355X for the 4bitsym width-64 FC
 model (configs[1]: 100M synthetic images per GPU, resident in HBM), bit-exact vs the C reference.
 
-  python bench.py --gpus 1 --steps K --warmup W                 (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher: bench.py starts its N ranks itself (re-executes under `python -m torch.distributed.run
+--nproc-per-node N`, one rank per GPU over RCCL); launched BY torch.distributed.run it takes RANK / LOCAL_RANK / WORLD_SIZE
+from the environment and insists that WORLD_SIZE == --gpus.  `--dist-backend gloo --ranks-share-device` puts all ranks on
+GPU 0 with gloo collectives: the N > 1 code path (model broadcast, shards, barriers, MAX-reduced time, all-reduced digest)
+on a box that has ONE GPU - a functional check of the sharding, not a scaling measurement.
 
 A "step" is one pass of the whole hot path (packed-weight FC x4 + ReLUNorm x4, one fused kernel launch)
 over the rank's resident image shard.  --scaling weak (default): every GPU owns --images images; --scaling strong:
 --images images in total, split contiguously over the ranks.  No data-path collective
-(images are independent); one RCCL broadcast of the ~13 KB model blob at setup.
+(images are independent); one broadcast of the ~13 KB model blob at setup.
 Prints ONE JSON line on rank 0.  At N = 1 the line also carries "extra_configs": BASELINE configs[2] (ternary, ALU
-kernel, VALU-issue roofline), configs[3] (CNN), the logits variant, Dist-M and the same model through the generic
-fused kernel — each timed on the same resident image set and checked against the oracle on a sample.
+kernel, VALU-issue roofline), configs[3] (CNN), the logits variant, Dist-M, the same model through the generic fused kernel
+and the reference's documented 12 KB model family (docs/documentation.md:169-183) — each timed on the same resident image set
+and checked against the oracle on a sample.
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -23,15 +31,25 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
-HBM_MEASURED_CEILING_GBS = 6290.0   # same table: measured float4-copy ceiling
 BYTES_PER_INFERENCE = 260      # 256 B image read + 4 B class id written (SURVEY.md §8d / DESIGN.md)
-BYTES_PER_INFERENCE_LOGITS = 300
+BYTES_PER_INFERENCE_LOGITS_10 = 300
 # VALU issue roofline: one wave64 VALU instruction occupies its SIMD for 4 cycles (measured: SQ_ACTIVE_INST_VALU =
 # 4.0 cycles per instruction, profiles/r01/rocprof_r01f_ternary_cnn.md); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
 VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.0
+MACS_PER_WAVE_DOT4 = 4 * 64    # one wave64 v_dot4_i32_i8: 4 MACs per lane
 # the oracle's digest / histogram of ALL 1e8 class ids of the headline workload (fc_4bitsym_64, Dist-U, first image 0),
 # computed on the host cores by tests/test_gpu_fullsize.py::test_full_1e8_digest_and_histogram_equal_the_oracle
 ORACLE_DIGEST_1E8 = 0x81b56c9fafee6636
+
+
+def checker():
+    """The oracle-backed checker (oracle/checker.py): imported only for verification outside the timed region and for the
+    cpu_baseline leg.  The product package never imports it."""
+    p = os.path.join(REPO, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import checker as ck
+    return ck
 
 
 def host_cores():
@@ -45,7 +63,7 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(model_name, dist, seconds):
+def cpu_baseline(b, model_name, dist, seconds):
     """The reference's UNMODIFIED BitMnistInference (oracle/_ref/<model>/Bitnet_inf_O3.dll) on all host cores
     over a bounded sample of the same synthetic workload.  Reported next to the GPU number; not a target."""
     cores = host_cores()
@@ -65,10 +83,7 @@ def cpu_baseline(model_name, dist, seconds):
                           f"dist {'U' if dist == 0 else 'M'}"}
     # port fallback (fresh clone without oracle/_ref): the C restatement, one Python thread per core
     import threading
-    sys.path.insert(0, os.path.join(REPO, "tests"))
-    import util
-    import bitnetmcu_amd as b
-    om = util.OracleModel(util.load_golden_model(model_name))
+    om = checker().OracleModel(b.Model.from_zoo(model_name))
     x = b.synth.images(0, 8192, dist)
     done = [0] * cores
     t_end = time.time() + seconds
@@ -87,8 +102,8 @@ def cpu_baseline(model_name, dist, seconds):
 
 
 def load_counters():
-    """Per-kernel constants measured with rocprofv3 --pmc in separate passes (profiles/collect_counters.sh ->
-    profiles/pmc_counters.json): HBM bytes per launch, VALU instructions per image, MFMA busy fraction.  They are properties
+    """Per-kernel constants measured with rocprofv3 --pmc in separate passes (profiles/pmc_kernel.sh ->
+    profiles/pmc_counters.json, pmc_traffic.json): HBM bytes per launch, VALU instructions per image.  They are properties
     of the kernel binaries; bench.py REPLAYS them next to its live timing and says so in every field it fills from here."""
     out = {}
     for name in ("pmc_traffic.json", "pmc_counters.json"):
@@ -101,20 +116,6 @@ def load_counters():
     return out
 
 
-def plain_stream_reference():
-    """Replayed, not measured by this run: profiles/ceiling_ab.py's same-box, same-process comparison of the default kernel with
-    plain 16 B/lane streaming loads of the same 25.6 GB (needs the diagnostic library, which bench.py never loads)."""
-    p = os.path.join(REPO, "profiles", "r02", "ceiling_ab_r02_final5.json")
-    try:
-        t = open(p).read()
-        d = json.loads(t[t.index("{"):])
-        return {"plain_stream_ms": d["plain_stream"]["median_ms"], "kernel_ms_same_box": d["kernel"]["median_ms"],
-                "kernel_over_plain_stream_bytes_per_s": d["kernel_over_plain_stream_bytes_per_s"],
-                "source": "replayed from profiles/r02/ceiling_ab_r02_final5.json (profiles/ceiling_ab.py on another box; not measured by this run)"}
-    except Exception:
-        return None
-
-
 def kernel_name(b, ctx, model):
     v = ctx.variant
     fused = {3: "fused_fc_dual_kernel", 5: "fused_fc_dual_kernel", 6: "fused_fc_dual_kernel", 4: "fused_fc_generic_kernel"}.get(v, "fused_fc_kernel")
@@ -124,18 +125,35 @@ def kernel_name(b, ctx, model):
     return k + ("+" + cnn if model.kind == b.KIND_CNN else "")
 
 
-def load_model_through_the_text_parser(b, util, name, header=None):
+def model_macs(b, model):
+    """multiply-accumulates of one inference: FC layers over their REAL inputs (a ternary layer's padded trits are not work),
+    conv layers 9 per output position (BitNetMCU_MNIST_dll.c:66-80: 14x14, 12x12, 4x4 positions per channel)"""
+    macs, width = 0, 256
+    layers = model.layers()
+    if model.kind == b.KIND_CNN:
+        c = layers[0].out_channels
+        macs += c * 9 * (14 * 14 + 12 * 12 + 4 * 4)
+        width = 4 * c
+    for li in layers:
+        if li.type == 1:      # BNM_LAYER_FC
+            macs += min(li.n_input, width) * li.n_output
+            width = li.n_output
+    return macs
+
+
+def load_model_through_the_text_parser(b, name, header=None):
     """The product's model path is exporter TEXT -> run-time parser -> GPU.  The reference's headers do not travel to the GPU
-    box (only their weight data does, as tests/golden/models/*.bnm), so the text is re-emitted in the exporter's dialect from
-    the committed blob (tests/headerwriter.py), parsed by the library like any BitNetMCU_model.h, and must reproduce the blob."""
+    box (only their weight data does, as bitnetmcu_amd/zoo/*.bnm), so unless --header names a real exporter-written file the
+    text is RE-EMITTED from the committed blob by the package's own writer (bitnetmcu_amd/headerwriter.py: the exporter's
+    dialect, not the exporter's bytes), parsed by the library like any BitNetMCU_model.h, and must reproduce the blob."""
     if header:
-        return b.Model.from_header(header), "header text: " + header
-    import headerwriter
-    blob_model = util.load_golden_model(name)
-    model = b.Model.from_header_text(headerwriter.write_header(blob_model))
+        return b.Model.from_header(header), "exporter-written header file " + header + " through the run-time parser"
+    blob_model = b.Model.from_zoo(name)
+    model = b.Model.from_header_text(blob_model.to_header_text())
     if model.to_blob() != blob_model.to_blob():
         raise RuntimeError(f"{name}: header text -> parser does not reproduce the committed blob")
-    return model, f"exporter-dialect header text of tests/golden/models/{name}.bnm through the run-time parser"
+    return model, (f"bitnetmcu_amd/zoo/{name}.bnm re-emitted as header text by bitnetmcu_amd/headerwriter.py (exporter dialect; "
+                   "not the exporter's own bytes) and parsed by the run-time parser")
 
 
 def timed_steps(torch, step, steps, warmup, barrier=None):
@@ -161,44 +179,56 @@ def timed_steps(torch, step, steps, warmup, barrier=None):
     return elapsed, [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
 
 
-def verify_sample(np, torch, util, model, images, cls, logits, n, first=0):
-    """head + tail + strided sample of the resident set against the oracle (class ids, and logits when written)"""
-    om = util.OracleModel(model)      # the checker
-    idx = np.concatenate([np.arange(0, 4096), np.arange(n - 2048, n), np.linspace(0, n - 1, 2048).astype(np.int64)])
-    idx = np.unique(idx[(idx >= 0) & (idx < n)])
-    ti = torch.from_numpy(idx).to(images.device)
-    sample = images[ti].cpu().numpy()
-    want, want_lg = om.infer(sample, logits=True)
-    ok = bool(np.array_equal(want, cls[ti].cpu().numpy().astype(np.uint32)))
-    if logits is not None:
-        ok = ok and bool(np.array_equal(want_lg, logits[ti].cpu().numpy()))
-    return ok
+def relaunch_with_ranks(a):
+    """--gpus N > 1 and no launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node (N > 1 without a launcher: bench.py starts them itself)")
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images", type=int, default=100_000_000, help="images per GPU (weak) or in total (strong); configs[1]: 1e8")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL (one rank per GPU); gloo for --ranks-share-device")
+    ap.add_argument("--ranks-share-device", action="store_true",
+                    help="all ranks on GPU 0 (needs --dist-backend gloo): the N > 1 code path on a one-GPU box; not a scaling measurement")
     ap.add_argument("--model", default="fc_4bitsym_64")
     ap.add_argument("--dist", type=int, default=0, help="0 = Dist-U (headline), 1 = Dist-M")
-    ap.add_argument("--logits", action="store_true", help="also write the 10 int32 logits (300 B/inference)")
+    ap.add_argument("--logits", action="store_true", help="also write the int32 logits (300 B/inference for 10 classes)")
     ap.add_argument("--variant", type=int, default=-1, help="fused kernel variant (-1 = default; 4 = generic kernel)")
     ap.add_argument("--grid", type=int, default=0, help="workgroups (0 = default)")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 fused MFMA, 2 layer-wise ALU, 3 ternary ALU")
     ap.add_argument("--cnn-variant", type=int, default=-1, help="CNN front end: 1 conv1 on MFMA (default), 0 all-VALU kernel of round 1")
     ap.add_argument("--ternary-variant", type=int, default=-1,
                     help="ternary ALU kernel: 2 streamed weights, two images per lane (default), 1 one image per lane, 0 round 1's kernel")
-    ap.add_argument("--work-batch", type=int, default=0, help="generic fused kernel: tiles per take from the work counter (0 = default)")
+    ap.add_argument("--work-batch", type=int, default=0, help="fused kernels: tiles / pairs per take from the work counter (0 = default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs section (N = 1 only)")
     ap.add_argument("--header", default=None, help="load the model from this exporter-written BitNetMCU_model.h (text parser) "
-                                                  "instead of tests/golden/models/<model>.bnm")
+                                                  "instead of bitnetmcu_amd/zoo/<model>.bnm")
     a = ap.parse_args()
+    if a.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if a.ranks_share_device and a.dist_backend != "gloo":
+        sys.exit("--ranks-share-device needs --dist-backend gloo (RCCL wants one device per rank)")
+
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if a.gpus > 1 and not launched:
+        relaunch_with_ranks(a)          # does not return
 
     import numpy as np
     import torch
@@ -207,33 +237,41 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit(f"bench.py --gpus {a.gpus} was launched with WORLD_SIZE={world}: the two must agree "
+                 f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus}, or plain `python bench.py --gpus {a.gpus}`)")
     # launched by torch.distributed.run (even with one rank): go through the process group, so the N>1 code path
     # (RCCL init, model broadcast, barriers, MAX-reduced time, all-reduced digest) is the one that runs
-    distributed = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    distributed = launched
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    dev_index = 0 if a.ranks_share_device else local_rank
+    if dev_index >= torch.cuda.device_count():
+        sys.exit(f"rank {rank}: GPU {dev_index} requested but only {torch.cuda.device_count()} visible "
+                 "(one rank per GPU; --dist-backend gloo --ranks-share-device runs all ranks on GPU 0)")
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
+    td = None
     if distributed:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    if distributed:
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.dist_backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            td.init_process_group("gloo", rank=rank, world_size=world)
+    coll_dev = dev if a.dist_backend == "nccl" else torch.device("cpu")     # where the (tiny) collectives' tensors live
     barrier = td.barrier if distributed else None
 
-    sys.path.insert(0, os.path.join(REPO, "tests"))
-    import util
-
-    # ---- model: rank 0 reads it, RCCL-broadcasts the blob (~13 KB) ------------------------------------
+    # ---- model: rank 0 reads it, the blob (~13 KB) is broadcast ---------------------------------------
     model = None
     model_source = None
     if rank == 0:
-        model, model_source = load_model_through_the_text_parser(b, util, a.model, a.header)
+        model, model_source = load_model_through_the_text_parser(b, a.model, a.header)
     if distributed:
-        model = b.dist.broadcast_model(model, src=0, device=dev)
-    ctx = b.Context(model, device=local_rank)
+        model = b.dist.broadcast_model(model, src=0, device=coll_dev)
+    ctx = b.Context(model, device=dev_index)
     if a.path:
         ctx.set_path(a.path)
     if a.variant >= 0 or a.grid > 0:
@@ -262,7 +300,7 @@ def main():
 
     elapsed, launch_ms = timed_steps(torch, lambda: ctx.infer_device(images, cls, logits), a.steps, a.warmup, barrier)
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -270,32 +308,35 @@ def main():
     verified = None
     digest = b.synth.digest_device(cls, first=first, n_bins=model.num_classes)
     if distributed:
-        digest = b.dist.allreduce_digest(digest)
+        digest = b.dist.allreduce_digest(digest.to(coll_dev))
     torch.cuda.synchronize()
     dg = digest.cpu().numpy()
     digest_hex = hex(int(dg[0].astype(np.uint64)))
     hist = dg[1:].astype(np.int64)
     headline = a.model == "fc_4bitsym_64" and a.dist == 0 and n_global == 100_000_000 and not a.header
     if rank == 0 and not a.no_verify:
-        verified = verify_sample(np, torch, util, model, images, cls, logits, n) and int(hist.sum()) == n_global
+        verified = checker().verify_sample(torch, model, images, cls, logits, n) and int(hist.sum()) == n_global
         if headline:   # every one of the 1e8 class ids, through the order-independent digest the oracle produced on host cores
             verified = verified and int(dg[0].astype(np.uint64)) == ORACLE_DIGEST_1E8
 
     if rank == 0:
         counters = load_counters()
         total = n_global * a.steps
-        bpi = BYTES_PER_INFERENCE_LOGITS if a.logits else BYTES_PER_INFERENCE
+        bpi = 256 + 4 + (4 * model.num_classes if a.logits else 0)
         avg_ms = float(np.mean(launch_ms))
         achieved = n * bpi / (avg_ms * 1e-3) / 1e9
         kname = kernel_name(b, ctx, model)
-        traffic, traffic_source, mfma_busy = None, None, None
+        # the box's plain read rate over the same resident images, same process, same stream (bnm_stream_read_device)
+        sink = torch.zeros(1, dtype=torch.int32, device=dev)
+        _, rd_ms = timed_steps(torch, lambda: b.synth.stream_read_device(images, sink), 5, 2)
+        rd = float(np.median(rd_ms))
+        stream_read = {"ms": rd, "bytes": n * 256, "GB/s": n * 256 / (rd * 1e-3) / 1e9,
+                       "what": "plain nontemporal 16 B/lane loads of this rank's resident images, nothing written; median of 5 launches after 2"}
+        traffic, traffic_source = None, None
         tj = counters.get("pmc_traffic.json")
         if tj and headline and world == 1 and not a.logits and kname == tj.get("kernel", "fused_fc_dual_kernel"):
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = f"replayed from profiles/pmc_traffic.json (rocprofv3 --pmc pass {tj.get('source')}; not measured by this run)"
-        cj = counters.get("pmc_counters.json", {}).get(kname.split("+")[0])
-        if cj and "mfma_busy_frac" in cj:
-            mfma_busy = {"value": cj["mfma_busy_frac"], "source": f"replayed from profiles/pmc_counters.json (pass {cj.get('source')})"}
         out = {
             "metric": ("16x16 int8 MNIST inferences/s, FC 4bitsym 64-64-64 (BitNetMCU_model_fc.h), bit-exact vs C reference"
                        if a.model == "fc_4bitsym_64" else f"16x16 int8 inferences/s, model {a.model}, bit-exact vs C reference"),
@@ -311,13 +352,17 @@ def main():
             "dtype": "i8",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: {a.model}, {n} synthetic 16x16 int8 images per GPU resident in HBM "
+                "workload": f"BASELINE configs[{1 if world == 1 else 4}]: {a.model}, {n} synthetic 16x16 int8 images per GPU resident in HBM "
                             f"(dist {'U' if a.dist == 0 else 'M'}), class ids{' + logits' if a.logits else ''} written",
                 "images_per_gpu": n,
                 "global_images": n_global,
                 "path": ctx.path,
                 "model_source": model_source,
-                "parallelism": f"dp{world} image-shard ({a.scaling} scaling), no data-path collective",
+                "parallelism": f"dp{world} image-shard ({a.scaling} scaling), no data-path collective"
+                               + (" - ALL RANKS ON GPU 0 (functional check of the N > 1 path, not a scaling measurement)" if a.ranks_share_device else ""),
+                "dist_backend": (a.dist_backend if distributed else None),
+                "rccl_ranks": (td.get_world_size() if distributed and a.dist_backend == "nccl" else None),
+                "ranks_share_device": bool(a.ranks_share_device),
             },
             "roofline": {
                 "bound": "hbm",
@@ -325,17 +370,17 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "frac_of_measured_ceiling": achieved / HBM_MEASURED_CEILING_GBS,
-                "measured_ceiling": HBM_MEASURED_CEILING_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
-                "mfma_busy_frac": mfma_busy,
-                "plain_stream_reference": plain_stream_reference(),
                 "kernel": kname,
                 "avg_launch_ms": avg_ms,
+                "median_launch_ms": float(np.median(launch_ms)),
                 "min_launch_ms": float(np.min(launch_ms)),
                 "algorithmic_bytes_per_launch": n * bpi,
                 "fused_variant": ctx.variant,
+                "stream_read": stream_read,
+                # > 1: the kernel takes longer than merely reading its input on this box
+                "time_vs_stream_read": float(np.median(launch_ms)) / rd,
             },
             "verified_vs_oracle": verified,
             "digest": digest_hex,
@@ -343,40 +388,44 @@ def main():
             "class_histogram": hist.tolist(),
         }
         if world == 1 and not a.no_extra:
-            out["extra_configs"] = extra_configs(a, np, torch, b, util, dev, images, cls, n, counters)
+            out["extra_configs"] = extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read)
         if world == 1 and not a.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(a.model, a.dist, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(b, a.model, a.dist, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if distributed:
+        td.barrier()
         td.destroy_process_group()
 
 
-def extra_configs(a, np, torch, b, util, dev, images, cls, n, counters):
+def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     """The other BASELINE configs and variants on the SAME resident image set, each checked against the oracle on a sample.
     Every entry: inferences/s from HIP events over `steps` launches after `warmup`, the roofline that binds it."""
     cj = counters.get("pmc_counters.json", {})
     res = {}
+    ck = None if a.no_verify else checker()
+    rd_rate = stream_read["GB/s"]
 
-    def hbm(rate, bpi):
-        g = rate * bpi / 1e9
-        return {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
-                "frac_of_measured_ceiling": g / HBM_MEASURED_CEILING_GBS}
-
-    def valu(rate, kernel, bpi):
-        c = cj.get(kernel)
+    def valu(rate, kernel, bpi, model):
+        """VALU-bound kernels.  frac = ALGORITHMIC fraction of the VALU issue roofline: the model's multiply-accumulates at 4 per
+        lane of a v_dot4 (the densest integer VALU form), i.e. MACs / 256 wave instructions per image - it falls when the kernel
+        spends instructions on anything else.  pipe_utilisation = the kernel's own instruction count x rate / peak (how busy the
+        pipe is, whatever it is busy with)."""
+        macs = model_macs(b, model)
+        alg = macs / MACS_PER_WAVE_DOT4
         r = {"bound": "valu", "unit": "wave64 VALU instructions/s", "peak": VALU_PEAK_WAVE_INSTR_PER_S,
+             "macs_per_image": macs, "algorithmic_valu_per_image": alg, "achieved": rate * alg,
+             "frac": rate * alg / VALU_PEAK_WAVE_INSTR_PER_S,
+             "definition": "frac = MACs per image / (4 MACs x 64 lanes per wave64 v_dot4) x inferences/s / (1024 SIMDs x 2.4 GHz / 4 cycles)",
              "hbm_frac": rate * bpi / 1e9 / HBM_PEAK_GBS}
+        c = cj.get(kernel)
         if c and "valu_per_image" in c:
-            r.update({"achieved": rate * c["valu_per_image"], "frac": rate * c["valu_per_image"] / VALU_PEAK_WAVE_INSTR_PER_S,
-                      "valu_per_image": c["valu_per_image"],
-                      "source": f"instruction count replayed from profiles/pmc_counters.json (SQ_INSTS_VALU, pass {c.get('source')}); "
-                                "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"})
-        else:
-            r.update({"achieved": None, "frac": None})
+            r.update({"valu_per_image": c["valu_per_image"],
+                      "pipe_utilisation": rate * c["valu_per_image"] / VALU_PEAK_WAVE_INSTR_PER_S,
+                      "valu_per_image_source": f"instruction count replayed from profiles/pmc_counters.json (SQ_INSTS_VALU, pass {c.get('source')})"})
         return r
 
     def run(name, model_name, count, steps, warmup, dist=0, want_logits=False, variant=-1, path=0, note=None):
-        model, _ = load_model_through_the_text_parser(b, util, model_name)
+        model, _ = load_model_through_the_text_parser(b, model_name)
         ctx = b.Context(model, device=dev.index)
         if path:
             ctx.set_path(path)
@@ -387,7 +436,7 @@ def extra_configs(a, np, torch, b, util, dev, images, cls, n, counters):
         lg = torch.empty((count, model.num_classes), dtype=torch.int32, device=dev) if want_logits else None
         _, ms = timed_steps(torch, lambda: ctx.infer_device(x, c, lg), steps, warmup)
         rate = count / (float(np.mean(ms)) * 1e-3)
-        ok = None if a.no_verify else verify_sample(np, torch, util, model, x, c, lg, count)
+        ok = None if a.no_verify else ck.verify_sample(torch, model, x, c, lg, count)
         res[name] = {"model": model_name, "images": count, "dist": "U" if dist == 0 else "M", "steps": steps, "warmup": warmup,
                      "value": rate, "unit": "inferences/s", "avg_launch_ms": float(np.mean(ms)), "min_launch_ms": float(np.min(ms)),
                      "kernel": kernel_name(b, ctx, model), "path": ctx.path, "fused_variant": ctx.variant, "verified_vs_oracle": ok}
@@ -395,31 +444,41 @@ def extra_configs(a, np, torch, b, util, dev, images, cls, n, counters):
             res[name]["note"] = note
         ctx.close()
         del lg
-        return rate
+        return rate, model
+
+    def hbm_entry(name, rate, bpi):
+        g = rate * bpi / 1e9
+        res[name]["roofline"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
+                                 "time_vs_stream_read": res[name]["avg_launch_ms"] / (res[name]["images"] * 256 / rd_rate / 1e6)}
 
     n_cnn = min(n, 10_000_000)
     # configs[2]: ternary 96-96-96, bit-unpack / sign-accumulate ALU kernel, no MFMA — bound by the VALU issue rate
-    r = run("ternary_alu", "tern_96", n, 3, 1, path=b.PATH_TERNARY_ALU, note="BASELINE configs[2]")
-    res["ternary_alu"]["roofline"] = valu(r, "ternary_stream_kernel", BYTES_PER_INFERENCE)
-    # the same model through the generic MFMA kernel (option; no spills since round 2)
-    r = run("ternary_mfma_generic", "tern_96", n, 5, 1, path=b.PATH_FUSED_MFMA)
-    res["ternary_mfma_generic"]["roofline"] = hbm(r, BYTES_PER_INFERENCE)
+    # (selected by name: the library's AUTO path runs ternary models on the MFMA kernels, 5x faster - next entry)
+    r, m = run("ternary_alu", "tern_96", n, 3, 1, path=b.PATH_TERNARY_ALU, note="BASELINE configs[2]: the no-MFMA kernel, selected explicitly")
+    res["ternary_alu"]["roofline"] = valu(r, "ternary_stream_kernel", BYTES_PER_INFERENCE, m)
+    r, _ = run("ternary_mfma_generic", "tern_96", n, 5, 1, note="the same model on the library's default (AUTO) path")
+    hbm_entry("ternary_mfma_generic", r, BYTES_PER_INFERENCE)
     # configs[3]: CNN 64-wide
-    r = run("cnn_64", "cnn_64", n_cnn, 3, 1, note="BASELINE configs[3]")
-    res["cnn_64"]["roofline"] = valu(r, "cnn_front_mfma_kernel", BYTES_PER_INFERENCE)
+    r, m = run("cnn_64", "cnn_64", n_cnn, 3, 1, note="BASELINE configs[3]")
+    res["cnn_64"]["roofline"] = valu(r, "cnn_front_mfma_kernel", BYTES_PER_INFERENCE, m)
     # headline model through the generic kernel (what any non-zoo 64-wide export would get)
-    r = run("fc_generic_kernel", "fc_4bitsym_64", n, 5, 2, variant=4)
-    res["fc_generic_kernel"]["roofline"] = hbm(r, BYTES_PER_INFERENCE)
+    r, _ = run("fc_generic_kernel", "fc_4bitsym_64", n, 5, 2, variant=4)
+    hbm_entry("fc_generic_kernel", r, BYTES_PER_INFERENCE)
+    # the reference's documented 12 KB family (docs/documentation.md:169-183; its 4-bit member is the headline model): random
+    # weights of those shapes and codecs from the reference's own exporter (tests/golden/make_doc12k_headers.py)
+    for nm in ("doc12k_binary", "doc12k_ternary", "doc12k_2bit", "doc12k_8bit"):
+        r, _ = run(nm, nm, n, 5, 2, note="reference docs' 12 KB model family")
+        hbm_entry(nm, r, BYTES_PER_INFERENCE)
     # headline model, class ids + logits (300 B per inference)
     if n <= 100_000_000:
-        r = run("fc_logits", "fc_4bitsym_64", n, 5, 2, want_logits=True)
-        res["fc_logits"]["roofline"] = hbm(r, BYTES_PER_INFERENCE_LOGITS)
+        r, _ = run("fc_logits", "fc_4bitsym_64", n, 5, 2, want_logits=True)
+        hbm_entry("fc_logits", r, BYTES_PER_INFERENCE_LOGITS_10)
     # headline model on Dist-M (MNIST-like value statistics): refill the resident set in place
     if a.dist == 0:
         b.synth.fill_device(images, first=0, dist=1)
         torch.cuda.synchronize()
-        r = run("fc_dist_m", "fc_4bitsym_64", n, 5, 2, dist=1)
-        res["fc_dist_m"]["roofline"] = hbm(r, BYTES_PER_INFERENCE)
+        r, _ = run("fc_dist_m", "fc_4bitsym_64", n, 5, 2, dist=1)
+        hbm_entry("fc_dist_m", r, BYTES_PER_INFERENCE)
     return res
 
 

@@ -76,6 +76,7 @@ PROTOTYPES = {
                                                    C.c_int, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "bnm_synth_fill_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "bnm_class_digest_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, _vp]),
+    "bnm_stream_read_device": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
     "bnm_run_synth_multi_gpu": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, C.c_uint64, _vp, C.c_uint32, C.POINTER(C.c_double)]),
     "bnm_bind_default_model": (C.c_int, [_vp]),
     "bnm_device_count": (C.c_int, []),

@@ -1069,6 +1069,13 @@ int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint64_t n, u
     return BNM_OK;
 }
 
+int bnm_stream_read_device(const void *d_src, uint64_t bytes, uint32_t *d_sink, void *stream) {
+    if (bytes && (!d_src || !d_sink)) return fail(BNM_EINVAL, "null pointer");
+    if ((uintptr_t)d_src & 15u) return fail(BNM_EINVAL, "d_src must be 16-byte aligned");
+    HIP_TRY(bnmk_stream_read(d_src, bytes, d_sink, (hipStream_t)stream));
+    return BNM_OK;
+}
+
 #ifdef BNM_DIAG
 // ---- diagnostic library only (bitnetmcu_amd/build.py --diag; declared in csrc/bnm_diag.h, not in the public header) ----
 int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out, void *stream) {

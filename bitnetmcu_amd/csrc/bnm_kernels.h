@@ -10,6 +10,9 @@ hipError_t bnmk_synth_fill(int8_t *d_images, uint64_t first, uint64_t count, uin
 hipError_t bnmk_class_digest(const uint32_t *d_cls, uint64_t first, uint64_t n, uint64_t *d_out,
                              uint32_t n_bins, hipStream_t s);
 
+// plain 16 B/lane nontemporal read of `bytes` bytes (a multiple of 16 is read); d_sink: one device dword that is practically never written
+hipError_t bnmk_stream_read(const void *d_src, uint64_t bytes, uint32_t *d_sink, hipStream_t s);
+
 // ---- GPU unpack: packed words -> int8 rows -> MFMA A-operand fragments ------------------------
 // lo/hi: [n_output][row_stride] int8, w = lo + hi (hi != 0 only for FP1.3.0's +-128).
 hipError_t bnmk_unpack_rows(const void *d_packed, int32_t bpw, uint32_t n_input, uint32_t n_real,

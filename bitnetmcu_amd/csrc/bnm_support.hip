@@ -177,3 +177,30 @@ hipError_t bnmk_quantize_input(const float *x, uint64_t n, int8_t *out, hipStrea
     return hipGetLastError();
 }
 
+
+// ---- the box's plain read rate ------------------------------------------------------------------------------------
+// Plain nontemporal 16 B/lane loads of a resident buffer, grid-stride, four loads in flight per lane, XOR-folded; nothing is
+// written (one conditional dword that practically never fires keeps the loads alive).  bench.py times this over the SAME
+// image set next to the inference kernels: an HBM-bound kernel's distance from its binding roofline is its time relative
+// to just reading its input on THIS box (boxes differ by 10 % in what they stream).
+__global__ __launch_bounds__(256) void stream_read_kernel(const u32x4 *__restrict__ src, uint64_t n16, uint32_t *__restrict__ sink) {
+    uint32_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        acc ^= a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3] ^ c[0] ^ c[1] ^ c[2] ^ c[3] ^ d[0] ^ d[1] ^ d[2] ^ d[3];
+    }
+    for (; i < n16; i += stride) {
+        const u32x4 a = __builtin_nontemporal_load(src + i);
+        acc ^= a[0] ^ a[1] ^ a[2] ^ a[3];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+hipError_t bnmk_stream_read(const void *d_src, uint64_t bytes, uint32_t *d_sink, hipStream_t s) {
+    if (bytes < 16) return hipSuccess;
+    stream_read_kernel<<<dim3((unsigned)bnm_num_cus() * 8u), dim3(256), 0, s>>>((const u32x4 *)d_src, bytes / 16ull, d_sink);
+    return hipGetLastError();
+}

@@ -119,6 +119,24 @@ def header_text(quantized_model, modelname=None):
     return "\n".join(o) + "\n"
 
 
+def record_geometry(layers):
+    """Write incoming_x/y and outgoing_x/y into the BitConv2d / MaxPool2d dicts, as the reference's own inference_quantized does
+    while it runs (BitNetMCU.py:479-483, 509-513; the fields start at 0): export_to_hfile writes them out
+    (exportquant.py:222-259), so an evaluator that replaces the reference method must leave them filled in - a header exported
+    after attach() would otherwise say `#define Lk_incoming_x 0`.  Same arithmetic as the reference: valid convolution, 2x2 pool."""
+    xy = 16
+    for l in layers:
+        if l["layer_type"] == "BitConv2d":
+            k = l["kernel_size"][0] if isinstance(l["kernel_size"], (tuple, list)) else int(l["kernel_size"])
+            l["incoming_x"] = l["incoming_y"] = xy
+            xy = xy - k + 1
+            l["outgoing_x"] = l["outgoing_y"] = xy
+        elif l["layer_type"] == "MaxPool2d":
+            l["incoming_x"] = l["incoming_y"] = xy
+            xy //= 2
+            l["outgoing_x"] = l["outgoing_y"] = xy
+
+
 class QuantizedEvaluator:
     """A reference `quantized_model` resident on one GPU, evaluated with the C engine's exact integer arithmetic."""
 
@@ -126,6 +144,14 @@ class QuantizedEvaluator:
         layers = getattr(quantized_model, "quantized_model", quantized_model)
         if not layers:
             raise ValueError("quantized_model is empty or None")          # BitNetMCU.py:432-433
+        record_geometry(layers)
+        if any(l.get("WScale") == "PerOutput" for l in layers):
+            # the reference method multiplies its float logits by quantized_scale for per-output scales (BitNetMCU.py:529-531);
+            # the exporter drops those scales and the C engine never sees them - this evaluator returns what the C engine computes
+            import warnings
+            warnings.warn("bitnetmcu_amd.evaluate: a layer uses WScale='PerOutput'; the per-output scales are not part of the exported "
+                          "header, so the C engine's int32 logits (returned here) can rank classes differently from "
+                          "QuantizedModel.inference_quantized, which applies them", stacklevel=3)
         self.text = header_text(layers, modelname)
         self.model = Model.from_header_text(self.text, lib)
         self.ctx = Context(self.model, device)
@@ -173,7 +199,9 @@ def from_quantized_model(qm, device=-1, modelname=None, lib=None):
 def attach(qm, device=-1, modelname=None):
     """Replace qm.inference_quantized by the GPU evaluator's (the reference's scripts then call it unchanged,
     exportquant.py:537-559, test_inference.py:153).  Returns the evaluator; the original method stays at
-    qm.inference_quantized_reference."""
+    qm.inference_quantized_reference.  Like the method it replaces, it leaves the conv / pool geometry (incoming_x ...) filled in
+    in qm.quantized_model, which export_to_hfile depends on.  It returns the C engine's int32 logits: per-output weight scales
+    (WScale='PerOutput'), which only the Python method applies and the exporter drops, are NOT applied (a warning says so)."""
     ev = from_quantized_model(qm, device, modelname)
     qm.inference_quantized_reference = qm.inference_quantized
     qm.inference_quantized = ev.inference_quantized

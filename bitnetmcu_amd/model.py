@@ -1,9 +1,15 @@
 """Model (host, parsed header) and Context (model resident on one GPU)."""
 import ctypes as C
+import os
 
 import numpy as np
 
 from . import _lib as L
+
+# Model zoo: the weight data of every header in the reference tree (and of the generated ternary / 12 KB-family headers under
+# tests/golden/headers) as BNMBLOB1 blobs, written by tests/golden/make_golden.py after a word-for-word check against the
+# compiled reference's own Lk_weights symbols.  The reference's headers themselves do not travel to the GPU box.
+ZOO_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zoo")
 
 
 class Model:
@@ -37,6 +43,21 @@ class Model:
         h = C.c_void_p()
         L.check(lib, lib.bnm_model_from_blob(blob, len(blob), C.byref(h)), "bnm_model_from_blob")
         return cls(h, lib)
+
+    @classmethod
+    def from_zoo(cls, name, lib=None):
+        """One of the committed zoo models (bitnetmcu_amd/zoo/<name>.bnm); zoo_names() lists them."""
+        with open(os.path.join(ZOO_DIR, name + ".bnm"), "rb") as f:
+            return cls.from_blob(f.read(), lib)
+
+    @staticmethod
+    def zoo_names():
+        return sorted(f[:-4] for f in os.listdir(ZOO_DIR) if f.endswith(".bnm"))
+
+    def to_header_text(self, dialect="exporter"):
+        """BitNetMCU_model.h text of this model in the exporter's dialect (headerwriter.write_header)."""
+        from .headerwriter import write_header
+        return write_header(self, dialect)
 
     def to_blob(self):
         n = self._lib.bnm_model_blob_size(self._h)

@@ -65,3 +65,16 @@ def digest_device(cls, first=0, n_bins=10, stream=None, lib=None):
     L.check(lib, lib.bnm_class_digest_device(cls.data_ptr(), first, cls.numel(), out.data_ptr(), n_bins,
                                              s.cuda_stream), "bnm_class_digest_device")
     return out
+
+
+def stream_read_device(tensor, sink=None, stream=None, lib=None):
+    """Plain 16 B/lane nontemporal read of a cuda tensor's bytes (bnm_stream_read_device): the box's read rate, asynchronous."""
+    import torch
+    lib = lib or L.load()
+    assert tensor.is_cuda and tensor.is_contiguous()
+    if sink is None:
+        sink = torch.zeros(1, dtype=torch.int32, device=tensor.device)
+    s = stream if stream is not None else torch.cuda.current_stream(tensor.device)
+    L.check(lib, lib.bnm_stream_read_device(tensor.data_ptr(), tensor.numel() * tensor.element_size(), sink.data_ptr(), s.cuda_stream),
+            "bnm_stream_read_device")
+    return sink

@@ -257,6 +257,11 @@ BNM_API int bnm_synth_fill_device(int8_t *d_images, uint64_t first, uint64_t cou
 BNM_API int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint64_t n,
                                     uint64_t *d_out, uint32_t n_bins, void *stream);
 
+/* The box's plain read rate: nontemporal 16 B/lane loads of `bytes` bytes at d_src (16-byte aligned), nothing written (d_sink:
+ * one device dword the kernel practically never touches).  bench.py times it over the resident image set next to the inference
+ * kernels: what an HBM-bound kernel can at best approach on the box it runs on. */
+BNM_API int bnm_stream_read_device(const void *d_src, uint64_t bytes, uint32_t *d_sink, void *stream);
+
 /* ---- multi-GPU, single process (C hosts; PyTorch hosts use one process per GPU, see bench.py) ------------------
  * Shards the global synthetic image stream [0, n_total) contiguously over the first n_gpus visible devices
  * (n_gpus <= 0: all), generates every shard on its own GPU, runs the whole-model path on all of them concurrently and

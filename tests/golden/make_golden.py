@@ -6,7 +6,7 @@ Run in the build container (where /root/reference exists):  python tests/golden/
 Outputs (small, committed; consumed on the GPU box where /root/reference does not exist):
   real_images.npz          the reference's 13 embedded MNIST images + labels
                            (BitNetMCU_MNIST_test_data.h:1-190, mcu/BitNetMCUdemo.c:23-28)
-  models/<name>.bnm        BNMBLOB1 form of every model header (parsed by the product loader and
+  ../../bitnetmcu_amd/zoo/<name>.bnm   BNMBLOB1 form of every model header (parsed by the product loader and
                            cross-checked here word-for-word against the DLL's own Lk_weights symbols)
   kat_<name>.npz           per model: inputs, class ids from Inference(), logits and all int8
                            activations from the DLL's own processfclayer/ReLUNorm/conv/pool
@@ -49,13 +49,17 @@ def kat_inputs(real):
                            synth.images(10**8 - 32, 32, DIST_U), edge])
 
 
-def main():
+def main(only=None):
+    """only: model names - (re)generate just those models' blobs and KATs and leave every other fixture untouched"""
     rng = np.random.default_rng(20240421)
     real, labels = real_images()
-    np.savez_compressed(os.path.join(HERE, "real_images.npz"), images=real, labels=labels)
+    if not only:
+        np.savez_compressed(os.path.join(HERE, "real_images.npz"), images=real, labels=labels)
     x = kat_inputs(real)
 
     for name, hdr in REF_MODELS.items():
+        if only and name not in only:
+            continue
         model = Model.from_header(hdr)
         dll = C.CDLL(ref_dll_path(name))
         dll.Inference.restype = C.c_uint32
@@ -68,7 +72,7 @@ def main():
             ct = {4: C.c_uint32, 2: C.c_uint16, 1: C.c_int8}[li.weight_elem_bytes]
             sym = (ct * li.weight_count).in_dll(dll, f"L{li.order}_weights")
             assert np.array_equal(np.ctypeslib.as_array(sym), w), (name, li.order)
-        with open(os.path.join(HERE, "models", name + ".bnm"), "wb") as f:
+        with open(os.path.join(REPO, "bitnetmcu_amd", "zoo", name + ".bnm"), "wb") as f:
             f.write(model.to_blob())
         f_ref = Funcs(dll)
         # Reference defect: the x86 CNN wrapper sizes its scratch `int32_t layer_out[MAX_N_ACTIVATIONS]`
@@ -99,6 +103,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"kat_{name}.npz"), images=x, cls=cls_inf, trace_n=trace_n,
                             logits=np.array(logits, np.int32), acts=np.array(acts, np.int8))
 
+    if only:
+        return
     # ---- per-codec layers ------------------------------------------------------------------------------
     f_ref = Funcs(C.CDLL(ref_dll_path("cnn_64")))   # a CNN build exports all four kernels
     codec = {}
@@ -168,4 +174,4 @@ def main():
 if __name__ == "__main__":
     if not util.have_reference():
         sys.exit("needs /root/reference and oracle/_ref (python oracle/build_oracle.py)")
-    main()
+    main(sys.argv[1:] or None)

@@ -1,58 +1,2 @@
-"""Write a parsed Model back out as BitNetMCU_model.h text in the dialects found in the reference tree, so the
-loader can be tested where /root/reference is absent.  Format reference: exportquant.py:49-263."""
-from bitnetmcu_amd import _lib as L
-
-
-def write_header(model, dialect="exporter", renumber=None):
-    """dialect: 'exporter' (today's writer: 8 words/line, 0x%08x), 'oneline' (mcu/BitNetMCU_model_12k.h:
-    single-line arrays, un-padded hex, MODEL_ define after the guard, embedded /* */ block).
-    renumber: optional list of new Lk orders (e.g. [3,5,7,9])."""
-    layers = model.layers()
-    orders = renumber or [l.order for l in layers]
-    kind = "CNNMNIST" if model.kind == L.KIND_CNN else "FCMNIST"
-    o = ["// Automatically generated header file", "// Date: test", "// Quantized model exported from test.pth",
-         "// Generated by exportquant.py", "", "#include <stdint.h>", ""]
-    if dialect == "oneline":
-        o += ["#ifndef BITNETMCU_MODEL_H", "#define BITNETMCU_MODEL_H", "", f"#define MODEL_{kind}", "",
-              "/*", "Total number of bits: 100864 (12.3125 kbytes)", "#define L99_active   (inside a comment: must be ignored)",
-              "*/", ""]
-    else:
-        o += ["#ifndef BITNETMCU_MODEL_H", "#define BITNETMCU_MODEL_H", "", "// Model class name as defined in models.py",
-              f"#define MODEL_{kind}", ""]
-    o += ["// Number of layers", f"#define NUM_LAYERS {len(layers)}", "", "// Maximum number of activations per layer",
-          "#define MAX_N_ACTIVATIONS 256", ""]
-    for i, (li, k) in enumerate(zip(layers, orders)):
-        p = f"L{k}"
-        w = model.layer_weights(i)
-        if li.type == L.LAYER_FC:
-            o += [f"// Layer: {p}", "// QuantType: test", f"#define {p}_active", f"#define {p}_bitperweight {li.bits_per_weight} ",
-                  f"#define {p}_incoming_weights {li.n_input}", f"#define {p}_outgoing_weights {li.n_output}"]
-            ctype = "uint16_t" if li.weight_elem_bytes == 2 else "uint32_t"
-            if dialect == "oneline":
-                o.append(f"const {ctype} {p}_weights[] = {{" + ", ".join(hex(int(v)) for v in w) + "};")
-                o.append("//first channel is topmost bit")
-            else:
-                fmt = "0x%04x," if li.weight_elem_bytes == 2 else "0x%08x,"
-                per = 10 if li.weight_elem_bytes == 2 else 8
-                o.append(f"const {ctype} {p}_weights[] = {{")
-                for s in range(0, len(w), per):
-                    o.append("\t" + "".join(fmt % int(v) for v in w[s:s + per]))
-                o.append("}; //first channel is topmost bit")
-        elif li.type == L.LAYER_CONV:
-            o += [f"// Layer: {p} (Convolutional)", f"#define {p}_active", f"#define {p}_type BitConv2d",
-                  f"#define {p}_in_channels {li.in_channels}", f"#define {p}_out_channels {li.out_channels}",
-                  f"#define {p}_incoming_x {li.incoming_x}", f"#define {p}_incoming_y {li.incoming_x}",
-                  f"#define {p}_outgoing_x {li.outgoing_x}", f"#define {p}_outgoing_y {li.outgoing_x}",
-                  f"#define {p}_kernel_size {li.kernel_size}", f"#define {p}_stride 1", f"#define {p}_padding 0",
-                  f"#define {p}_groups {li.groups}", f"#define {p}_bitperweight {li.bits_per_weight}",
-                  f"const int8_t {p}_weights[] = {{"]
-            for s in range(0, len(w), 16):
-                o.append("\t" + "".join(f"{int(v)}," for v in w[s:s + 16]))
-            o.append("};")
-        else:
-            o += [f"#define {p}_active", f"#define {p}_type MaxPool2d", f"#define {p}_pool_size {li.pool_size}",
-                  f"#define {p}_incoming_x {li.incoming_x}", f"#define {p}_incoming_y {li.incoming_x}",
-                  f"#define {p}_outgoing_x {li.outgoing_x}", f"#define {p}_outgoing_y {li.outgoing_x}"]
-        o.append("")
-    o.append("#endif")
-    return "\n".join(o) + "\n"
+"""Moved into the package (bitnetmcu_amd/headerwriter.py); kept so that older scripts keep importing."""
+from bitnetmcu_amd.headerwriter import write_header  # noqa: F401

@@ -18,6 +18,24 @@ def test_bench_refuses_to_run_without_gpu(bnm):
     assert "{" not in out.stdout          # no JSON line, no fabricated number
 
 
+def test_bench_gpus_2_starts_two_ranks_itself(bnm):
+    """`python bench.py --gpus 2` without a launcher re-executes under torch.distributed.run with two ranks; without a GPU each
+    rank must refuse - and no JSON line appears (in particular no one-rank number labelled n_gpus 1)."""
+    if bnm.bnm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--images", "1000", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600)
+    text = out.stderr + out.stdout
+    assert out.returncode != 0 and "needs a GPU" in text and "{\"metric\"" not in out.stdout
+    assert "local_rank: 1" in text or "rank      : 1" in text or text.count("needs a GPU") >= 2, text[-1500:]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout) and "{" not in out.stdout
+
+
 def test_product_never_imports_the_oracle():
     """oracle/ is test infrastructure: nothing under bitnetmcu_amd/ or include/ may reference it."""
     bad = []

@@ -47,6 +47,47 @@ def test_in_memory_packing_equals_the_exporters_header(path):
     assert Model.from_header_text(evaluate.header_text(layers)).to_blob() == want
 
 
+def test_record_geometry_fills_the_dicts_as_the_reference_method_does():
+    """export_to_hfile writes Lk_incoming_x ... from the dicts, which the reference's inference_quantized fills in as a
+    side effect (BitNetMCU.py:479-483, 509-513).  evaluate.record_geometry (run by attach / from_quantized_model) must leave the
+    values the reference run left in the fixture."""
+    seen = 0
+    for path in FIXTURES:
+        d, layers = load(path)
+        want = [{k: l.get(k) for k in ("incoming_x", "incoming_y", "outgoing_x", "outgoing_y")} for l in layers]
+        if not any(w["incoming_x"] for w in want):
+            continue
+        for l in layers:
+            for k in ("incoming_x", "incoming_y", "outgoing_x", "outgoing_y"):
+                if k in l:
+                    l[k] = 0
+        evaluate.record_geometry(layers)
+        got = [{k: l.get(k) for k in ("incoming_x", "incoming_y", "outgoing_x", "outgoing_y")} for l in layers]
+        assert got == want, path
+        seen += 1
+    assert seen >= 1, "no CNN fixture with geometry"
+
+
+def test_per_output_scales_raise_a_warning():
+    import warnings
+
+    class Stop(Exception):
+        pass
+
+    _, layers = load(FIXTURES[0])
+    layers[-1]["WScale"] = "PerOutput"
+    orig = evaluate.header_text
+    evaluate.header_text = lambda *a, **k: (_ for _ in ()).throw(Stop())      # stop before anything needs a GPU
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with pytest.raises(Stop):
+                evaluate.QuantizedEvaluator(layers)
+        assert any("PerOutput" in str(x.message) for x in w)
+    finally:
+        evaluate.header_text = orig
+
+
 def test_fixtures_exist():
     assert len(FIXTURES) >= 4
 

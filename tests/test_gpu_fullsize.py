@@ -163,13 +163,14 @@ def _oracle_parallel(model, first, count, dist, threads=None):
     return out
 
 
-def test_million_images_per_distribution_ids_and_logits(gpu_ok, orc):
-    """full compare of class ids AND logits on 10^6 images per distribution."""
+def test_ten_million_images_per_distribution_ids_and_logits(gpu_ok, orc):
+    """SURVEY.md 8(d) asks for a full compare on >= 10^6 images per distribution; this compares 10^7 per distribution id for id
+    against the oracle on the host threads (about 8 s each on 16 threads), so that less rests on the one-off 10^8 digest."""
     from bitnetmcu_amd import DIST_M
     model = util.load_golden_model("fc_4bitsym_64")
     ctx = b.Context(model)
     for dist in (DIST_U, DIST_M):
-        n = 1_000_000
+        n = int(os.environ.get("BNM_IDS_N", "10000000"))
         want = _oracle_parallel(model, 0, n, dist)
         import torch
         xt = torch.empty((n, 256), dtype=torch.int8, device="cuda")

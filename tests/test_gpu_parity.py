@@ -252,13 +252,11 @@ def test_many_launches_on_three_streams(name, path, variant, n, gpu_ok):
         inputs.append((x, want))
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in range(3)]
-    outs = []
+    outs = [(inputs[(k * 7) % 4][1], torch.full((len(inputs[(k * 7) % 4][0]),), -1, dtype=torch.int32, device="cuda")) for k in range(120)]
+    torch.cuda.synchronize()          # the fills ran on the default stream, which the side streams do not wait for
     for k in range(120):
-        x, want = inputs[(k * 7) % 4]
-        got = torch.full((len(x),), -1, dtype=torch.int32, device="cuda")
         with torch.cuda.stream(streams[k % 3]):
-            ctx.infer_device(x, got)
-        outs.append((want, got))
+            ctx.infer_device(inputs[(k * 7) % 4][0], outs[k][1])
     torch.cuda.synchronize()
     for k, (want, got) in enumerate(outs):
         assert torch.equal(want, got), (name, path, variant, k)
@@ -266,6 +264,7 @@ def test_many_launches_on_three_streams(name, path, variant, n, gpu_ok):
     ctx.release_stream(streams[0])
     x, want = inputs[0]
     got = torch.full((len(x),), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     with torch.cuda.stream(streams[0]):
         ctx.infer_device(x, got)
     torch.cuda.synchronize()
@@ -463,13 +462,22 @@ def test_bench_json_contract(gpu_ok):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "i8" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["verified_vs_oracle"] is True and "workload" in d["config"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "frac_of_measured_ceiling", "mfma_busy_frac"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "stream_read", "time_vs_stream_read", "median_launch_ms"):
         assert k in d["roofline"]
+    assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["stream_read"]["GB/s"] > 0
     assert d["digest"].startswith("0x") and "header text" in d["config"]["model_source"]
     ex = d["extra_configs"]
-    for k in ("ternary_alu", "ternary_mfma_generic", "cnn_64", "fc_generic_kernel", "fc_logits", "fc_dist_m"):
+    for k in ("ternary_alu", "ternary_mfma_generic", "cnn_64", "fc_generic_kernel", "fc_logits", "fc_dist_m", "doc12k_binary",
+              "doc12k_ternary", "doc12k_2bit", "doc12k_8bit"):
         assert ex[k]["verified_vs_oracle"] is True and ex[k]["value"] > 0 and "roofline" in ex[k], k
+        assert 0 < ex[k]["roofline"]["frac"] <= 1, k
     assert ex["ternary_alu"]["roofline"]["bound"] == "valu" and ex["cnn_64"]["roofline"]["bound"] == "valu"
+    assert ex["ternary_alu"]["path"] == b.PATH_TERNARY_ALU and ex["ternary_mfma_generic"]["path"] == b.PATH_FUSED_MFMA
+    # the VALU-bound configs quote the ALGORITHMIC fraction (MACs at 4 per dot4 lane), which can only be below the pipe's utilisation
+    assert ex["ternary_alu"]["roofline"]["macs_per_image"] == 43968 and ex["cnn_64"]["roofline"]["macs_per_image"] == 236416
+    for k in ("ternary_alu", "cnn_64"):
+        if "pipe_utilisation" in ex[k]["roofline"]:
+            assert ex[k]["roofline"]["frac"] <= ex[k]["roofline"]["pipe_utilisation"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"]
 
@@ -731,6 +739,53 @@ def test_bench_under_torchrun_single_rank(gpu_ok):
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 1 and d["verified_vs_oracle"] is True and sum(d["class_histogram"]) == 1000000
     assert d["scaling"] == "strong" and d["config"]["global_images"] == 1000000 and "extra_configs" in d
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["dist_backend"] == "nccl"
+
+
+def _bench_json(args, timeout=900):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(util.REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+    assert len(lines) == 1, "ONE JSON line, from rank 0"
+    return json.loads(lines[-1])
+
+
+def test_bench_launches_its_own_ranks_two_ranks_share_the_gpu(gpu_ok):
+    """`python bench.py --gpus 2` WITHOUT a launcher starts two ranks itself.  On the one-GPU test box they share GPU 0 over gloo:
+    the strong split of BASELINE configs[4] - 10^8 images as 2 x 5 x 10^7 contiguous shards generated on their owner, model
+    blob broadcast from rank 0, barriers, MAX-reduced time - and the ALL-REDUCED digest of the two shards' class ids must be the
+    oracle's digest of all 10^8 images."""
+    n = int(os.environ.get("BNM_FULL_N", "100000000"))
+    d = _bench_json(["--gpus", "2", "--dist-backend", "gloo", "--ranks-share-device", "--scaling", "strong", "--images", str(n),
+                     "--steps", "3", "--warmup", "1", "--no-cpu"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_images"] == n
+    assert d["config"]["images_per_gpu"] == n // 2 and d["config"]["dist_backend"] == "gloo" and d["config"]["ranks_share_device"] is True
+    assert d["config"]["rccl_ranks"] is None and "extra_configs" not in d
+    assert d["verified_vs_oracle"] is True and sum(d["class_histogram"]) == n
+    if n == 100_000_000:
+        assert int(d["digest"], 16) == 0x81b56c9fafee6636 == int(d["digest_expected"], 16)
+
+
+def test_bench_gpus_flag_must_match_the_world_size(gpu_ok):
+    """An 8-GPU command may never print a 1-GPU number: bench.py --gpus 2 started as ONE rank by a launcher refuses to run, and
+    --gpus 2 on a box with one visible GPU (RCCL, one rank per GPU) fails loudly instead of printing n_gpus: 1."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    out = subprocess.run([sys.executable, os.path.join(util.REPO, "bench.py"), "--gpus", "2", "--images", "100000", "--steps", "1",
+                          "--warmup", "0", "--no-cpu", "--no-extra"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout) and "{" not in out.stdout
+    import torch
+    if torch.cuda.device_count() == 1:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = subprocess.run([sys.executable, os.path.join(util.REPO, "bench.py"), "--gpus", "2", "--images", "100000", "--steps", "1",
+                              "--warmup", "0", "--no-cpu", "--no-extra"], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode != 0 and "{" not in out.stdout
+        assert "only 1 visible" in (out.stderr + out.stdout)
 
 
 def test_c_abi_multi_gpu_entry_point(gpu_ok, bnm, orc):

@@ -18,7 +18,8 @@ ORACLE_SO = os.path.join(REPO, "oracle", "libbnm_oracle.so")
 REF_OUT = os.path.join(REPO, "oracle", "_ref")
 
 MODEL_NAMES = ["fc_4bitsym_64", "cnn_64", "mcu_12k", "mcu_12k_fp130", "mcu_1k", "mcu_cnn_16", "mcu_cnn_16small",
-               "mcu_cnn_32", "mcu_cnn_48", "mcu_cnn_64", "mcu_cnn_letters", "tern_96", "tern_96_sparse"]
+               "mcu_cnn_32", "mcu_cnn_48", "mcu_cnn_64", "mcu_cnn_letters", "tern_96", "tern_96_sparse",
+               "doc12k_binary", "doc12k_ternary", "doc12k_2bit", "doc12k_8bit"]
 
 _i8p, _u32p, _i32p = C.POINTER(C.c_int8), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
 
@@ -130,68 +131,13 @@ def run_schedule(f, model, image):
     return cls, logits, np.concatenate(acts)
 
 
-def load_oracle():
-    if not os.path.isfile(ORACLE_SO):
-        import subprocess
-        subprocess.check_call([sys.executable, os.path.join(REPO, "oracle", "build_oracle.py"), "--port"])
-    lib = C.CDLL(ORACLE_SO)
-    lib.orc_weight_at.restype = C.c_int32
-    lib.orc_weight_at.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
-    lib.orc_synth.restype = None
-    lib.orc_synth.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
-    lib.orc_class_digest.restype = C.c_uint64
-    lib.orc_class_digest.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32]
-    lib.orc_model_batch.restype = None
-    lib.orc_model_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-    return lib
-
-
-class OrcFcLayer(C.Structure):
-    _fields_ = [("bits_per_weight", C.c_int32), ("n_input", C.c_uint32), ("n_output", C.c_uint32), ("weights", C.c_void_p)]
-
-
-class OrcCnnFront(C.Structure):
-    _fields_ = [("channels", C.c_uint32), ("w_conv1", C.c_void_p), ("w_conv2", C.c_void_p), ("w_conv3", C.c_void_p),
-                ("n_shift", C.c_uint32)]
-
-
-class OracleModel:
-    """A parsed Model bound to the oracle port's batch driver (orc_model_batch)."""
-
-    def __init__(self, model, orc=None):
-        from bitnetmcu_amd import _lib as L
-        self.orc = orc or load_oracle()
-        self.model = model
-        layers = model.layers()
-        self._keep = []
-        fcs = [(i, l) for i, l in enumerate(layers) if l.type == L.LAYER_FC]
-        self.n_layers = len(fcs)
-        self.arr = (OrcFcLayer * len(fcs))()
-        for k, (i, li) in enumerate(fcs):
-            w = model.layer_weights(i)
-            self._keep.append(w)
-            self.arr[k] = OrcFcLayer(li.bits_per_weight, li.n_input, li.n_output, w.ctypes.data)
-        self.front = None
-        if model.kind == L.KIND_CNN:
-            ws = [model.layer_weights(i) for i in (0, 1, 3)]
-            self._keep += ws
-            self.front = OrcCnnFront(layers[0].out_channels, ws[0].ctypes.data, ws[1].ctypes.data, ws[2].ctypes.data, 4)
-        self.n_classes = model.num_classes
-
-    def infer(self, images, logits=False):
-        x = np.ascontiguousarray(images, dtype=np.int8).reshape(-1, 256)
-        n = len(x)
-        cls = np.zeros(n, np.uint32)
-        lg = np.zeros((n, self.n_classes), np.int32)
-        self.orc.orc_model_batch(x.ctypes.data, n, C.byref(self.front) if self.front else None, self.arr, self.n_layers,
-                                 cls.ctypes.data, lg.ctypes.data)
-        return (cls, lg) if logits else cls
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+from checker import load_oracle, OrcFcLayer, OrcCnnFront, OracleModel  # noqa: E402,F401  (the checker lives under oracle/)
 
 
 def load_golden_model(name):
     from bitnetmcu_amd import Model
-    with open(os.path.join(GOLDEN, "models", name + ".bnm"), "rb") as f:
-        return Model.from_blob(f.read())
+    return Model.from_zoo(name)
 
 
 def parse_c_int8_arrays(text):
