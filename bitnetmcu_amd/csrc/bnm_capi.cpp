@@ -416,7 +416,8 @@ int ctx_build(bnm_ctx *c) {
         // fragment image for input rows of kt0 K-steps: per layer, per 32-row tile m: [KT lo fragments][KT hi fragments]
         // fragment image: per layer, per 32-row tile m: [ktp lo fragments][ktp hi fragments]; mt[i] tiles (>= the real
         // count: surplus tiles and K-steps hold zero weights), ktp[i] K-steps; layer i starts at layer_off[i]
-        auto build_frags = [&](const uint32_t *mt, const uint32_t *ktp, const uint32_t *layer_off, uint32_t total, void **out) -> int {
+        // kmajor: the generic kernel's layout - per layer [plane][K-step][tile] (fragment (p, s, m) at ((p * kt + s) * mt + m) KiB)
+        auto build_frags = [&](const uint32_t *mt, const uint32_t *ktp, const uint32_t *layer_off, uint32_t total, bool kmajor, void **out) -> int {
             if (int e = dev_alloc(c, out, total)) return e;
             HIP_TRY(hipMemsetAsync(*out, 0, total, s));
             for (size_t i = 0; i < nfc; i++) {
@@ -432,8 +433,12 @@ int ctx_build(bnm_ctx *c) {
                         const int scale = (sh.dbl && i + 1 < nfc) ? 2 : 1;   // hidden layers only
                         // classifier layer: padding rows weigh -128 so they can never win the argmax (first plane only)
                         const int pad = (i + 1 == nfc && part == 0) ? -128 : 0;
-                        HIP_TRY(bnmk_build_fragments(rows, d.row_stride, rows_left, d.n_real, 1, kt, i == 0 ? 0 : 1, scale, pad,
-                                                     dst + ((size_t)m * kt * sp + (size_t)part * kt) * 1024, s));
+                        if (kmajor)
+                            HIP_TRY(bnmk_build_fragments(rows, d.row_stride, rows_left, d.n_real, 1, kt, i == 0 ? 0 : 1, scale, pad,
+                                                         dst + ((size_t)part * kt * mt[i] + m) * 1024, mt[i] * 1024u, s));
+                        else
+                            HIP_TRY(bnmk_build_fragments(rows, d.row_stride, rows_left, d.n_real, 1, kt, i == 0 ? 0 : 1, scale, pad,
+                                                         dst + ((size_t)m * kt * sp + (size_t)part * kt) * 1024, 1024u, s));
                     }
                 }
             }
@@ -450,7 +455,7 @@ int ctx_build(bnm_ctx *c) {
                     bytes += mt[i] * kt * (uint32_t)sp * 1024u;
                     kt = mt[i];
                 }
-                if (int e = build_frags(mt, ktp, off, bytes, &c->frags)) return e;
+                if (int e = build_frags(mt, ktp, off, bytes, false, &c->frags)) return e;
                 c->table_ok = true;
                 c->variant = var;
             }
@@ -467,7 +472,7 @@ int ctx_build(bnm_ctx *c) {
         uint32_t m_real[4];
         for (size_t i = 0; i < 4; i++) m_real[i] = (uint32_t)sh.M[i];
         if (bnmk_generic_plan(gd, m_real) && bnmk_generic_supported(gd, sh.dbl)) {
-            if (int e = build_frags(gd.M, gd.KTP, gd.frag_off, gd.w_bytes, &c->gfrags)) return e;
+            if (int e = build_frags(gd.M, gd.KTP, gd.frag_off, gd.w_bytes, true, &c->gfrags)) return e;
             c->gdesc = gd;
             c->generic_ok = true;
             if (!c->table_ok) c->variant = BNM_FUSED_GENERIC;
@@ -496,11 +501,15 @@ int ctx_build(bnm_ctx *c) {
 }
 
 // ---- whole-model launches on device data -----------------------------------------------------------
+bool is_generic(int variant) { return variant == BNM_FUSED_GENERIC || variant == BNM_FUSED_GENERIC_T1 || variant == BNM_FUSED_GENERIC_T2; }
+
 int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32_t *d_logits, hipStream_t s) {
     uint32_t *block = nullptr;
     if (int e = work_block(c, s, &block)) return e;
-    if (c->variant == BNM_FUSED_GENERIC) {
-        HIP_TRY(bnmk_fused_generic(c->gdesc, c->shape.dbl, c->grid_blocks, d_in, n, c->gfrags, d_cls, d_logits, block, c->work_batch, s));
+    if (is_generic(c->variant)) {
+        const int tiles = c->variant == BNM_FUSED_GENERIC_T1 ? 1 : c->variant == BNM_FUSED_GENERIC_T2 ? 2 : 0;
+        HIP_TRY(bnmk_fused_generic(c->gdesc, c->shape.dbl, tiles, c->grid_blocks, d_in, n, c->gfrags, d_cls, d_logits, block,
+                                   c->work_batch, s));
         return BNM_OK;
     }
     BnmFusedArgs a{};
@@ -591,7 +600,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
     // CNN: front end (conv/pool/ReLUNorm fused) -> int8 [n][4C] -> FC tail
     const uint32_t W = c->channels * 4u;
     // act rows: 4*C bytes, padded to the generic kernel's row length when that kernel runs the FC tail
-    const uint32_t AS = (path == BNM_PATH_FUSED_MFMA && c->variant == BNM_FUSED_GENERIC) ? c->gdesc.KT0 * 32u : W;
+    const uint32_t AS = (path == BNM_PATH_FUSED_MFMA && is_generic(c->variant)) ? c->gdesc.KT0 * 32u : W;
     // chunks: 2^22 images when the fused tail consumes the act rows directly (1 GiB of act rows; every launch has a ramp and a
     // tail, so fewer, larger launches: +2 % over 2^20), 2^20 when the int32 features are needed as well (> 64 channels, taps)
     // or the layer-wise tail runs (its scratch is sized for kChunk)
@@ -755,7 +764,10 @@ int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
     if (!c) return fail(BNM_EINVAL, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
     if (variant >= 0) {
-        const bool ok = variant == BNM_FUSED_GENERIC ? c->generic_ok : (c->table_ok && bnmk_fused_supported(c->shape, variant));
+        const bool ok = variant == BNM_FUSED_GENERIC ? c->generic_ok
+                        : variant == BNM_FUSED_GENERIC_T1 ? (c->generic_ok && bnmk_generic_tiles(c->gdesc, c->shape.dbl, 1, false) == 1)
+                        : variant == BNM_FUSED_GENERIC_T2 ? (c->generic_ok && bnmk_generic_tiles(c->gdesc, c->shape.dbl, 2, false) == 2)
+                        : (c->table_ok && bnmk_fused_supported(c->shape, variant));
         if (!ok) return fail(BNM_EUNSUPPORTED, "fused kernel variant not available for this model shape");
         c->variant = variant;
     }

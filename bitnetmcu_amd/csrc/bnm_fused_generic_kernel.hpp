@@ -2,16 +2,24 @@
 // layers, any class count <= 256, input rows of 64/128/256/512 bytes, every int8-representable codec plus FP1.3.0's
 // +128 (second weight plane).  gfx950 (CDNA4 / MI355X) only.  Reference semantics: BitNetMCU_inference.c:23-72
 // (ReLUNorm), :88-208 (processfclayer); schedule BitNetMCU_MNIST_dll.c:48-121; widths are free parameters of the
-// reference's model zoo (models.py:62-84).
+// reference's model zoo (models.py:62-84; the documented 12 KB family docs/documentation.md:169-183).
 //
 // Same formulation as bnm_fused_fc.hip (Y^T = W * X^T on v_mfma_i32_32x32x32_i8, ReLUNorm output packed straight into
-// the next layer's B operand) with two differences that remove the per-shape instantiation table:
+// the next layer's B operand).  What makes it shape-free:
 //   * the weight fragments live in LDS (one copy per workgroup = per CU, staged once per launch) and are read as A
-//     operands with lane-linear ds_read_b128 — no weight VGPRs, so no shape can spill, and the layer widths are
-//     RUN-TIME values: per layer the kernel switches once on the K-step count and branches (wave-uniformly) per 32-row
-//     output tile; only the upper bound MMAX of tiles per layer is a compile-time parameter (2 / 4 / 8);
-//   * one 32-image tile buffer per wave: the tile's B operands are read into VGPRs and the buffer is refilled with the
-//     wave's next tile by LDS-DMA at once, so the load is in flight for the whole of the tile's arithmetic.
+//     operands with lane-linear ds_read_b128 - no weight VGPRs, so no shape can spill;
+//   * the layer widths are RUN-TIME values and nothing is padded: a layer of M 32-row tiles over K K-steps executes exactly
+//     M*K MFMAs and its fragment image holds exactly M*K KiB.  Per layer the kernel switches (wave-uniformly) on the tile
+//     count M - inside a case every accumulator index is a compile-time constant - and walks the K-steps in source order
+//     with an early exit behind each one (K-steps are compile-time positions, so the packed activations stay in registers).
+//     The fragments of a layer are stored K-step major ([plane][K-step][tile]): with M fixed inside a case, every fragment
+//     address is the lane's base plus an immediate offset.  Only the upper bound MMAX of tiles per layer (2 / 4 / 8) is a
+//     template parameter: it sizes the register arrays;
+//   * T = 1 or 2 image tiles per wave per iteration.  With T = 2 every fragment read from LDS feeds TWO MFMAs (one per
+//     tile): half the LDS traffic per image - at one fragment read per MFMA the matrix cores of a CU ask the LDS for exactly
+//     its peak 128 B per clock - and two independent dependency chains inside a wave;
+//   * the tile buffers are refilled with the wave's next unit by LDS-DMA as soon as the layer-1 B operands sit in registers,
+//     so the load is in flight for the whole of the unit's arithmetic.
 // LDS image of a tile: row r (image) at r*ROW, 16-byte slot c' holds global slot c = c' ^ mask(r) with
 // mask(r) = (r >> (4-p)) & (S-1) for S = ROW/16 = 2^p slots per row (p <= 4) and r & 15 for p = 5: the ds_read_b128
 // lane groups (MI355X_MICROARCH.md, LDS table) then hit 16 distinct 16-byte bank groups for every supported ROW.  The
@@ -63,6 +71,9 @@ BNM_DEVICE void dma_group1(uint32_t lds_, const int8_t *base_, uint32_t v0) {
 // before overwriting a buffer: this wave's own ds_reads of it must have returned (hipcc only waits before the USE of
 // a ds_read's result); the s_nop covers a VALU-written SGPR feeding M0
 BNM_DEVICE void retire_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 4" ::: "memory"); }
+// a point no memory operation may be moved across by the compiler (no instruction is emitted): keeps a fragment read that is
+// issued ahead of a branch from being sunk into the block that uses it
+BNM_DEVICE void pin_memory_order() { asm volatile("" ::: "memory"); }
 
 template <int ROW>
 struct RowGeom {
@@ -72,31 +83,29 @@ struct RowGeom {
     static constexpr int TILE = 32 * ROW;
     static constexpr int PIECES = TILE / 1024;
     static constexpr int ROWS_PER_PIECE = 1024 / ROW;
+    // distinct per-piece source offsets: xmask() below has this period
+    static constexpr int NV = ROW == 64 ? 1 : ROW == 128 ? 2 : ROW == 256 ? 4 : 8;
     BNM_DEVICE static uint32_t mask(uint32_t r) { return P == 5 ? (r & 15u) : ((r >> (4 - P)) & (uint32_t)(SLOTS - 1)); }
     // what piece t XORs into the lane's piece-relative source offset (see the derivation in DESIGN.md §4.1b)
     static constexpr uint32_t xmask(int t) { return P == 5 ? ((32u * t) & 0xF0u) : ((64u * t) & (uint32_t)(ROW - 16)); }
 };
 
-// ---- layer blocks --------------------------------------------------------------------------------------------
-// A layer is executed by ONE straight-line block chosen by a wave-uniform switch on its run-time tile count M (and on the
-// padded K-step count KT): inside a block every accumulator index is a compile-time constant and the accumulators do not
-// outlive it — only the packed int8 outputs (4 registers per tile) cross block boundaries.  (A first version branched per
-// tile around updates of one shared accumulator array: hipcc answered with accumulator copies and spills.)
-// A fragment (m, part, s) of a layer sits at off + ((m*SP + part)*KT + s) KiB of the LDS weight image, lane-linear; K-steps
-// past the previous layer's real tile count hold zero weights, so whatever the matching B registers contain is harmless.
-// The MFMA stream of (part of) a layer: items (part p, K-step s, tile m), K-step outermost so that consecutive MFMAs go to
-// DIFFERENT accumulators (no dependent-accumulator stalls), fragment reads issued DEPTH items ahead of their MFMA in source
-// order — hipcc keeps that order, whereas left to itself it put every ds_read directly in front of its MFMA and paid the
-// full LDS latency fifty times per tile.  The fragment of (m, p, K-step s0+s) sits at a + ((m*SP + p)*KSTRIDE + s)*1024.
-template <int MT, int NS, int KSTRIDE, int SP, bool INIT, int NB>
-BNM_DEVICE void mma_stream(const char *a, const i32x4 (&b)[NB], i32x16 (&acc)[MT]) {
-    static_assert(NS <= NB, "operand array too short");
+// ---- MFMA streams ------------------------------------------------------------------------------------------------
+// Items are (plane p, K-step s, tile m), K-step outermost inside a plane so that consecutive MFMAs go to DIFFERENT
+// accumulators (no dependent-accumulator stalls); every item reads ONE fragment and issues T MFMAs (one per image tile of the
+// wave).  Fragment reads are issued DEPTH items ahead of their MFMAs in source order and the order is pinned with
+// sched_group_barrier - left to itself hipcc put every ds_read directly in front of its MFMA and paid the full LDS latency per
+// item.  Fragment (p, s, m) of a layer with MT tiles and KTOT K-steps sits at ((p*KTOT + s)*MT + m) KiB, lane-linear.
+
+// layer 1 (or a chunk of its K-steps): NS compile-time K-steps S0 .. S0+NS-1 of KTOT
+template <int MT, int NS, int S0, int KTOT, int SP, bool INIT, int T>
+BNM_DEVICE void mma_l1(const char *a, const i32x4 (&b)[T][NS], i32x16 (&acc)[T][MT]) {
     constexpr int N = SP * NS * MT;
     constexpr int DEPTH = N < 4 ? N : 4;
     auto frag = [&](auto I) -> i32x4 {
         constexpr int i = decltype(I)::value;
         constexpr int pp = i / (NS * MT), ss = (i % (NS * MT)) / MT, mm = i % MT;
-        return *(const i32x4 *)(a + ((mm * SP + pp) * KSTRIDE + ss) * 1024);
+        return *(const i32x4 *)(a + ((pp * KTOT + S0 + ss) * MT + mm) * 1024);
     };
     __builtin_amdgcn_sched_barrier(0);      // the stream is its own scheduling region
     i32x4 ring[DEPTH];
@@ -104,74 +113,111 @@ BNM_DEVICE void mma_stream(const char *a, const i32x4 (&b)[NB], i32x16 (&acc)[MT
     static_for<0, N>([&](auto I) {
         constexpr int i = decltype(I)::value;
         constexpr int pp = i / (NS * MT), ss = (i % (NS * MT)) / MT, mm = i % MT;
-        const i32x16 c = (INIT && pp == 0 && ss == 0) ? zero16() : acc[mm];
-        acc[mm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[i % DEPTH], b[ss], c, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const i32x16 c = (INIT && pp == 0 && ss == 0) ? zero16() : acc[t][mm];
+            acc[t][mm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[i % DEPTH], b[t][ss], c, 0, 0, 0);
+        }
         if constexpr (i + DEPTH < N) ring[i % DEPTH] = frag(std::integral_constant<int, i + DEPTH>{});
     });
-    // pin the issue order: DEPTH fragment reads, then { one MFMA, one read } pairs (0x100 = DS read, 0x008 = MFMA)
+    // pin the issue order: DEPTH fragment reads, then { T MFMAs, one read } groups (0x100 = DS read, 0x008 = MFMA)
     __builtin_amdgcn_sched_group_barrier(0x100, DEPTH, 0);
     static_for<0, N>([&](auto I) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
         if constexpr (decltype(I)::value + DEPTH < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     });
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MT, int KT, int SP, int NB>
-BNM_DEVICE void block_mma(const char *smem, uint32_t lane16, uint32_t off, const i32x4 (&b)[NB], i32x16 (&acc)[MT]) {
-    mma_stream<MT, KT, KT, SP, true, NB>(smem + (off + lane16), b, acc);
+// layers 2..4, one plane: K (run-time, 1 .. MMAX) K-steps.  K-step S is a compile-time position (its B operands are the
+// registers in[.][S]); behind every K-step the chain leaves when K is reached.  The ring is primed by the caller; reads run
+// DEPTH items ahead across the exits (an exit drops at most DEPTH reads of fragments that exist but are not needed - or of
+// whatever follows the layer's last fragment in LDS: the next layer's fragments or the tile buffers, never out of bounds).
+template <int S, int MT, int T, int MMAX, int DEPTH, bool INIT>
+BNM_DEVICE void hidden_steps(const char *a, uint32_t K, const i32x4 (&in)[T][MMAX], i32x16 (&acc)[T][MT], i32x4 (&ring)[DEPTH]) {
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, MT>([&](auto MI) {
+        constexpr int m = decltype(MI)::value, i = S * MT + m;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const i32x16 c = (INIT && S == 0) ? zero16() : acc[t][m];
+            acc[t][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[i % DEPTH], in[t][S], c, 0, 0, 0);
+        }
+        if constexpr (i + DEPTH < MMAX * MT) ring[i % DEPTH] = *(const i32x4 *)(a + (i + DEPTH) * 1024);
+    });
+    static_for<0, MT>([&](auto MI) {
+        __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
+        if constexpr (S * MT + decltype(MI)::value + DEPTH < MMAX * MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    pin_memory_order();
+    if constexpr (S + 1 < MMAX) {
+        if (K > (uint32_t)(S + 1)) hidden_steps<S + 1, MT, T, MMAX, DEPTH, INIT>(a, K, in, acc, ring);
+    }
 }
 
-// K-step count a layer's fragments are padded to, given the previous layer's tile count
-template <int MMAX>
-constexpr int kpad(int m_prev) { return MMAX == 2 ? 2 : (m_prev <= MMAX / 2 ? MMAX / 2 : MMAX); }
+template <int MT, int SP, int T, int MMAX>
+BNM_DEVICE void hidden_mma(const char *a, uint32_t K, const i32x4 (&in)[T][MMAX], i32x16 (&acc)[T][MT]) {
+    constexpr int DEPTH = MMAX * MT < 4 ? MMAX * MT : 4;
+    static_for<0, SP>([&](auto PI) {
+        constexpr int p = decltype(PI)::value;
+        const char *ap = a;
+        if constexpr (p == 1) ap = a + K * (uint32_t)(MT * 1024);      // the second plane follows the first one's K*MT fragments
+        i32x4 ring[DEPTH];
+        static_for<0, DEPTH>([&](auto I) { ring[decltype(I)::value] = *(const i32x4 *)(ap + decltype(I)::value * 1024); });
+        hidden_steps<0, MT, T, MMAX, DEPTH, p == 0>(ap, K, in, acc, ring);
+    });
+}
 
-// hidden layer: MFMAs + ReLUNorm, in -> out
-template <int MMAX, int SP, bool DBL>
-BNM_DEVICE void hidden_layer(const char *smem, uint32_t lane16, uint32_t off, uint32_t M, uint32_t KTP, const i32x4 (&in)[MMAX],
-                             i32x4 (&out)[MMAX], int h) {
-    constexpr int MSTEP = MMAX == 8 ? 2 : 1;     // 8-tile class: tile counts are rounded up to even (zero fragments)
-    static_for<1, MMAX / MSTEP + 1>([&](auto MI) {
-        constexpr int mt = decltype(MI)::value * MSTEP;
-        static_for<0, (MMAX == 2 ? 1 : 2)>([&](auto KI) {
-            constexpr int kt = MMAX == 2 ? 2 : (decltype(KI)::value == 0 ? MMAX / 2 : MMAX);
-            if (M == (uint32_t)mt && KTP == (uint32_t)kt) {
-                i32x16 acc[mt];
-                block_mma<mt, kt, SP, MMAX>(smem, lane16, off, in, acc);
-                relunorm_pack<mt, DBL, MMAX>(acc, out, h);
+// hidden layer: MFMAs + ReLUNorm, in -> out (M tiles, K K-steps, both run-time)
+template <int MMAX, int SP, bool DBL, int T>
+BNM_DEVICE void hidden_layer(const char *smem, uint32_t lane16, uint32_t off, uint32_t M, uint32_t K, const i32x4 (&in)[T][MMAX],
+                             i32x4 (&out)[T][MMAX], int h) {
+    static_for<1, MMAX + 1>([&](auto MI) {
+        constexpr int mt = decltype(MI)::value;
+        if (M == (uint32_t)mt) {
+            i32x16 acc[T][mt];
+            hidden_mma<mt, SP, T, MMAX>(smem + (off + lane16), K, in, acc);
 #pragma unroll
-                for (int m = mt; m < MMAX; m++) out[m] = i32x4{0, 0, 0, 0};     // K-steps past the real tiles: zero weights meet zeros
-            }
-        });
+            for (int t = 0; t < T; t++) relunorm_pack<mt, DBL, MMAX>(acc[t], out[t], h);
+        }
     });
 }
 
 // classifier layer: MFMAs + first-maximum argmax (+ logits)
-template <int MMAX, int SP>
-BNM_DEVICE uint32_t final_layer(const char *smem, uint32_t lane16, uint32_t off, uint32_t M, uint32_t KTP, const i32x4 (&in)[MMAX],
-                                int h, int32_t *logits_row, uint32_t n_classes) {
-    constexpr int MSTEP = MMAX == 8 ? 2 : 1;
-    uint32_t cls = 0;
-    static_for<1, MMAX / MSTEP + 1>([&](auto MI) {
-        constexpr int mt = decltype(MI)::value * MSTEP;
-        static_for<0, (MMAX == 2 ? 1 : 2)>([&](auto KI) {
-            constexpr int kt = MMAX == 2 ? 2 : (decltype(KI)::value == 0 ? MMAX / 2 : MMAX);
-            if (M == (uint32_t)mt && KTP == (uint32_t)kt) {
-                i32x16 acc[mt];
-                block_mma<mt, kt, SP, MMAX>(smem, lane16, off, in, acc);
-                cls = argmax_rows<mt, 0>(acc, h);
-                if (logits_row) store_logits<mt>(acc, logits_row, h, n_classes);
+template <int MMAX, int SP, int T>
+BNM_DEVICE void final_layer(const char *smem, uint32_t lane16, uint32_t off, uint32_t M, uint32_t K, const i32x4 (&in)[T][MMAX], int h,
+                            int j, int lane, uint32_t (&cls)[T], int32_t *logits_out, int32_t *stage, uint64_t first_img, uint64_t n,
+                            uint32_t n_classes) {
+    static_for<1, MMAX + 1>([&](auto MI) {
+        constexpr int mt = decltype(MI)::value;
+        if (M == (uint32_t)mt) {
+            i32x16 acc[T][mt];
+            hidden_mma<mt, SP, T, MMAX>(smem + (off + lane16), K, in, acc);
+#pragma unroll
+            for (int t = 0; t < T; t++) cls[t] = argmax_rows<mt, 0>(acc[t], h);
+            if (logits_out) {
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const uint64_t tile_first = first_img + 32ull * (uint64_t)t;
+                    if (tile_first >= n) continue;
+                    int32_t *tile_dst = logits_out + tile_first * n_classes;
+                    if (stage != nullptr && tile_first + 32ull <= n) {
+                        // a whole tile through the staging area: contiguous nontemporal 16 B/lane stores, every line written whole
+                        store_logits_tile<mt, 0, 0>(acc[t], stage, tile_dst, j, h, lane, n_classes);
+                    } else if (tile_first + (uint64_t)j < n) {
+                        store_logits<mt>(acc[t], tile_dst + (uint32_t)j * n_classes, h, n_classes);
+                    }
+                }
             }
-        });
+        }
     });
-    return cls;
 }
 
 }  // namespace
 
 // WPS: waves per SIMD the register budget is compiled for (the workgroup holds up to 4*WPS waves, ONE workgroup per CU).
-// The descriptor's M[] are the tile counts the fragment image was BUILT for (already rounded as the class requires).
-template <int MMAX, int KT0, int SP, bool DBL, int WPS>
+template <int MMAX, int KT0, int SP, bool DBL, int T, int WPS>
 __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                      const i32x4 *__restrict__ frags, BnmGenericDesc d,
                                                                      uint32_t *__restrict__ cls_out,
@@ -180,8 +226,11 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
     using G = RowGeom<32 * KT0>;
     const uint32_t batch = batch_arg & 0xFFFFu;
     constexpr int ROW = 32 * KT0;
-    constexpr int KC = KT0 < 8 ? KT0 : 8;          // layer-1 K-steps held in VGPRs at a time
-    constexpr int MSTEP = MMAX == 8 ? 2 : 1;
+    // layer-1 K-steps whose B operands are held in VGPRs at a time (x T tiles x 4 registers): all of a 256-byte row with one
+    // tile per wave, half of it with two (the refill then starts after the first half's MFMAs)
+    constexpr int KC = KT0 * T <= 8 ? KT0 : 8 / T;
+    constexpr int UNIT = T * G::TILE;              // bytes of the T consecutive tiles a wave handles per iteration
+    static_assert(T == 1 || T == 2, "one or two tiles per wave");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -191,139 +240,167 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
     for (uint32_t o = threadIdx.x * 16u; o < d.w_bytes; o += blockDim.x * 16u) *(i32x4 *)(smem + o) = frags[o >> 4];
     __syncthreads();
 
-    const uint32_t tile_off = d.w_bytes + wave * (uint32_t)G::TILE;                    // this wave's tile buffer
+    const uint32_t tile_off = d.w_bytes + wave * (uint32_t)UNIT;                       // this wave's T tile buffers
     const uint32_t tile_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + tile_off;
-    // DMA piece t, lane l: LDS byte 1024t + 16l = row t*RPP + rl, slot c'; source slot c = c' ^ mask(row)
-    // B operand of K-step s: image j, global slot 2s+h -> LDS slot (2s+h) ^ mask(j): XOR 32*s into the byte offset (rd_off)
+    // logits staging area of the wave (2 KiB behind all tile buffers) when the launcher reserved one
+    int32_t *const stage = d.stage ? (int32_t *)(smem + d.w_bytes + nwaves * (uint32_t)UNIT + wave * 2048u) : nullptr;
+
+    // Lane constants that stay in registers across the persistent loop: the lane id and the NV distinct DMA source offsets
+    // (DMA piece t, lane l: LDS byte 1024t + 16l = row t*RPP + rl, slot c'; source slot c = c' ^ mask(row)).  Everything else
+    // per-lane is re-derived per iteration from an opaque copy of the lane id (half a dozen VALU): left to itself hipcc hoists
+    // dozens of derived operand / fragment addresses out of the loop and spills them.
+    uint32_t voff[G::NV];
+    {
+        const uint32_t rl0 = (16u * (uint32_t)lane) / (uint32_t)ROW, cs0 = (uint32_t)lane & (uint32_t)(G::SLOTS - 1);
+#pragma unroll
+        for (int k = 0; k < G::NV; k++) voff[k] = (rl0 * (uint32_t)ROW + 16u * (cs0 ^ G::mask(rl0))) ^ G::xmask(k);
+    }
 
     const uint32_t n_tiles = (uint32_t)((n + 31ull) >> 5);       // the launcher refuses n >= 2^36
-    // (the per-use copies below keep hipcc from hoisting dozens of derived per-piece / per-K-step address registers out of
-    // the persistent loop, where they would only raise the register pressure of the arithmetic)
-    auto dma_tile = [&](uint32_t t) {
-        const int8_t *base = images + (uint64_t)t * (uint64_t)G::TILE;
-        const uint64_t first = (uint64_t)t << 5;
-        uint32_t l = (uint32_t)lane;
-        asm volatile("" : "+v"(l));
-        const uint32_t rl = (16u * l) / (uint32_t)ROW, cs = l & (uint32_t)(G::SLOTS - 1);
-        if (first + 32ull <= n) {
-            const uint32_t voff0 = rl * (uint32_t)ROW + 16u * (cs ^ G::mask(rl));
-            static_for<0, (G::PIECES + 3) / 4>([&](auto GI) {
-                constexpr int g = decltype(GI)::value, t0 = 4 * g;
-                if constexpr (G::PIECES - t0 >= 4)
-                    dma_group4(tile_lds + 1024u * t0, base + 1024 * t0, voff0 ^ G::xmask(t0), voff0 ^ G::xmask(t0 + 1),
-                               voff0 ^ G::xmask(t0 + 2), voff0 ^ G::xmask(t0 + 3));
-                else if constexpr (G::PIECES - t0 == 2)
-                    dma_group2(tile_lds + 1024u * t0, base + 1024 * t0, voff0 ^ G::xmask(t0), voff0 ^ G::xmask(t0 + 1));
+    const uint32_t n_units = (n_tiles + (uint32_t)(T - 1)) / (uint32_t)T;
+    auto dma_unit = [&](uint32_t u) {
+        const int8_t *base = images + (uint64_t)u * (uint64_t)UNIT;
+        const uint64_t first = (uint64_t)u * (uint64_t)(32 * T);
+        if (first + (uint64_t)(32 * T) <= n) {
+            constexpr int NP = T * G::PIECES;
+            static_for<0, (NP + 3) / 4>([&](auto GI) {
+                constexpr int t0 = 4 * decltype(GI)::value;
+                if constexpr (NP - t0 >= 4)
+                    dma_group4(tile_lds + 1024u * t0, base + 1024 * t0, voff[t0 % G::NV], voff[(t0 + 1) % G::NV], voff[(t0 + 2) % G::NV],
+                               voff[(t0 + 3) % G::NV]);
+                else if constexpr (NP - t0 == 2)
+                    dma_group2(tile_lds + 1024u * t0, base + 1024 * t0, voff[t0 % G::NV], voff[(t0 + 1) % G::NV]);
                 else
-                    dma_group1(tile_lds + 1024u * t0, base + 1024 * t0, voff0 ^ G::xmask(t0));
+                    dma_group1(tile_lds + 1024u * t0, base + 1024 * t0, voff[t0 % G::NV]);
             });
         } else {
-            // ragged last tile: rows past the end re-read the last valid image (never out of bounds)
-            const uint32_t nv = (uint32_t)(n - first);
-            static_for<0, G::PIECES>([&](auto TI) {
+            // ragged end: rows past the last image re-read it (never out of bounds); a tile wholly past the end reads the last
+            // image 32 times and stores nothing
+            const uint32_t nv = (uint32_t)(n - first);                                 // valid rows from `first` on (1 .. 32 T - 1)
+            uint32_t l = (uint32_t)lane;
+            asm volatile("" : "+v"(l));
+            const uint32_t rl = (16u * l) / (uint32_t)ROW, cs = l & (uint32_t)(G::SLOTS - 1);
+            static_for<0, T * G::PIECES>([&](auto TI) {
                 constexpr int tt = decltype(TI)::value;
-                const uint32_t r = (uint32_t)(tt * G::ROWS_PER_PIECE) + rl;
+                const uint32_t r = (uint32_t)(tt * G::ROWS_PER_PIECE) + rl;            // row within the unit
                 const uint32_t src = r < nv ? r : nv - 1u;
-                dma_group1(tile_lds + 1024u * tt, base, src * (uint32_t)ROW + 16u * (cs ^ G::mask(r)));
+                dma_group1(tile_lds + 1024u * tt, base, src * (uint32_t)ROW + 16u * (cs ^ G::mask(r & 31u)));
             });
         }
     };
 
-    // ---- tiles in batches of `batch` consecutive ones: a wave's first batch is static, every later one comes from the
-    // device-wide counter (work_take_*; the wave that runs out of batch asks while it still has one tile to go)
+    // ---- units in batches of `batch` consecutive ones: a wave's first batch is static, every later one comes from the
+    // device-wide counter (work_take_*; the wave that runs out of batch asks while it still has one unit to go).
     // The counter is split into `words` words (upper half of the argument: 8 when the wave count is a multiple of 8, else 1):
     // wave w takes from word w % words, which hands out the batches g = t * words + w % words - every word is shared by waves
     // of all CUs, so the balance stays device-wide while a word sees an eighth of the takes (work distribution).
     const uint32_t total_waves = gridDim.x * nwaves, wave_id = blockIdx.x * nwaves + wave;
     const uint32_t words = batch_arg >> 16, wshift = (uint32_t)__builtin_ctz(words | 0x100u);
     const uint32_t my_word = wave_id & (words - 1u), first_dyn = total_waves >> wshift;
-    uint32_t tile = wave_id * batch, left = batch - 1u;      // `left`: tiles of the batch after this one
+    uint32_t unit = wave_id * batch, left = batch - 1u;      // `left`: units of the batch after this one
     uint32_t taken = 0;
-    if (tile < n_tiles) dma_tile(tile);
+    if (unit < n_units) dma_unit(unit);
 
     const uint32_t M1 = d.M[0], M2 = d.M[1], M3 = d.M[2], M4 = d.M[3];
-    const uint32_t K2 = d.KTP[1], K3 = d.KTP[2], K4 = d.KTP[3];
-    while (tile < n_tiles) {
+    // Class ids leave one iteration LATE, right behind the refill: the loop's top waits for vmcnt(0) (the tile), and a store
+    // issued at the end of the body would make that wait sit on its write acknowledgement every iteration.  Every class word is
+    // written exactly once (bnm_infer_host's latency path polls them), so the first iteration stores nothing.
+    uint32_t cls_prev = 0, unit_prev = 0;
+    bool pend = false;
+    auto flush_cls = [&]() {
+        if (!pend) return;
+        // T = 2: lanes 0..31 hold tile 0's ids, lanes 32..63 tile 1's - one 256-byte store per unit; T = 1: the lower half stores
+        uint32_t l = (uint32_t)lane;
+        asm volatile("" : "+v"(l));
+        const uint64_t img = (uint64_t)unit_prev * (uint64_t)(32 * T) + (uint64_t)(T == 2 ? l : (l & 31u));
+        if (img < n && (T == 2 || l < 32u)) __builtin_nontemporal_store(cls_prev, cls_out + img);
+    };
+    while (unit < n_units) {
         if (left == 0u) work_take_issue(taken, counter + 16u * my_word, 1u);
         bnm_wait_vmcnt<0>();
-        // every per-lane quantity of the iteration is re-derived from this copy of the lane id (a handful of VALU per tile):
-        // nothing but the lane id itself stays live across iterations, and hipcc cannot hoist derived addresses
+        uint32_t next_unit = unit + 1u, next_left = left - 1u;
         uint32_t lv = (uint32_t)lane;
         asm volatile("" : "+v"(lv));
-        uint32_t next_tile = tile + 1u, next_left = left - 1u;
         const int j = (int)(lv & 31u), h = (int)(lv >> 5);
-        const uint32_t lane16 = 16u * lv;
-        const uint32_t rd_off = tile_off + (uint32_t)j * (uint32_t)ROW + 16u * ((uint32_t)h ^ G::mask((uint32_t)j));
-        i32x4 pa[MMAX], pb[MMAX];       // packed layer outputs = the next layer's B operands
-        // ---- layer 1: B operands from the tile buffer, KC K-steps at a time; the buffer is refilled with the wave's
-        // next tile as soon as its last operand has been read (the load is then in flight for the rest of the tile)
-        static_for<1, MMAX / MSTEP + 1>([&](auto MI) {
-            constexpr int mt = decltype(MI)::value * MSTEP;
+        const uint32_t l16 = 16u * lv;
+        // B operand of K-step s: image j, global slot 2s+h -> LDS slot (2s+h) ^ mask(j): XOR 32*s into the byte offset
+        const uint32_t rd = tile_off + (uint32_t)j * (uint32_t)ROW + 16u * ((uint32_t)h ^ G::mask((uint32_t)j));
+        i32x4 pa[T][MMAX], pb[T][MMAX];       // packed layer outputs = the next layer's B operands
+        // ---- layer 1: B operands from the tile buffers, KC K-steps at a time; the buffers are refilled with the wave's
+        // next unit as soon as the last operand has been read (the load is then in flight for the rest of the iteration)
+        static_for<1, MMAX + 1>([&](auto MI) {
+            constexpr int mt = decltype(MI)::value;
             if (M1 == (uint32_t)mt) {
-                i32x16 acc[mt];
+                i32x16 acc[T][mt];
                 static_for<0, KT0 / KC>([&](auto CI) {
                     constexpr int ch = decltype(CI)::value;
-                    i32x4 b0[KC];
+                    i32x4 b0[T][KC];
 #pragma unroll
-                    for (int s = 0; s < KC; s++) b0[s] = *(const i32x4 *)(smem + (rd_off ^ (32u * (uint32_t)(ch * KC + s))));
+                    for (int t = 0; t < T; t++)
+#pragma unroll
+                        for (int s = 0; s < KC; s++)
+                            b0[t][s] = *(const i32x4 *)(smem + ((rd + (uint32_t)(t * G::TILE)) ^ (32u * (uint32_t)(ch * KC + s))));
                     if constexpr (ch == KT0 / KC - 1) {
                         retire_lds_reads();
                         if (left == 0u) {
                             work_take_wait(taken);
-                            next_tile = (((first_dyn + taken) << wshift) + my_word) * batch;
+                            next_unit = (((first_dyn + taken) << wshift) + my_word) * batch;
                             next_left = batch - 1u;
                         }
-                        if (next_tile < n_tiles) dma_tile(next_tile);
+                        if (next_unit < n_units) dma_unit(next_unit);
+                        flush_cls();
                     }
-                    mma_stream<mt, KC, KT0, SP, ch == 0, KC>(smem + (d.frag_off[0] + (uint32_t)(ch * KC * 1024) + lane16), b0, acc);
+                    mma_l1<mt, KC, ch * KC, KT0, SP, ch == 0, T>(smem + (d.frag_off[0] + l16), b0, acc);
                 });
-                relunorm_pack<mt, DBL, MMAX>(acc, pa, h);
 #pragma unroll
-                for (int m = mt; m < MMAX; m++) pa[m] = i32x4{0, 0, 0, 0};
+                for (int t = 0; t < T; t++) relunorm_pack<mt, DBL, MMAX>(acc[t], pa[t], h);
             }
         });
-        hidden_layer<MMAX, SP, DBL>(smem, lane16, d.frag_off[1], M2, K2, pa, pb, h);
-        const uint64_t img = ((uint64_t)tile << 5) + (uint64_t)j;
-        int32_t *lrow = (logits_out && img < n) ? logits_out + img * d.n_classes : nullptr;
-        // per-iteration copy: keeps the (row < n_classes) predicates of every accumulator register of every block from being
+        hidden_layer<MMAX, SP, DBL, T>(smem, l16, d.frag_off[1], M2, M1, pa, pb, h);
+        const uint64_t first_img = (uint64_t)unit * (uint64_t)(32 * T);
+        // per-iteration copy: keeps the (row < n_classes) predicates of every accumulator register of every case from being
         // hoisted out of the persistent loop as hundreds of live 64-bit masks
         uint32_t nc = d.n_classes;
         asm volatile("" : "+v"(nc));
-        uint32_t cls;
+        uint32_t cls[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) cls[t] = 0;
         if (M4) {
-            hidden_layer<MMAX, SP, DBL>(smem, lane16, d.frag_off[2], M3, K3, pb, pa, h);
-            cls = final_layer<MMAX, SP>(smem, lane16, d.frag_off[3], M4, K4, pa, h, lrow, nc);
+            hidden_layer<MMAX, SP, DBL, T>(smem, l16, d.frag_off[2], M3, M2, pb, pa, h);
+            final_layer<MMAX, SP, T>(smem, l16, d.frag_off[3], M4, M3, pa, h, j, lane, cls, logits_out, stage, first_img, n, nc);
         } else {
-            cls = final_layer<MMAX, SP>(smem, lane16, d.frag_off[2], M3, K3, pb, h, lrow, nc);
+            final_layer<MMAX, SP, T>(smem, l16, d.frag_off[2], M3, M2, pb, h, j, lane, cls, logits_out, stage, first_img, n, nc);
         }
-#ifdef BNM_EXPERIMENT_PLAIN_CLASS_STORE
-        if (h == 0 && img < n) cls_out[img] = cls;
-#else
-        if (h == 0 && img < n) __builtin_nontemporal_store(cls, cls_out + img);   // see bnm_fused_fc.hip's dual kernel
-#endif
-        tile = next_tile;
+        // both halves of the wave hold every tile's result: T = 2 keeps tile 0's ids in lanes 0..31 and tile 1's in lanes 32..63
+        // (one 256-byte store per unit), T = 1 stores from the lower half
+        if constexpr (T == 2) cls_prev = h ? cls[1] : cls[0];   // (h: this iteration's copy)
+        else cls_prev = cls[0];
+        unit_prev = unit;
+        pend = true;
+        unit = next_unit;
         left = next_left;
     }
+    flush_cls();
     bnm_wait_vmcnt<0>();   // no LDS-DMA may outlive the workgroup's LDS allocation
     work_block_leave_s(counter, total_waves);   // the last wave to leave puts the counter block back to all-zero
 }
 
-// ---- per-class launcher: each tile class is its own translation unit (bnm_fused_generic_m{2,4,8}.hip) so that the
-// classes compile side by side.  Instantiations per (class, row length): doubled hidden weights; plain; plain with
-// FP1.3.0's second weight plane.
-#define BNM_GENERIC_PICK(MMAX, K0)                                                                              \
-    if (kt0 == K0) {                                                                                            \
-        if (sp == 1 && dbl) fn = fused_fc_generic_kernel<MMAX, K0, 1, true, bnmk_generic_wps(MMAX, K0, 1)>;     \
-        else if (sp == 1) fn = fused_fc_generic_kernel<MMAX, K0, 1, false, bnmk_generic_wps(MMAX, K0, 1)>;      \
-        else if (sp == 2 && !dbl) fn = fused_fc_generic_kernel<MMAX, K0, 2, false, bnmk_generic_wps(MMAX, K0, 2)>; \
+// ---- per-class launcher: each (tile class, tiles per wave) pair is its own translation unit (bnm_fused_generic_m{2,4,8}[_t2].hip)
+// so that they compile side by side.  Instantiations per row length: doubled hidden weights; plain; plain with FP1.3.0's second
+// weight plane.  T = 2 is instantiated for rows of 128 and 256 bytes (32 / 64 B-operand registers per wave).
+#define BNM_GENERIC_PICK(MMAX, K0, T)                                                                                       \
+    if (kt0 == K0) {                                                                                                        \
+        if (sp == 1 && dbl) fn = fused_fc_generic_kernel<MMAX, K0, 1, true, T, bnmk_generic_wps(MMAX, K0, 1, T)>;           \
+        else if (sp == 1) fn = fused_fc_generic_kernel<MMAX, K0, 1, false, T, bnmk_generic_wps(MMAX, K0, 1, T)>;            \
+        else if (sp == 2 && !dbl) fn = fused_fc_generic_kernel<MMAX, K0, 2, false, T, bnmk_generic_wps(MMAX, K0, 2, T)>;    \
     }
-#define BNM_GENERIC_LAUNCHER(NAME, MMAX)                                                                               \
+#define BNM_GENERIC_LAUNCHER_BEGIN(NAME)                                                                                    \
     hipError_t NAME(uint32_t kt0, uint32_t sp, bool dbl, unsigned blocks, unsigned threads, unsigned lds, hipStream_t s,     \
                     const int8_t *images, uint64_t n, const void *frags, const BnmGenericDesc &d, uint32_t *cls,            \
                     int32_t *logits, uint32_t *counter, uint32_t batch) {                                                    \
         typedef void (*fn_t)(const int8_t *, uint64_t, const i32x4 *, BnmGenericDesc, uint32_t *, int32_t *, uint32_t *, uint32_t); \
-        fn_t fn = nullptr;                                                                                                   \
-        BNM_GENERIC_PICK(MMAX, 2) BNM_GENERIC_PICK(MMAX, 4) BNM_GENERIC_PICK(MMAX, 8) BNM_GENERIC_PICK(MMAX, 16)             \
+        fn_t fn = nullptr;
+#define BNM_GENERIC_LAUNCHER_END                                                                                             \
         if (!fn) return hipErrorInvalidValue;                                                                                \
         if (!blocks) return hipSuccess;   /* probe: is there an instantiation? */                                            \
         /* opt in to > 64 KiB of dynamic LDS (a per-device function attribute; a host call of about a microsecond) */        \
@@ -332,3 +409,19 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         fn<<<dim3(blocks), dim3(threads), lds, s>>>(images, n, (const i32x4 *)frags, d, cls, logits, counter, batch);        \
         return hipGetLastError();                                                                                            \
     }
+#define BNM_GENERIC_LAUNCHER_T1(NAME, MMAX)                                                                                  \
+    BNM_GENERIC_LAUNCHER_BEGIN(NAME)                                                                                         \
+    BNM_GENERIC_PICK(MMAX, 2, 1) BNM_GENERIC_PICK(MMAX, 4, 1) BNM_GENERIC_PICK(MMAX, 8, 1) BNM_GENERIC_PICK(MMAX, 16, 1)     \
+    BNM_GENERIC_LAUNCHER_END
+// one row length per translation unit (the 8-tile class: a single unit with all four took 6.5 minutes to compile)
+#define BNM_GENERIC_LAUNCHER_T1_K(NAME, MMAX, K0)                                                                            \
+    BNM_GENERIC_LAUNCHER_BEGIN(NAME)                                                                                         \
+    BNM_GENERIC_PICK(MMAX, K0, 1)                                                                                            \
+    BNM_GENERIC_LAUNCHER_END
+#define BNM_GENERIC_LAUNCHER_T2(NAME, MMAX)                                                                                  \
+    BNM_GENERIC_LAUNCHER_BEGIN(NAME)                                                                                         \
+    BNM_GENERIC_PICK(MMAX, 4, 2) BNM_GENERIC_PICK(MMAX, 8, 2)                                                                \
+    BNM_GENERIC_LAUNCHER_END
+// (Two tiles per wave exist for the 2-tile class only.  A wave addresses at most 256 VGPRs; two tiles' accumulators of a 4-tile
+// layer are 128 of them, of an 8-tile layer all 256 - what does not fit goes to AGPRs, which ReLUNorm can only read through a
+// v_accvgpr_read per value, or to scratch: the 4-tile instantiation spilled 22,000 registers.)

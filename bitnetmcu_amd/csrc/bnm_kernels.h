@@ -22,9 +22,11 @@ hipError_t bnmk_unpack_rows(const void *d_packed, int32_t bpw, uint32_t n_input,
 // ReLUNorm output (see DESIGN.md §fragment layout).  dst: MT*KT fragments of 64 lanes x 16 B.
 // pad_row_weight: weight given to rows >= n_output on the real input columns — 0 for hidden layers (ReLUNorm must
 // see 0 there), -128 for the classifier layer (argmax_rows in bnm_fused_fc.hip relies on it).
+// frag_stride: bytes between the fragments of consecutive K-steps of one tile (1024 = contiguous; the generic kernel's K-step
+// major layout passes M KiB with MT == 1)
 hipError_t bnmk_build_fragments(const int8_t *d_rows, uint32_t row_stride, uint32_t n_output,
                                 uint32_t n_real, uint32_t MT, uint32_t KT, int kmap, int scale, int pad_row_weight,
-                                void *d_dst, hipStream_t s);
+                                void *d_dst, uint32_t frag_stride, hipStream_t s);
 
 // ---- fused whole-model FC kernel (int8 MFMA) -------------------------------------------------
 struct BnmFusedShape {
@@ -68,23 +70,30 @@ int bnmk_fused_default_variant(const BnmFusedShape &sh);
 struct BnmGenericDesc {      // passed to the kernel by value
     uint32_t KT0;            // input row bytes / 32: 2, 4, 8 or 16 (rows of 64 / 128 / 256 / 512 bytes)
     uint32_t mmax;           // tile class: 2, 4 or 8 = upper bound of 32-row tiles per layer the kernel is compiled for
-    uint32_t M[4];           // 32-row output tiles per FC layer as the kernel runs them; M[3] == 0 for 3-layer models
-    uint32_t KTP[4];         // K-steps per layer in the fragment image (layer 1: KT0; deeper: padded previous tile count)
+    uint32_t M[4];           // 32-row output tiles per FC layer (exact); M[3] == 0 for 3-layer models
+    uint32_t KTP[4];         // K-steps per layer (exact): KT0 for layer 1, the previous layer's tile count for the others
     uint32_t frag_off[4];    // byte offset of each layer's fragments inside the fragment image
-    uint32_t w_bytes;        // size of the fragment image (a multiple of 1 KiB)
-    uint32_t sp;             // 1, or 2 when a second weight plane follows each tile's fragments (FP1.3.0's +128)
+    uint32_t w_bytes;        // size of the fragment image (a multiple of 1 KiB): sp * sum M[i] * KTP[i] KiB, nothing padded
+    uint32_t sp;             // 1, or 2 when a second weight plane follows each layer's first (FP1.3.0's +128)
     uint32_t n_classes;      // <= 256
+    uint32_t stage;          // set by the launcher: a 2 KiB logits staging area per wave follows the tile buffers in LDS
 };
-// waves per SIMD an instantiation of the generic kernel is compiled for (its launch bound is 256 * this many threads)
-constexpr int bnmk_generic_wps(int mmax, int kt0, int sp) {
-    return mmax == 2 ? 4 : mmax == 4 ? ((sp == 2 || kt0 == 16) ? 2 : 3) : 1;
+// Fragment (plane p, K-step s, tile m) of layer i sits at frag_off[i] + ((p * KTP[i] + s) * M[i] + m) KiB of the image.
+// waves per SIMD an instantiation of the generic kernel is compiled for (its launch bound is 256 * this many threads);
+// tiles: image tiles a wave carries per iteration (1 or 2)
+constexpr int bnmk_generic_wps(int mmax, int kt0, int sp, int tiles) {
+    return mmax == 2 ? (tiles == 2 || kt0 == 16 ? 3 : 4) : mmax == 4 ? ((sp == 2 && kt0 == 16) ? 2 : 3) : 1;
 }
-// variant id of the generic kernel in bnm_ctx_set_tuning / bnm_ctx_get_variant
-enum { BNM_FUSED_GENERIC = 4 };
+// variant ids of the generic kernel in bnm_ctx_set_tuning / bnm_ctx_get_variant: 4 = tiles per wave chosen by the library,
+// 7 / 8 = one / two tiles per wave forced (A/B measurements)
+enum { BNM_FUSED_GENERIC = 4, BNM_FUSED_GENERIC_T1 = 7, BNM_FUSED_GENERIC_T2 = 8 };
 bool bnmk_generic_plan(BnmGenericDesc &d, const uint32_t m_real[4]);   // fills mmax, M, KTP, frag_off, w_bytes from KT0, sp
+// tiles: 0 = the library's choice, 1 / 2 forced; logits: the call writes logits (a staging area is reserved when it fits).
+// Returns the tiles per wave a launch would use (1 or 2), or 0 when the model does not fit the kernel in that form.
+int bnmk_generic_tiles(const BnmGenericDesc &d, bool dbl, int tiles, bool logits);
 bool bnmk_generic_supported(const BnmGenericDesc &d, bool dbl);
-// d_counter: a counter block of the caller (BNM_WORK_BLOCK_WORDS words, all zero; the kernel leaves it all zero); batch: tiles per take (0 = default)
-hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int grid_blocks, const int8_t *d_images, uint64_t n,
+// d_counter: a counter block of the caller (BNM_WORK_BLOCK_WORDS words, all zero; the kernel leaves it all zero); batch: units per take (0 = default)
+hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int tiles, int grid_blocks, const int8_t *d_images, uint64_t n,
                               const void *d_frags, uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t batch,
                               hipStream_t s);
 

@@ -116,7 +116,7 @@ hipError_t bnmk_unpack_rows(const void *packed, int32_t bpw, uint32_t n_input, u
 // scale: 1, or 2 for hidden layers of the "doubled" kernels (see relunorm_pack<MT, true>).
 __global__ __launch_bounds__(256) void build_fragments_kernel(const int8_t *rows, uint32_t stride, uint32_t n_output,
                                                               uint32_t n_real, uint32_t MT, uint32_t KT, int kmap,
-                                                              int scale, int pad_row_weight, uint32_t *dst) {
+                                                              int scale, int pad_row_weight, uint32_t *dst, uint32_t frag_dwords) {
     uint32_t total = MT * KT * 64u * 4u;   // dwords
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         uint32_t j = i & 3u, lane = (i >> 2) & 63u, frag = i >> 8;
@@ -129,16 +129,18 @@ __global__ __launch_bounds__(256) void build_fragments_kernel(const int8_t *rows
             int w = k >= n_real ? 0 : row < n_output ? (int)rows[(size_t)row * stride + k] * scale : pad_row_weight;
             v |= (uint32_t)(uint8_t)(int8_t)w << (8u * b);
         }
-        dst[i] = v;
+        // fragment (m, s) at (m * KT + s) * frag_dwords; within it lane-linear
+        dst[(size_t)frag * frag_dwords + (i & 255u)] = v;
     }
 }
 
 hipError_t bnmk_build_fragments(const int8_t *rows, uint32_t stride, uint32_t n_output, uint32_t n_real, uint32_t MT,
-                                uint32_t KT, int kmap, int scale, int pad_row_weight, void *dst, hipStream_t s) {
+                                uint32_t KT, int kmap, int scale, int pad_row_weight, void *dst, uint32_t frag_stride, hipStream_t s) {
     uint32_t total = MT * KT * 256u;
     if (!total) return hipSuccess;
+    if (frag_stride < 1024u || (frag_stride & 1023u)) return hipErrorInvalidValue;
     build_fragments_kernel<<<dim3((total + 255u) / 256u), dim3(256), 0, s>>>(rows, stride, n_output, n_real, MT, KT, kmap,
-                                                                             scale, pad_row_weight, (uint32_t *)dst);
+                                                                             scale, pad_row_weight, (uint32_t *)dst, frag_stride / 4u);
     return hipGetLastError();
 }
 
