@@ -9,6 +9,7 @@
                     uint32_t *counter, uint32_t batch)
 DECL(bnmk_generic_launch_m2);
 DECL(bnmk_generic_launch_m4);
+DECL(bnmk_generic_launch_m6_k8);
 DECL(bnmk_generic_launch_m8_k2);
 DECL(bnmk_generic_launch_m8_k4);
 DECL(bnmk_generic_launch_m8_k8);
@@ -24,6 +25,7 @@ launch_fn launcher_of(uint32_t mmax, int tiles, uint32_t kt0) {
     if (mmax == 8 && tiles != 2)
         return kt0 == 2 ? bnmk_generic_launch_m8_k2 : kt0 == 4 ? bnmk_generic_launch_m8_k4 : kt0 == 8 ? bnmk_generic_launch_m8_k8
                : kt0 == 16 ? bnmk_generic_launch_m8_k16 : nullptr;
+    if (mmax == 6) return (tiles != 2 && kt0 == 8) ? bnmk_generic_launch_m6_k8 : nullptr;
     switch (mmax) {
         case 2: return tiles == 2 ? bnmk_generic_launch_m2_t2 : bnmk_generic_launch_m2;
         case 4: return tiles == 2 ? nullptr : bnmk_generic_launch_m4;
@@ -53,7 +55,8 @@ bool bnmk_generic_plan(BnmGenericDesc &d, const uint32_t m_real[4]) {
     uint32_t mm = 0;
     for (int i = 0; i < 4; i++) mm = m_real[i] > mm ? m_real[i] : mm;
     if (mm == 0 || mm > 8) return false;
-    d.mmax = mm <= 2 ? 2 : mm <= 4 ? 4 : 8;
+    // (the 6-tile class is instantiated for 256-byte rows - FC models - only)
+    d.mmax = mm <= 2 ? 2 : mm <= 4 ? 4 : (mm <= 6 && d.KT0 == 8) ? 6 : 8;
     uint32_t kt = d.KT0, bytes = 0;
     for (int i = 0; i < 4; i++) {
         d.M[i] = m_real[i];
@@ -67,13 +70,15 @@ bool bnmk_generic_plan(BnmGenericDesc &d, const uint32_t m_real[4]) {
     return true;
 }
 
-// Tiles per wave.  Two tiles per wave halve the LDS traffic of the weight fragments (one read feeds two MFMAs) and double the
-// work a wave has in flight, but need two tile buffers per wave: chosen when at least four waves (one per SIMD) still fit.
+// Tiles per wave.  Two tiles per wave (2-tile class only) halve the LDS traffic of the weight fragments - one read feeds two MFMAs -
+// but the two tiles' MFMAs then finish together and both ReLUNorms follow with nothing of the wave's own to overlap them, and
+// half as many waves fit beside the weights: measured on the headline model, same process, interleaved (profiles/generic_ab.py,
+// profiles/r03/generic_ab_r03c.log): 4.46 ms against 4.35 ms with one tile per wave (specialised dual kernel 4.11, plain read of the
+// images 3.92).  The library therefore runs one tile per wave; two remain selectable (variant 8) for measurements.
 int bnmk_generic_tiles(const BnmGenericDesc &d, bool dbl, int tiles, bool logits) {
     const bool stage = logits && d.n_classes <= 16u;
     auto ok = [&](int t) { return instantiated(d, dbl, t) && (generic_waves(d, t, stage) >= 1u || generic_waves(d, t, false) >= 1u); };
     if (tiles == 1 || tiles == 2) return ok(tiles) ? tiles : 0;
-    if (instantiated(d, dbl, 2) && generic_waves(d, 2, false) >= 4u) return 2;
     if (ok(1)) return 1;
     return ok(2) ? 2 : 0;
 }

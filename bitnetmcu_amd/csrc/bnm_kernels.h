@@ -69,7 +69,7 @@ int bnmk_fused_default_variant(const BnmFusedShape &sh);
 // ---- generic fused whole-model FC kernel (bnm_fused_generic.hip): run-time layer widths, weights in LDS ----------
 struct BnmGenericDesc {      // passed to the kernel by value
     uint32_t KT0;            // input row bytes / 32: 2, 4, 8 or 16 (rows of 64 / 128 / 256 / 512 bytes)
-    uint32_t mmax;           // tile class: 2, 4 or 8 = upper bound of 32-row tiles per layer the kernel is compiled for
+    uint32_t mmax;           // tile class: 2, 4, 6 or 8 = upper bound of 32-row tiles per layer the kernel is compiled for
     uint32_t M[4];           // 32-row output tiles per FC layer (exact); M[3] == 0 for 3-layer models
     uint32_t KTP[4];         // K-steps per layer (exact): KT0 for layer 1, the previous layer's tile count for the others
     uint32_t frag_off[4];    // byte offset of each layer's fragments inside the fragment image
@@ -82,7 +82,7 @@ struct BnmGenericDesc {      // passed to the kernel by value
 // waves per SIMD an instantiation of the generic kernel is compiled for (its launch bound is 256 * this many threads);
 // tiles: image tiles a wave carries per iteration (1 or 2)
 constexpr int bnmk_generic_wps(int mmax, int kt0, int sp, int tiles) {
-    return mmax == 2 ? (tiles == 2 || kt0 == 16 ? 3 : 4) : mmax == 4 ? ((sp == 2 && kt0 == 16) ? 2 : 3) : 1;
+    return mmax == 2 ? (tiles == 2 || kt0 == 16 ? 3 : 4) : mmax == 4 ? ((sp == 2 && kt0 == 16) ? 2 : 3) : mmax == 6 ? 2 : 1;
 }
 // variant ids of the generic kernel in bnm_ctx_set_tuning / bnm_ctx_get_variant: 4 = tiles per wave chosen by the library,
 // 7 / 8 = one / two tiles per wave forced (A/B measurements)
