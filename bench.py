@@ -439,7 +439,8 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         rate = count / (float(np.mean(ms)) * 1e-3)
         ok = None if a.no_verify else ck.verify_sample(torch, model, x, c, lg, count)
         res[name] = {"model": model_name, "images": count, "dist": "U" if dist == 0 else "M", "steps": steps, "warmup": warmup,
-                     "value": rate, "unit": "inferences/s", "avg_launch_ms": float(np.mean(ms)), "min_launch_ms": float(np.min(ms)),
+                     "value": rate, "unit": "inferences/s", "avg_launch_ms": float(np.mean(ms)), "median_launch_ms": float(np.median(ms)),
+                     "min_launch_ms": float(np.min(ms)),
                      "kernel": kernel_name(b, ctx, model), "path": ctx.path, "fused_variant": ctx.variant, "verified_vs_oracle": ok}
         if note:
             res[name]["note"] = note
@@ -457,28 +458,28 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     # (selected by name: the library's AUTO path runs ternary models on the MFMA kernels, 5x faster - next entry)
     r, m = run("ternary_alu", "tern_96", n, 3, 1, path=b.PATH_TERNARY_ALU, note="BASELINE configs[2]: the no-MFMA kernel, selected explicitly")
     res["ternary_alu"]["roofline"] = valu(r, "ternary_stream_kernel", BYTES_PER_INFERENCE, m)
-    r, _ = run("ternary_mfma_generic", "tern_96", n, 5, 1, note="the same model on the library's default (AUTO) path")
+    r, _ = run("ternary_mfma_generic", "tern_96", n, 10, 3, note="the same model on the library's default (AUTO) path")
     hbm_entry("ternary_mfma_generic", r, BYTES_PER_INFERENCE)
     # configs[3]: CNN 64-wide
     r, m = run("cnn_64", "cnn_64", n_cnn, 3, 1, note="BASELINE configs[3]")
     res["cnn_64"]["roofline"] = valu(r, "cnn_front_mfma_kernel", BYTES_PER_INFERENCE, m)
     # headline model through the generic kernel (what any non-zoo 64-wide export would get)
-    r, _ = run("fc_generic_kernel", "fc_4bitsym_64", n, 5, 2, variant=4)
+    r, _ = run("fc_generic_kernel", "fc_4bitsym_64", n, 10, 3, variant=4)
     hbm_entry("fc_generic_kernel", r, BYTES_PER_INFERENCE)
     # the reference's documented 12 KB family (docs/documentation.md:169-183; its 4-bit member is the headline model): random
     # weights of those shapes and codecs from the reference's own exporter (tests/golden/make_doc12k_headers.py)
     for nm in ("doc12k_binary", "doc12k_ternary", "doc12k_2bit", "doc12k_8bit"):
-        r, _ = run(nm, nm, n, 5, 2, note="reference docs' 12 KB model family")
+        r, _ = run(nm, nm, n, 10, 3, note="reference docs' 12 KB model family")
         hbm_entry(nm, r, BYTES_PER_INFERENCE)
     # headline model, class ids + logits (300 B per inference)
     if n <= 100_000_000:
-        r, _ = run("fc_logits", "fc_4bitsym_64", n, 5, 2, want_logits=True)
+        r, _ = run("fc_logits", "fc_4bitsym_64", n, 10, 3, want_logits=True)
         hbm_entry("fc_logits", r, BYTES_PER_INFERENCE_LOGITS_10)
     # headline model on Dist-M (MNIST-like value statistics): refill the resident set in place
     if a.dist == 0:
         b.synth.fill_device(images, first=0, dist=1)
         torch.cuda.synchronize()
-        r, _ = run("fc_dist_m", "fc_4bitsym_64", n, 5, 2, dist=1)
+        r, _ = run("fc_dist_m", "fc_4bitsym_64", n, 10, 3, dist=1)
         hbm_entry("fc_dist_m", r, BYTES_PER_INFERENCE)
     return res
 
