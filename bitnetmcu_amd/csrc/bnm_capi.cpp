@@ -246,7 +246,8 @@ int resolve_path(bnm_ctx *c) {
     if (want == BNM_PATH_FUSED_MFMA && !c->fused_ok)
         return fail(BNM_EUNSUPPORTED, "model shape/codec is outside the fused MFMA kernel table");
     if (want == BNM_PATH_TERNARY_ALU && !(c->tern_ok && c->model.kind == BNM_KIND_FC))
-        return fail(BNM_EUNSUPPORTED, "ternary ALU kernel needs a ternary FC 256-96-96-96-N model");
+        return fail(BNM_EUNSUPPORTED, "the ternary ALU kernels serve ternary FC models 256-H1-H2-H3-N with (H1, H2, H3) one of "
+                                      "96-96-96, 128-128-112, 64-64-64, 128-128-128");
     c->path = want;
     return BNM_OK;
 }
@@ -482,19 +483,25 @@ int ctx_build(bnm_ctx *c) {
         c->fused_ok = c->table_ok || c->generic_ok;
     }
     // ---- ternary ALU path ------------------------------------------------------------------------------
-    if (m.kind == BNM_KIND_FC && all_tern && nfc == 4 && c->fc[0].n_real == 256 && c->fc[0].info.n_output == 96 &&
-        c->fc[1].info.n_output == 96 && c->fc[2].info.n_output == 96 && c->fc[3].info.n_output <= 64) {
+    if (m.kind == BNM_KIND_FC && all_tern && nfc == 4) {
         BnmTernArgs a{};
         for (int i = 0; i < 4; i++) {
             a.rows[i] = c->fc[i].rows_lo;
             a.stride[i] = c->fc[i].row_stride;
+            a.n_in[i] = c->fc[i].n_real;
             a.n_out[i] = c->fc[i].info.n_output;
         }
-        void *p = nullptr;
-        if (int e = dev_alloc(c, &p, (size_t)bnmk_ternary_stream_dwords(a.n_out) * 4u)) return e;
-        c->tern_stream = (int *)p;
-        HIP_TRY(bnmk_ternary_stream_build(a, c->tern_stream, s));
-        c->tern_ok = true;
+        if (bnmk_ternary_alu_supported(a.n_in, a.n_out) && a.n_out[3] <= 64) {
+            if (bnmk_ternary_stream_supported(a.n_out)) {
+                void *p = nullptr;
+                if (int e = dev_alloc(c, &p, (size_t)bnmk_ternary_stream_dwords(a.n_out) * 4u)) return e;
+                c->tern_stream = (int *)p;
+                HIP_TRY(bnmk_ternary_stream_build(a, c->tern_stream, s));
+            } else {
+                c->tern_variant = 0;      // the plain ALU kernel (the streamed one exists for 96-96-96)
+            }
+            c->tern_ok = true;
+        }
     }
     HIP_TRY(hipDeviceSynchronize());
     return resolve_path(c);
@@ -793,6 +800,8 @@ int bnm_ctx_set_work_batch(bnm_ctx *c, int tiles) {
 int bnm_ctx_set_ternary_variant(bnm_ctx *c, int variant) {
     if (!c || variant < 0 || (variant > 2 && variant != 11 && variant != 12)) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
+    if (variant != 0 && c->tern_ok && !c->tern_stream)
+        return fail(BNM_EUNSUPPORTED, "the streamed ternary kernels exist for 96-96-96 only; this model runs the plain ALU kernel (variant 0)");
     c->tern_variant = variant % 10;
     c->tern_dynamic = variant < 10;
     return BNM_OK;

@@ -169,17 +169,18 @@ BNM_DEVICE void hidden_mma(const char *a, uint32_t K, const i32x4 (&in)[T][MMAX]
     });
 }
 
-// hidden layer: MFMAs + ReLUNorm, in -> out (M tiles, K K-steps, both run-time)
+// hidden layer: MFMAs + ReLUNorm (M tiles, K K-steps, both run-time), IN PLACE: the packed activations act[.][0..K) are the B
+// operands, act[.][0..M) receive the layer's outputs once the last MFMA has been issued.  (With separate in / out arrays the
+// cases' outputs met in PHI nodes whose undefined inputs hipcc filled with copies of `in`: a dozen v_mov per layer and tile.)
 template <int MMAX, int SP, bool DBL, int T>
-BNM_DEVICE void hidden_layer(const char *smem, uint32_t lane16, uint32_t off, uint32_t M, uint32_t K, const i32x4 (&in)[T][MMAX],
-                             i32x4 (&out)[T][MMAX], int h) {
+BNM_DEVICE void hidden_layer(const char *smem, uint32_t lane16, uint32_t off, uint32_t M, uint32_t K, i32x4 (&act)[T][MMAX], int h) {
     static_for<1, MMAX + 1>([&](auto MI) {
         constexpr int mt = decltype(MI)::value;
         if (M == (uint32_t)mt) {
             i32x16 acc[T][mt];
-            hidden_mma<mt, SP, T, MMAX>(smem + (off + lane16), K, in, acc);
+            hidden_mma<mt, SP, T, MMAX>(smem + (off + lane16), K, act, acc);
 #pragma unroll
-            for (int t = 0; t < T; t++) relunorm_pack<mt, DBL, MMAX>(acc[t], out[t], h);
+            for (int t = 0; t < T; t++) relunorm_pack<mt, DBL, MMAX>(acc[t], act[t], h);
         }
     });
 }
@@ -188,14 +189,21 @@ BNM_DEVICE void hidden_layer(const char *smem, uint32_t lane16, uint32_t off, ui
 template <int MMAX, int SP, int T>
 BNM_DEVICE void final_layer(const char *smem, uint32_t lane16, uint32_t off, uint32_t M, uint32_t K, const i32x4 (&in)[T][MMAX], int h,
                             int j, int lane, uint32_t (&cls)[T], int32_t *logits_out, int32_t *stage, uint64_t first_img, uint64_t n,
-                            uint32_t n_classes) {
+                            uint32_t n_classes, bool few_classes) {
     static_for<1, MMAX + 1>([&](auto MI) {
         constexpr int mt = decltype(MI)::value;
         if (M == (uint32_t)mt) {
             i32x16 acc[T][mt];
             hidden_mma<mt, SP, T, MMAX>(smem + (off + lane16), K, in, acc);
+            // up to 16 classes sit in the first two register groups of tile 0 (rows 0..15): the common case examines 8 registers
+            // instead of 16 per tile (wave-uniform branch)
+            if (few_classes) {
 #pragma unroll
-            for (int t = 0; t < T; t++) cls[t] = argmax_rows<mt, 0>(acc[t], h);
+                for (int t = 0; t < T; t++) cls[t] = argmax_rows<mt, 2>(acc[t], h);
+            } else {
+#pragma unroll
+                for (int t = 0; t < T; t++) cls[t] = argmax_rows<mt, 0>(acc[t], h);
+            }
             if (logits_out) {
 #pragma unroll
                 for (int t = 0; t < T; t++) {
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         const uint32_t l16 = 16u * lv;
         // B operand of K-step s: image j, global slot 2s+h -> LDS slot (2s+h) ^ mask(j): XOR 32*s into the byte offset
         const uint32_t rd = tile_off + (uint32_t)j * (uint32_t)ROW + 16u * ((uint32_t)h ^ G::mask((uint32_t)j));
-        i32x4 pa[T][MMAX], pb[T][MMAX];       // packed layer outputs = the next layer's B operands
+        i32x4 act[T][MMAX];       // packed layer outputs = the next layer's B operands (updated in place, layer by layer)
         // ---- layer 1: B operands from the tile buffers, KC K-steps at a time; the buffers are refilled with the wave's
         // next unit as soon as the last operand has been read (the load is then in flight for the rest of the iteration)
         static_for<1, MMAX + 1>([&](auto MI) {
@@ -353,10 +361,10 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
                     mma_l1<mt, KC, ch * KC, KT0, SP, ch == 0, T>(smem + (d.frag_off[0] + l16), b0, acc);
                 });
 #pragma unroll
-                for (int t = 0; t < T; t++) relunorm_pack<mt, DBL, MMAX>(acc[t], pa[t], h);
+                for (int t = 0; t < T; t++) relunorm_pack<mt, DBL, MMAX>(acc[t], act[t], h);
             }
         });
-        hidden_layer<MMAX, SP, DBL, T>(smem, l16, d.frag_off[1], M2, M1, pa, pb, h);
+        hidden_layer<MMAX, SP, DBL, T>(smem, l16, d.frag_off[1], M2, M1, act, h);
         const uint64_t first_img = (uint64_t)unit * (uint64_t)(32 * T);
         // per-iteration copy: keeps the (row < n_classes) predicates of every accumulator register of every case from being
         // hoisted out of the persistent loop as hundreds of live 64-bit masks
@@ -365,12 +373,12 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         uint32_t cls[T];
 #pragma unroll
         for (int t = 0; t < T; t++) cls[t] = 0;
+        uint32_t m_last = M3, k_last = M2, off_last = d.frag_off[2];
         if (M4) {
-            hidden_layer<MMAX, SP, DBL, T>(smem, l16, d.frag_off[2], M3, M2, pb, pa, h);
-            final_layer<MMAX, SP, T>(smem, l16, d.frag_off[3], M4, M3, pa, h, j, lane, cls, logits_out, stage, first_img, n, nc);
-        } else {
-            final_layer<MMAX, SP, T>(smem, l16, d.frag_off[2], M3, M2, pb, h, j, lane, cls, logits_out, stage, first_img, n, nc);
+            hidden_layer<MMAX, SP, DBL, T>(smem, l16, d.frag_off[2], M3, M2, act, h);
+            m_last = M4; k_last = M3; off_last = d.frag_off[3];
         }
+        final_layer<MMAX, SP, T>(smem, l16, off_last, m_last, k_last, act, h, j, lane, cls, logits_out, stage, first_img, n, nc, d.n_classes <= 16u);
         // both halves of the wave hold every tile's result: T = 2 keeps tile 0's ids in lanes 0..31 and tile 1's in lanes 32..63
         // (one 256-byte store per unit), T = 1 stores from the lower half
         if constexpr (T == 2) cls_prev = h ? cls[1] : cls[0];   // (h: this iteration's copy)

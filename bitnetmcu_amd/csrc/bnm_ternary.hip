@@ -442,21 +442,54 @@ hipError_t bnmk_ternary_stream_build(const BnmTernArgs &a, int *d_stream, hipStr
     return e != hipSuccess ? e : hipGetLastError();
 }
 
+// ---- shapes ------------------------------------------------------------------------------------------------------
+// The ALU path is instantiated per hidden-width triple (a lane keeps a layer's packed activations in H/4 registers and the
+// neuron loop is unrolled over them): the widths the reference documents for ternary models - 96-96-96 (BASELINE configs[2]) and
+// the 12 KB family's 128-128-112 (docs/documentation.md:169-183) - plus 64-64-64 and 128-128-128.  The streamed kernel (weights
+// through scalar registers, two images per lane) exists for 96-96-96; the other shapes run the plain ALU kernel.  Ternary
+// layers declare a padded input count (a multiple of 10, exportquant.py:132-137); the kernels read the REAL inputs only.
+namespace {
+typedef void (*tern_fn)(const int8_t *, uint64_t, const int8_t *, const int8_t *, const int8_t *, const int8_t *, uint32_t, uint32_t,
+                        uint32_t, uint32_t, uint32_t, uint32_t *, int32_t *);
+struct TernShape {
+    uint32_t h[3];
+    tern_fn fn;
+};
+const TernShape kTernShapes[] = {
+    {{96, 96, 96}, ternary_alu_kernel<96, 96, 96>},
+    {{128, 128, 112}, ternary_alu_kernel<128, 128, 112>},
+    {{64, 64, 64}, ternary_alu_kernel<64, 64, 64>},
+    {{128, 128, 128}, ternary_alu_kernel<128, 128, 128>},
+};
+const TernShape *find_tern(const uint32_t n_out[4]) {
+    for (const TernShape &t : kTernShapes)
+        if (t.h[0] == n_out[0] && t.h[1] == n_out[1] && t.h[2] == n_out[2]) return &t;
+    return nullptr;
+}
+}  // namespace
+
+bool bnmk_ternary_alu_supported(const uint32_t n_in[4], const uint32_t n_out[4]) {
+    return n_in[0] == 256 && n_in[1] == n_out[0] && n_in[2] == n_out[1] && n_in[3] == n_out[2] && find_tern(n_out) != nullptr;
+}
+bool bnmk_ternary_stream_supported(const uint32_t n_out[4]) { return n_out[0] == 96 && n_out[1] == 96 && n_out[2] == 96; }
+
 hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s) {
     if (!a.n) return hipSuccess;
-    if (a.n_layers != 4 || a.n_in[0] != 256 || a.n_out[0] != 96 || a.n_out[1] != 96 || a.n_out[2] != 96 ||
-        a.n_in[1] != 96 || a.n_in[2] != 96 || a.n_in[3] != 96)
-        return hipErrorInvalidValue;
+    if (a.n_layers != 4 || !bnmk_ternary_alu_supported(a.n_in, a.n_out)) return hipErrorInvalidValue;
+    const bool stream = a.variant != 0;
+    if (stream && !bnmk_ternary_stream_supported(a.n_out)) return hipErrorInvalidValue;
     const int G = a.variant == 2 ? 2 : 1;
     const uint64_t per = 64ull * (uint64_t)G;
     const uint64_t want = (a.n + per - 1ull) / per;
-    const uint64_t wpc = a.variant == 2 ? 8ull : 12ull;   // resident waves per CU
+    // resident waves per CU: the streamed kernels 8 / 12; the plain kernel's LDS column is max(H) * 128 bytes per wave
+    uint32_t hm = a.n_out[0] > a.n_out[1] ? a.n_out[0] : a.n_out[1];
+    hm = hm > a.n_out[2] ? hm : a.n_out[2];
+    const uint64_t wpc = stream ? (a.variant == 2 ? 8ull : 12ull) : (uint64_t)((160u * 1024u) / (hm * 128u) < 12u ? (160u * 1024u) / (hm * 128u) : 12u);
     const uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * wpc;
     const unsigned blocks = (unsigned)(want < cap ? want : cap);
-    if (a.variant == 0) {
-        ternary_alu_kernel<96, 96, 96><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.rows[0], a.rows[1], a.rows[2],
-                                                                           a.rows[3], a.stride[0], a.stride[1], a.stride[2],
-                                                                           a.stride[3], a.n_out[3], a.cls, a.logits);
+    if (!stream) {
+        find_tern(a.n_out)->fn<<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.rows[0], a.rows[1], a.rows[2], a.rows[3], a.stride[0],
+                                                                 a.stride[1], a.stride[2], a.stride[3], a.n_out[3], a.cls, a.logits);
     } else {
         if (!a.wstream || want >= (1ull << 32)) return hipErrorInvalidValue;
         if (G == 2)

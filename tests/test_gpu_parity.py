@@ -37,15 +37,17 @@ def paths_for(ctx):
             c.set_path(b.PATH_FUSED_MFMA)
             c.set_tuning(variant=6, grid_blocks=1)
         out.append(("fused_v6_grid1", fused6_small_grid))
-    try:
-        ctx.set_path(b.PATH_TERNARY_ALU)
-        for tv in (2, 1, 12, 11, 0):     # streamed weights (two / one image per lane; work counter / fixed stride), round 1's kernel
-            def tern(c, tv=tv):
-                c.set_path(b.PATH_TERNARY_ALU)
-                c.set_ternary_variant(tv)
+    # streamed weights (two / one image per lane; work counter / fixed stride: 96-96-96 only), the plain ALU kernel (every shape of
+    # the ALU table)
+    for tv in (2, 1, 12, 11, 0):
+        def tern(c, tv=tv):
+            c.set_path(b.PATH_TERNARY_ALU)
+            c.set_ternary_variant(tv)
+        try:
+            tern(ctx)
             out.append((f"ternary_alu_v{tv}", tern))
-    except b.BnmError:
-        pass
+        except b.BnmError:
+            pass
     ctx.set_path(b.PATH_AUTO)
     return out
 
@@ -601,6 +603,50 @@ def test_ternary_alu_kernels_extreme_sums(signs, gpu_ok, orc):
         for n in (len(x), 129, 128, 127, 65, 1):
             got = ctx.infer(x[:n], logits=True)
             assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (signs, tv, n)
+    ctx.close()
+
+
+@pytest.mark.parametrize("widths", [(128, 128, 112), (64, 64, 64), (128, 128, 128)])
+@pytest.mark.parametrize("signs", ["-+-+", "++++", "dense"])
+def test_ternary_alu_kernel_other_widths(widths, signs, gpu_ok, orc):
+    """The no-MFMA path for the other ternary shapes of its table - among them the reference's documented 12 KB ternary model,
+    128-128-112 (docs/documentation.md:169-183; padded input counts 260 / 130 / 130 / 120 as the exporter writes them): all +1 /
+    mixed / zero-free random trits on extreme and synthetic images, ids and logits against the oracle; the MFMA path on the same
+    model must agree as well."""
+    rng = np.random.default_rng(sum(widths) * 7 + len(signs) + ord(signs[0]))
+
+    def digits(k, n_out, n_in):
+        if signs == "dense":
+            return rng.integers(0, 2, size=(n_out, n_in))
+        d = np.full((n_out, n_in), 0 if signs[k - 1] == "+" else 1)
+        if k > 1:
+            d[::7] = 1 - d[::7]
+        return d
+    model = b.Model.from_header_text(_random_model_text(rng, (64, 64, 64, 64), widths, trit_digits=digits))
+    om = util.OracleModel(model, orc)
+    x = np.concatenate([np.full((70, 256), -128, np.int8), np.full((70, 256), 127, np.int8), np.zeros((5, 256), np.int8),
+                        synth.images(11, 700, DIST_U), synth.images(11, 700, DIST_M)])
+    want = om.infer(x, logits=True)
+    ctx = b.Context(model)
+    assert ctx.path == b.PATH_FUSED_MFMA          # AUTO: the fastest bit-exact kernel
+    got = ctx.infer(x, logits=True)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ctx.set_path(b.PATH_TERNARY_ALU)
+    with pytest.raises(b.BnmError):
+        ctx.set_ternary_variant(2)                # the streamed kernels exist for 96-96-96 only
+    for n in (len(x), 129, 64, 1):
+        got = ctx.infer(x[:n], logits=True)
+        assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (widths, signs, n)
+    ctx.close()
+
+
+def test_ternary_alu_path_refuses_shapes_outside_its_table(gpu_ok):
+    rng = np.random.default_rng(3)
+    model = b.Model.from_header_text(_random_model_text(rng, (64, 64, 64, 64), (96, 64, 32)))
+    ctx = b.Context(model)
+    assert ctx.path == b.PATH_FUSED_MFMA
+    with pytest.raises(b.BnmError):
+        ctx.set_path(b.PATH_TERNARY_ALU)
     ctx.close()
 
 
