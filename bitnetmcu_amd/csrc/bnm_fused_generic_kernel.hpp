@@ -97,9 +97,10 @@ struct RowGeom {
 // sched_group_barrier - left to itself hipcc put every ds_read directly in front of its MFMA and paid the full LDS latency per
 // item.  Fragment (p, s, m) of a layer with MT tiles and KTOT K-steps sits at ((p*KTOT + s)*MT + m) KiB, lane-linear.
 
-// layer 1 (or a chunk of its K-steps): NS compile-time K-steps S0 .. S0+NS-1 of KTOT
-template <int MT, int NS, int S0, int KTOT, int SP, bool INIT, int T>
-BNM_DEVICE void mma_l1(const char *a, const i32x4 (&b)[T][NS], i32x16 (&acc)[T][MT]) {
+// NS compile-time K-steps S0 .. S0+NS-1 of KTOT: layer 1 (or a chunk of its K-steps), and every layer of the uniform fast path
+template <int MT, int NS, int S0, int KTOT, int SP, bool INIT, int T, int NB = NS>
+BNM_DEVICE void mma_l1(const char *a, const i32x4 (&b)[T][NB], i32x16 (&acc)[T][MT]) {
+    static_assert(NS <= NB, "operand array too short");
     constexpr int N = SP * NS * MT;
     constexpr int DEPTH = N < 4 ? N : 4;
     auto frag = [&](auto I) -> i32x4 {
@@ -185,7 +186,36 @@ BNM_DEVICE void hidden_layer(const char *smem, uint32_t lane16, uint32_t off, ui
     });
 }
 
-// classifier layer: MFMAs + first-maximum argmax (+ logits)
+// first-maximum argmax of a classifier layer's accumulators (+ logits)
+template <int MT, int T>
+BNM_DEVICE void classify(const i32x16 (&acc)[T][MT], int h, int j, int lane, uint32_t (&cls)[T], int32_t *logits_out, int32_t *stage,
+                         uint64_t first_img, uint64_t n, uint32_t n_classes, bool few_classes) {
+    // up to 16 classes sit in the first two register groups of tile 0 (rows 0..15): the common case examines 8 registers
+    // instead of 16 per tile (wave-uniform branch)
+    if (few_classes) {
+#pragma unroll
+        for (int t = 0; t < T; t++) cls[t] = argmax_rows<MT, 2>(acc[t], h);
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; t++) cls[t] = argmax_rows<MT, 0>(acc[t], h);
+    }
+    if (logits_out) {
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const uint64_t tile_first = first_img + 32ull * (uint64_t)t;
+            if (tile_first >= n) continue;
+            int32_t *tile_dst = logits_out + tile_first * n_classes;
+            if (stage != nullptr && tile_first + 32ull <= n) {
+                // a whole tile through the staging area: contiguous nontemporal 16 B/lane stores, every line written whole
+                store_logits_tile<MT, 0, 0>(acc[t], stage, tile_dst, j, h, lane, n_classes);
+            } else if (tile_first + (uint64_t)j < n) {
+                store_logits<MT>(acc[t], tile_dst + (uint32_t)j * n_classes, h, n_classes);
+            }
+        }
+    }
+}
+
+// classifier layer, general path: MFMAs (M tiles, K K-steps, both run-time) + classify
 template <int MMAX, int SP, int T>
 BNM_DEVICE void final_layer(const char *smem, uint32_t lane16, uint32_t off, uint32_t M, uint32_t K, const i32x4 (&in)[T][MMAX], int h,
                             int j, int lane, uint32_t (&cls)[T], int32_t *logits_out, int32_t *stage, uint64_t first_img, uint64_t n,
@@ -195,31 +225,36 @@ BNM_DEVICE void final_layer(const char *smem, uint32_t lane16, uint32_t off, uin
         if (M == (uint32_t)mt) {
             i32x16 acc[T][mt];
             hidden_mma<mt, SP, T, MMAX>(smem + (off + lane16), K, in, acc);
-            // up to 16 classes sit in the first two register groups of tile 0 (rows 0..15): the common case examines 8 registers
-            // instead of 16 per tile (wave-uniform branch)
-            if (few_classes) {
-#pragma unroll
-                for (int t = 0; t < T; t++) cls[t] = argmax_rows<mt, 2>(acc[t], h);
-            } else {
-#pragma unroll
-                for (int t = 0; t < T; t++) cls[t] = argmax_rows<mt, 0>(acc[t], h);
-            }
-            if (logits_out) {
-#pragma unroll
-                for (int t = 0; t < T; t++) {
-                    const uint64_t tile_first = first_img + 32ull * (uint64_t)t;
-                    if (tile_first >= n) continue;
-                    int32_t *tile_dst = logits_out + tile_first * n_classes;
-                    if (stage != nullptr && tile_first + 32ull <= n) {
-                        // a whole tile through the staging area: contiguous nontemporal 16 B/lane stores, every line written whole
-                        store_logits_tile<mt, 0, 0>(acc[t], stage, tile_dst, j, h, lane, n_classes);
-                    } else if (tile_first + (uint64_t)j < n) {
-                        store_logits<mt>(acc[t], tile_dst + (uint32_t)j * n_classes, h, n_classes);
-                    }
-                }
-            }
+            classify<mt, T>(acc, h, j, lane, cls, logits_out, stage, first_img, n, n_classes, few_classes);
         }
     });
+}
+
+// ---- the uniform fast path -----------------------------------------------------------------------------------------
+// When every hidden layer has the same tile count MT (the shapes the reference documents: 64-64-64, 96-96-96, 128-128-112,
+// 160-160-160) and the classifier fits one tile, everything behind layer 1 is ONE straight-line piece of code per MT: K-steps
+// are compile-time counts (no exits), no case boundaries between the layers (no PHI copies of the packed activations: the
+// general path spends 7-26 v_mov per layer on them), and hipcc schedules across layers as in the shape-specialised kernels.
+template <int MT, int MMAX, int SP, bool DBL, int T>
+BNM_DEVICE void uniform_layer(const char *a, i32x4 (&act)[T][MMAX], int h) {
+    i32x16 acc[T][MT];
+    mma_l1<MT, MT, 0, MT, SP, true, T, MMAX>(a, act, acc);
+#pragma unroll
+    for (int t = 0; t < T; t++) relunorm_pack<MT, DBL, MMAX>(acc[t], act[t], h);
+}
+template <int MT, int MMAX, int SP, bool DBL, int T>
+BNM_DEVICE void uniform_tail(const char *smem, uint32_t lane16, const BnmGenericDesc &d, i32x4 (&act)[T][MMAX], int h, int j, int lane,
+                             uint32_t (&cls)[T], int32_t *logits_out, int32_t *stage, uint64_t first_img, uint64_t n, uint32_t n_classes,
+                             bool few_classes) {
+    uniform_layer<MT, MMAX, SP, DBL, T>(smem + (d.frag_off[1] + lane16), act, h);
+    uint32_t off_last = d.frag_off[2];
+    if (d.M[3]) {
+        uniform_layer<MT, MMAX, SP, DBL, T>(smem + (d.frag_off[2] + lane16), act, h);
+        off_last = d.frag_off[3];
+    }
+    i32x16 acc[T][1];
+    mma_l1<1, MT, 0, MT, SP, true, T, MMAX>(smem + (off_last + lane16), act, acc);
+    classify<1, T>(acc, h, j, lane, cls, logits_out, stage, first_img, n, n_classes, few_classes);
 }
 
 }  // namespace
@@ -310,6 +345,9 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
     if (unit < n_units) dma_unit(unit);
 
     const uint32_t M1 = d.M[0], M2 = d.M[1], M3 = d.M[2], M4 = d.M[3];
+    const bool few_classes = d.n_classes <= 16u;
+    // the uniform fast path (see uniform_tail): equal tile counts in all hidden layers, near the class's maximum, one classifier tile
+    const bool uniform = M2 == M1 && (M4 ? (M3 == M1 && M4 == 1u) : M3 == 1u) && M1 + 1u >= (uint32_t)MMAX;
     // Class ids leave one iteration LATE, right behind the refill: the loop's top waits for vmcnt(0) (the tile), and a store
     // issued at the end of the body would make that wait sit on its write acknowledgement every iteration.  Every class word is
     // written exactly once (bnm_infer_host's latency path polls them), so the first iteration stores nothing.
@@ -334,6 +372,15 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         // B operand of K-step s: image j, global slot 2s+h -> LDS slot (2s+h) ^ mask(j): XOR 32*s into the byte offset
         const uint32_t rd = tile_off + (uint32_t)j * (uint32_t)ROW + 16u * ((uint32_t)h ^ G::mask((uint32_t)j));
         i32x4 act[T][MMAX];       // packed layer outputs = the next layer's B operands (updated in place, layer by layer)
+        const uint64_t first_img = (uint64_t)unit * (uint64_t)(32 * T);
+        // per-iteration copy: keeps the (row < n_classes) predicates of every accumulator register of every case from being
+        // hoisted out of the persistent loop as hundreds of live 64-bit masks
+        uint32_t nc = d.n_classes;
+        asm volatile("" : "+v"(nc));
+        uint32_t cls[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) cls[t] = 0;
+        bool done = false;
         // ---- layer 1: B operands from the tile buffers, KC K-steps at a time; the buffers are refilled with the wave's
         // next unit as soon as the last operand has been read (the load is then in flight for the rest of the iteration)
         static_for<1, MMAX + 1>([&](auto MI) {
@@ -362,23 +409,23 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
                 });
 #pragma unroll
                 for (int t = 0; t < T; t++) relunorm_pack<mt, DBL, MMAX>(acc[t], act[t], h);
+                if constexpr (mt >= MMAX - 1) {
+                    if (uniform) {      // all hidden layers have mt tiles, one classifier tile: straight-line code from here on
+                        uniform_tail<mt, MMAX, SP, DBL, T>(smem, l16, d, act, h, j, lane, cls, logits_out, stage, first_img, n, nc, few_classes);
+                        done = true;
+                    }
+                }
             }
         });
-        hidden_layer<MMAX, SP, DBL, T>(smem, l16, d.frag_off[1], M2, M1, act, h);
-        const uint64_t first_img = (uint64_t)unit * (uint64_t)(32 * T);
-        // per-iteration copy: keeps the (row < n_classes) predicates of every accumulator register of every case from being
-        // hoisted out of the persistent loop as hundreds of live 64-bit masks
-        uint32_t nc = d.n_classes;
-        asm volatile("" : "+v"(nc));
-        uint32_t cls[T];
-#pragma unroll
-        for (int t = 0; t < T; t++) cls[t] = 0;
-        uint32_t m_last = M3, k_last = M2, off_last = d.frag_off[2];
-        if (M4) {
-            hidden_layer<MMAX, SP, DBL, T>(smem, l16, d.frag_off[2], M3, M2, act, h);
-            m_last = M4; k_last = M3; off_last = d.frag_off[3];
+        if (!done) {
+            hidden_layer<MMAX, SP, DBL, T>(smem, l16, d.frag_off[1], M2, M1, act, h);
+            uint32_t m_last = M3, k_last = M2, off_last = d.frag_off[2];
+            if (M4) {
+                hidden_layer<MMAX, SP, DBL, T>(smem, l16, d.frag_off[2], M3, M2, act, h);
+                m_last = M4; k_last = M3; off_last = d.frag_off[3];
+            }
+            final_layer<MMAX, SP, T>(smem, l16, off_last, m_last, k_last, act, h, j, lane, cls, logits_out, stage, first_img, n, nc, few_classes);
         }
-        final_layer<MMAX, SP, T>(smem, l16, off_last, m_last, k_last, act, h, j, lane, cls, logits_out, stage, first_img, n, nc, d.n_classes <= 16u);
         // both halves of the wave hold every tile's result: T = 2 keeps tile 0's ids in lanes 0..31 and tile 1's in lanes 32..63
         // (one 256-byte store per unit), T = 1 stores from the lower half
         if constexpr (T == 2) cls_prev = h ? cls[1] : cls[0];   // (h: this iteration's copy)
