@@ -288,10 +288,20 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
     // logits staging area of the wave (2 KiB behind all tile buffers) when the launcher reserved one
     int32_t *const stage = d.stage ? (int32_t *)(smem + d.w_bytes + nwaves * (uint32_t)UNIT + wave * 2048u) : nullptr;
 
-    // Lane constants that stay in registers across the persistent loop: the lane id and the NV distinct DMA source offsets
-    // (DMA piece t, lane l: LDS byte 1024t + 16l = row t*RPP + rl, slot c'; source slot c = c' ^ mask(row)).  Everything else
-    // per-lane is re-derived per iteration from an opaque copy of the lane id (half a dozen VALU): left to itself hipcc hoists
-    // dozens of derived operand / fragment addresses out of the loop and spills them.
+    // Lane constants that stay in registers across the persistent loop: the lane id, the B-operand base, the fragment base and
+    // the NV distinct DMA source offsets (DMA piece t, lane l: LDS byte 1024t + 16l = row t*RPP + rl, slot c'; source slot
+    // c = c' ^ mask(row)).  The loop body works on opaque per-iteration copies of them: left to itself hipcc hoists dozens of
+    // DERIVED operand / fragment addresses out of the loop and spills them.
+    // B operand of K-step s: image j, global slot 2s+h -> LDS slot (2s+h) ^ mask(j): XOR 32*s into the byte offset rd_off
+    const uint32_t lane16 = 16u * (uint32_t)lane;
+    const uint32_t rd_off = tile_off + (uint32_t)(lane & 31) * (uint32_t)ROW + 16u * ((uint32_t)(lane >> 5) ^ G::mask((uint32_t)(lane & 31)));
+    // rows of up to 256 bytes: the K-steps' B-operand addresses themselves stay in registers (no XOR per K-step and tile)
+    constexpr bool PRE_RD = KT0 <= 8;
+    uint32_t rda[PRE_RD ? KT0 : 1];
+    if constexpr (PRE_RD) {
+#pragma unroll
+        for (int s = 0; s < KT0; s++) rda[s] = rd_off ^ (32u * (uint32_t)s);
+    }
     uint32_t voff[G::NV];
     {
         const uint32_t rl0 = (16u * (uint32_t)lane) / (uint32_t)ROW, cs0 = (uint32_t)lane & (uint32_t)(G::SLOTS - 1);
@@ -365,12 +375,11 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         if (left == 0u) work_take_issue(taken, counter + 16u * my_word, 1u);
         bnm_wait_vmcnt<0>();
         uint32_t next_unit = unit + 1u, next_left = left - 1u;
-        uint32_t lv = (uint32_t)lane;
-        asm volatile("" : "+v"(lv));
+        // per-iteration opaque copies of the three lane values the arithmetic starts from (one v_mov each): what is derived from
+        // them inside the iteration cannot be hoisted out of the persistent loop
+        uint32_t lv = (uint32_t)lane, rd = rd_off, l16 = lane16;
+        asm volatile("" : "+v"(lv), "+v"(rd), "+v"(l16));
         const int j = (int)(lv & 31u), h = (int)(lv >> 5);
-        const uint32_t l16 = 16u * lv;
-        // B operand of K-step s: image j, global slot 2s+h -> LDS slot (2s+h) ^ mask(j): XOR 32*s into the byte offset
-        const uint32_t rd = tile_off + (uint32_t)j * (uint32_t)ROW + 16u * ((uint32_t)h ^ G::mask((uint32_t)j));
         i32x4 act[T][MMAX];       // packed layer outputs = the next layer's B operands (updated in place, layer by layer)
         const uint64_t first_img = (uint64_t)unit * (uint64_t)(32 * T);
         // per-iteration copy: keeps the (row < n_classes) predicates of every accumulator register of every case from being
@@ -394,7 +403,8 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
                     for (int t = 0; t < T; t++)
 #pragma unroll
                         for (int s = 0; s < KC; s++)
-                            b0[t][s] = *(const i32x4 *)(smem + ((rd + (uint32_t)(t * G::TILE)) ^ (32u * (uint32_t)(ch * KC + s))));
+                            if constexpr (PRE_RD) b0[t][s] = *(const i32x4 *)(smem + (rda[ch * KC + s] + (uint32_t)(t * G::TILE)));
+                            else b0[t][s] = *(const i32x4 *)(smem + ((rd + (uint32_t)(t * G::TILE)) ^ (32u * (uint32_t)(ch * KC + s))));
                     if constexpr (ch == KT0 / KC - 1) {
                         retire_lds_reads();
                         if (left == 0u) {

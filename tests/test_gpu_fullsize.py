@@ -138,6 +138,54 @@ def test_cnn_many_chunks_all_kernels(gpu_ok, orc):
     ctx.close()
 
 
+def test_generic_kernel_full_size_documented_shapes(gpu_ok, orc):
+    """The generic fused kernel at BASELINE's N on the shapes the reference documents (docs/documentation.md:169-183: the 12 KB
+    family; the headline model as its 4-bit member): every form of the kernel (library's choice, one / two tiles per wave, other
+    work batches) gives the same digest and histogram over all N class ids; the first 10^6 ids equal the layer-wise ALU path's
+    (an independent implementation); head / tail / strided sample with logits against the oracle."""
+    import torch
+    n = N_FULL
+    imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+    synth.fill_device(imgs, first=0, dist=DIST_U)
+    cls = torch.empty(n, dtype=torch.int32, device="cuda")
+    for name in ("fc_4bitsym_64", "doc12k_8bit", "doc12k_2bit", "doc12k_ternary", "doc12k_binary"):
+        model = util.load_golden_model(name)
+        ctx = b.Context(model)
+        ref = None
+        forms = []
+        for variant, batch in ((7, 0), (8, 0), (4, 1), (4, 16), (4, 0)):        # the library's own choice last
+            try:
+                ctx.set_tuning(variant=variant)
+            except b.BnmError:
+                continue                      # two tiles per wave exist for the 2-tile class only
+            ctx.set_work_batch(batch)
+            cls.fill_(-1)
+            ctx.infer_device(imgs, cls)
+            d = synth.digest_device(cls, first=0, n_bins=model.num_classes).cpu().numpy()
+            assert int(d[1:].sum()) == n, (name, variant)
+            ref = d if ref is None else ref
+            assert np.array_equal(d, ref), f"{name}: generic kernel form (variant {variant}, batch {batch}) disagrees"
+            forms.append((variant, batch))
+        assert (7, 0) in forms and (4, 0) in forms, forms
+        if name == "fc_4bitsym_64" and n == 100_000_000:
+            assert int(ref[0].astype(np.uint64)) == ORACLE_DIGEST_1E8 and ref[1:].tolist() == ORACLE_HIST_1E8
+        m = min(n, 1_000_000)
+        lw = b.Context(model)
+        lw.set_path(b.PATH_LAYERWISE_ALU)
+        c2 = torch.empty(m, dtype=torch.int32, device="cuda")
+        lw.infer_device(imgs[:m], c2)
+        assert torch.equal(c2, cls[:m]), f"{name}: generic kernel != layer-wise path on the first {m} images"
+        lw.close()
+        idx = np.unique(np.concatenate([np.arange(0, 2000), np.arange(n - 2000, n), np.linspace(0, n - 1, 4000).astype(np.int64)]))
+        ti = torch.from_numpy(idx).cuda()
+        want_cls, want_lg = util.OracleModel(model, orc).infer(imgs[ti].cpu().numpy(), logits=True)
+        assert np.array_equal(cls[ti].cpu().numpy().astype(np.uint32), want_cls), name
+        lg = torch.empty((len(idx), model.num_classes), dtype=torch.int32, device="cuda")
+        ctx.infer_device(imgs[ti].contiguous(), torch.empty(len(idx), dtype=torch.int32, device="cuda"), lg)
+        assert np.array_equal(lg.cpu().numpy(), want_lg), name
+        ctx.close()
+
+
 def _oracle_parallel(model, first, count, dist, threads=None):
     """class ids + digest/histogram of [first, first+count) computed by the ORACLE on host threads (ctypes releases
     the GIL inside orc_model_batch)."""
