@@ -1158,6 +1158,10 @@ int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, in
             return fail(BNM_EHIP, "shard setup failed");
         }
     }
+    // one untimed pass per device first (clock ramp, code upload, first touch of the counters): `seconds` then is a warm launch,
+    // comparable with bench.py's per-step time
+    for (int g = 0; g < G; g++)
+        (void)bnm_infer_device(sh[g].ctx, (const int8_t *)sh[g].img.p, sh[g].count, (uint32_t *)sh[g].cls.p, nullptr, nullptr);
     for (int g = 0; g < G; g++) { (void)hipSetDevice(g); (void)hipDeviceSynchronize(); }
     const auto t0 = std::chrono::steady_clock::now();
     int rc = BNM_OK;

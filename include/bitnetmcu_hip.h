@@ -268,7 +268,8 @@ BNM_API int bnm_stream_read_device(const void *d_src, uint64_t bytes, uint32_t *
  * Shards the global synthetic image stream [0, n_total) contiguously over the first n_gpus visible devices
  * (n_gpus <= 0: all), generates every shard on its own GPU, runs the whole-model path on all of them concurrently and
  * returns the combined order-independent digest + class histogram (digest_hist[0], digest_hist[1..n_bins]) and the
- * wall-clock seconds of the inference phase.  No image byte crosses a link; the model is uploaded to each device.
+ * wall-clock seconds of the inference phase (one warm pass over all shards, after an untimed one).  No image byte crosses a link;
+ * the model (~13 KB) is uploaded to each device by the host (PyTorch hosts broadcast it over RCCL instead, bench.py).
  * Returns the number of GPUs used (> 0) or a negative BNM_E* code. */
 BNM_API int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, int dist, uint64_t seed,
                                     uint64_t *digest_hist, uint32_t n_bins, double *seconds);
