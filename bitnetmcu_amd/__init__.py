@@ -5,10 +5,10 @@ does the work, this package loads exporter-written ``BitNetMCU_model.h`` files, 
 launches.  PyTorch is used only for device memory, streams and torch.distributed.
 """
 from ._lib import (BnmError, LayerInfo, load, LIB_PATH, PATH_AUTO, PATH_FUSED_MFMA, PATH_LAYERWISE_ALU,
-                   PATH_TERNARY_ALU, DIST_U, DIST_M, SEED_DIST_U, SEED_DIST_M, KIND_FC, KIND_CNN)
+                   PATH_TERNARY_ALU, PATH_LAYERWISE_MFMA, DIST_U, DIST_M, SEED_DIST_U, SEED_DIST_M, KIND_FC, KIND_CNN)
 from .model import Model, Context
 from . import harness, synth, dist, evaluate
 
 __all__ = ["BnmError", "LayerInfo", "load", "LIB_PATH", "Model", "Context", "harness", "synth", "dist", "evaluate",
-           "PATH_AUTO", "PATH_FUSED_MFMA", "PATH_LAYERWISE_ALU", "PATH_TERNARY_ALU", "DIST_U", "DIST_M",
+           "PATH_AUTO", "PATH_FUSED_MFMA", "PATH_LAYERWISE_ALU", "PATH_TERNARY_ALU", "PATH_LAYERWISE_MFMA", "DIST_U", "DIST_M",
            "SEED_DIST_U", "SEED_DIST_M", "KIND_FC", "KIND_CNN"]

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("BNM_LIBRARY") or os.path.join(HERE, "libbitnetmcu_hip
 BNM_OK = 0
 KIND_FC, KIND_CNN = 0, 1
 LAYER_FC, LAYER_CONV, LAYER_POOL = 1, 2, 3
-PATH_AUTO, PATH_FUSED_MFMA, PATH_LAYERWISE_ALU, PATH_TERNARY_ALU = 0, 1, 2, 3
+PATH_AUTO, PATH_FUSED_MFMA, PATH_LAYERWISE_ALU, PATH_TERNARY_ALU, PATH_LAYERWISE_MFMA = 0, 1, 2, 3, 4
 DIST_U, DIST_M = 0, 1
 SEED_DIST_U, SEED_DIST_M = 0xB17E7001, 0xB17E7002
 

@@ -148,6 +148,7 @@ struct FcDev {
     void *packed = nullptr;
     int8_t *rows_lo = nullptr, *rows_hi = nullptr;
     uint32_t row_stride = 0;
+    bool has_hi = false;      // the layer holds an FP1.3.0 +128 (second weight plane in use)
 };
 
 }  // namespace
@@ -188,6 +189,7 @@ struct bnm_ctx {
     int tern_variant = 2;         // 2: streamed weights, two images per lane (default); 1: one image per lane; 0: round 1's kernel
     int requested_path = BNM_PATH_AUTO, path = BNM_PATH_LAYERWISE_ALU;
     bool warned_layerwise = false;
+    bool all_known = false;       // every FC layer's codec is one the C engine decodes (=> int8 rows, the MFMA layer-wise path)
     std::string fused_reason = "unknown";   // why fused_ok is false
 #ifdef BNM_DIAG
     uint64_t diag_src_wrap = 0;
@@ -234,15 +236,20 @@ int resolve_path(bnm_ctx *c) {
         if (c->fused_ok) want = BNM_PATH_FUSED_MFMA;
         else if (c->model.kind == BNM_KIND_FC && all_tern && c->tern_ok) want = BNM_PATH_TERNARY_ALU;
         else {
-            want = BNM_PATH_LAYERWISE_ALU;
-            // no silent cliffs: this path is orders of magnitude slower than the fused kernels
+            // no silent cliffs: one kernel per layer with int32 sums through HBM - on the matrix cores when every codec decodes
+            // to int8 rows (an order of magnitude below the fused kernels), else the bit-serial kernel (~500x below)
+            want = c->all_known ? BNM_PATH_LAYERWISE_MFMA : BNM_PATH_LAYERWISE_ALU;
             if (!c->warned_layerwise && !std::getenv("BNM_QUIET")) {
-                std::fprintf(stderr, "bitnetmcu_hip: model is outside the fused MFMA kernels (%s); using the layer-wise ALU "
-                                     "path, which is about 500x slower\n", c->fused_reason.c_str());
+                std::fprintf(stderr, "bitnetmcu_hip: model is outside the fused MFMA kernels (%s); using the layer-wise %s\n",
+                             c->fused_reason.c_str(),
+                             c->all_known ? "MFMA path (one GEMM kernel per layer, sums through HBM: about 10-30x slower than a fused kernel)"
+                                          : "ALU path, which is about 500x slower");
                 c->warned_layerwise = true;
             }
         }
     }
+    if (want == BNM_PATH_LAYERWISE_MFMA && !c->all_known)
+        return fail(BNM_EUNSUPPORTED, "the layer-wise MFMA path needs codecs the C engine decodes (int8 rows) in every layer");
     if (want == BNM_PATH_FUSED_MFMA && !c->fused_ok)
         return fail(BNM_EUNSUPPORTED, "model shape/codec is outside the fused MFMA kernel table");
     if (want == BNM_PATH_TERNARY_ALU && !(c->tern_ok && c->model.kind == BNM_KIND_FC))
@@ -386,15 +393,17 @@ int ctx_build(bnm_ctx *c) {
             // -128 fits.  Trained models rarely contain it (mcu/BitNetMCU_model_12k_FP130.h has none), so the
             // two-pass kernel is selected only when the packed words actually hold such a nibble.
             const uint32_t *w = (const uint32_t *)L.weights.data();
-            for (size_t k = 0; k < L.weights.size() / 4 && !any_fp130; k++)
+            for (size_t k = 0; k < L.weights.size() / 4 && !d.has_hi; k++)
                 for (int nib = 0; nib < 8; nib++)
-                    if (((w[k] >> (4 * nib)) & 15u) == 7u) { any_fp130 = true; break; }
+                    if (((w[k] >> (4 * nib)) & 15u) == 7u) { d.has_hi = true; break; }
+            any_fp130 = any_fp130 || d.has_hi;
         }
         all_tern = all_tern && L.info.bits_per_weight == 64;
         width = L.info.n_output;
         c->fc.push_back(d);
     }
 
+    c->all_known = all_known;
     // ---- fused MFMA path: shape + fragment buffers ------------------------------------------------------
     const size_t nfc = c->fc.size();
     c->in_width = in_width;
@@ -536,30 +545,38 @@ int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32
     return BNM_OK;
 }
 
-// FC chain layer by layer on [n][in_stride] int8 inputs; n <= kChunk
+// FC chain layer by layer on [n][in_stride] int8 inputs; n <= kChunk.  mfma: the layers as int8 GEMMs on the matrix cores
+// (bnmk_fc_layer_mfma; activation rows padded to 32-byte K-steps) instead of the bit-serial kernel.
 int run_layerwise(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32_t *d_logits, int8_t *d_acts_tap,
-                  uint32_t tap_stride, uint32_t tap_off, hipStream_t s) {
+                  uint32_t tap_stride, uint32_t tap_off, bool mfma, hipStream_t s) {
     uint32_t maxw = 0;
     for (auto &l : c->fc) maxw = l.info.n_output > maxw ? l.info.n_output : maxw;
+    const uint32_t maxs = mfma ? round_up(maxw, 32) : maxw;      // stride of the scratch activation rows
     bnm_ctx::StreamScratch &sc = stream_scratch(c, s);
-    if (int e = sc.act_a.ensure((size_t)n * maxw)) return e;
-    if (int e = sc.act_b.ensure((size_t)n * maxw)) return e;
+    if (int e = sc.act_a.ensure((size_t)n * maxs + 64)) return e;
+    if (int e = sc.act_b.ensure((size_t)n * maxs + 64)) return e;
     if (int e = sc.out32.ensure((size_t)n * maxw * 4)) return e;
     const int8_t *act = d_in;
+    uint32_t act_stride = c->fc[0].act_stride;
     int8_t *bufs[2] = {(int8_t *)sc.act_a.p, (int8_t *)sc.act_b.p};
     for (size_t i = 0; i < c->fc.size(); i++) {
         const FcDev &d = c->fc[i];
         const bool last = i + 1 == c->fc.size();
         int32_t *out = (last && d_logits) ? d_logits : (int32_t *)sc.out32.p;
-        HIP_TRY(bnmk_fc_layer(act, d.act_stride, d.packed, d.info.bits_per_weight, d.info.n_input, d.info.n_output, out, n, s));
+        if (mfma)
+            HIP_TRY(bnmk_fc_layer_mfma(act, act_stride, d.rows_lo, d.has_hi ? d.rows_hi : nullptr, d.row_stride, d.info.n_output, out, n, s));
+        else
+            HIP_TRY(bnmk_fc_layer(act, act_stride, d.packed, d.info.bits_per_weight, d.info.n_input, d.info.n_output, out, n, s));
         int8_t *nxt = bufs[i & 1];
-        HIP_TRY(bnmk_relunorm(out, d.info.n_output, nxt, d.info.n_output, last ? d_cls : nullptr, n, s));
+        const uint32_t nxt_stride = mfma ? round_up(d.info.n_output, 32) : d.info.n_output;
+        HIP_TRY(bnmk_relunorm(out, d.info.n_output, nxt, nxt_stride, last ? d_cls : nullptr, n, s));
         if (d_acts_tap) {
-            HIP_TRY(hipMemcpy2DAsync(d_acts_tap + tap_off, tap_stride, nxt, d.info.n_output, d.info.n_output, n,
+            HIP_TRY(hipMemcpy2DAsync(d_acts_tap + tap_off, tap_stride, nxt, nxt_stride, d.info.n_output, n,
                                      hipMemcpyDeviceToDevice, s));
             tap_off += d.info.n_output;
         }
         act = nxt;
+        act_stride = nxt_stride;
     }
     return BNM_OK;
 }
@@ -599,7 +616,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         for (uint64_t off = 0; off < n; off += kChunk) {
             uint64_t cn = n - off < kChunk ? n - off : kChunk;
             if (int e = run_layerwise(c, d_images + off * 256, cn, d_cls + off, d_logits ? d_logits + off * ncls : nullptr,
-                                      d_acts_tap ? d_acts_tap + off * tap_stride : nullptr, tap_stride, 0, s))
+                                      d_acts_tap ? d_acts_tap + off * tap_stride : nullptr, tap_stride, 0, path == BNM_PATH_LAYERWISE_MFMA, s))
                 return e;
         }
         return BNM_OK;
@@ -633,7 +650,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
             if (int e = run_fused(c, acts, cn, cls, lg, s)) return e;
         } else {
             if (int e = run_layerwise(c, acts, cn, cls, lg, d_acts_tap ? d_acts_tap + off * tap_stride : nullptr, tap_stride,
-                                      d_acts_tap ? W : 0, s))
+                                      d_acts_tap ? W : 0, path == BNM_PATH_LAYERWISE_MFMA, s))
                 return e;
         }
     }
@@ -752,7 +769,7 @@ void bnm_ctx_destroy(bnm_ctx *c) {
 int bnm_ctx_device(const bnm_ctx *c) { return c ? c->device : -1; }
 
 int bnm_ctx_set_path(bnm_ctx *c, int path) {
-    if (!c || path < BNM_PATH_AUTO || path > BNM_PATH_TERNARY_ALU) return fail(BNM_EINVAL, "bad path");
+    if (!c || path < BNM_PATH_AUTO || path > BNM_PATH_LAYERWISE_MFMA) return fail(BNM_EINVAL, "bad path");
     std::lock_guard<std::mutex> g(c->mu);
     int old = c->requested_path;
     c->requested_path = path;

@@ -101,6 +101,9 @@ hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int tiles, int 
 hipError_t bnmk_fc_layer(const int8_t *d_act, uint32_t act_stride, const void *d_packed, int32_t bpw,
                          uint32_t n_input, uint32_t n_output, int32_t *d_out, uint64_t batch,
                          hipStream_t s);
+// the same layer on the matrix cores from the unpacked int8 rows (any width; see bnm_layerwise.hip)
+hipError_t bnmk_fc_layer_mfma(const int8_t *d_act, uint32_t act_stride, const int8_t *d_rows_lo, const int8_t *d_rows_hi,
+                              uint32_t row_stride, uint32_t n_output, int32_t *d_out, uint64_t batch, hipStream_t s);
 hipError_t bnmk_relunorm(const int32_t *d_in, uint32_t n, int8_t *d_out, uint32_t out_stride,
                          uint32_t *d_argmax, uint64_t batch, hipStream_t s);
 hipError_t bnmk_conv33(const int32_t *d_in, const int8_t *d_w, uint32_t xy, uint32_t n_shift,

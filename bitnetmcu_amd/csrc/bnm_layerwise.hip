@@ -103,6 +103,83 @@ hipError_t bnmk_fc_layer(const int8_t *act, uint32_t act_stride, const void *pac
     return hipGetLastError();
 }
 
+// =================================================================================================
+// One FC layer of a batch on the matrix cores: out[img][neuron] = sum_k act[img][k] * w[neuron][k], int8 x int8 -> int32,
+// any layer width, any input length.  The layer-wise path of models that fit no fused kernel (a layer wider than 256
+// outputs, input rows longer than 512 bytes, fragments beyond LDS): every codec the C engine decodes unpacks to int8 rows
+// (FP1.3.0's +128: a second plane), so processfclayer (BitNetMCU_inference.c:88-208) is an integer GEMM whatever the width.
+// A wave computes a 32-image x (MT x 32)-neuron block with v_mfma_i32_32x32x32_i8: B operand = 16 activation bytes of image
+// j = lane & 31 straight from its row, A operand = 16 weight bytes of neuron row i straight from the unpacked rows (L2-resident),
+// natural K order on both sides; every activation load feeds MT MFMAs.  Rows and activations are padded to 32-byte K-steps:
+// the rows' padding is zero, so whatever the activation bytes behind a short row are (the next image's, scratch) is harmless.
+// Not tuned to a roofline - it only has to keep shapes outside the fused kernels off the bit-serial kernel (~20x slower).
+// =================================================================================================
+template <int MT>
+__global__ __launch_bounds__(256) void fc_layer_mfma_kernel(const int8_t *__restrict__ act, uint32_t act_stride,
+                                                            const int8_t *__restrict__ rows_lo, const int8_t *__restrict__ rows_hi,
+                                                            uint32_t row_stride, uint32_t kt, uint32_t n_output,
+                                                            int32_t *__restrict__ out, uint64_t batch) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const uint64_t tile = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);      // 32-image tile
+    const uint32_t m0 = blockIdx.y * (uint32_t)MT;                               // first 32-neuron tile of this wave
+    if (tile * 32ull >= batch) return;
+    uint64_t img = tile * 32ull + (uint64_t)j;
+    const bool live = img < batch;
+    if (!live) img = batch - 1ull;
+    const int8_t *ap = act + img * (uint64_t)act_stride + 16 * h;
+    i32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = 0;
+    for (uint32_t s = 0; s < kt; s++) {
+        const i32x4 b = *(const i32x4 *)(ap + 32u * s);
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            const size_t wo = (size_t)(32u * (m0 + (uint32_t)m) + (uint32_t)j) * row_stride + 32u * s + 16u * (uint32_t)h;
+            acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const i32x4 *)(rows_lo + wo), b, acc[m], 0, 0, 0);
+            if (rows_hi != nullptr) acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const i32x4 *)(rows_hi + wo), b, acc[m], 0, 0, 0);
+        }
+    }
+    if (!live) return;
+    // lane (j, h), register 4q + e of tile m: neuron 32 (m0 + m) + 8 q + 4 h + e of image j - four consecutive outputs per quad
+    typedef int v4a4 __attribute__((ext_vector_type(4), aligned(4)));
+    int32_t *dst = out + img * (uint64_t)n_output;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t row = 32u * (m0 + (uint32_t)m) + 8u * q + 4u * (uint32_t)h;
+            if (row + 4u <= n_output) {
+                *(v4a4 *)(dst + row) = v4a4{acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (row + (uint32_t)e < n_output) dst[row + e] = acc[m][4 * q + e];
+            }
+        }
+}
+
+// rows_lo / rows_hi: unpacked int8 rows [round32(n_output)][row_stride] (rows past n_output zero; rows_hi nullptr unless the
+// layer holds FP1.3.0's +128), row_stride a multiple of 32 >= the layer's real inputs; act rows 16-byte aligned with at least
+// row_stride readable bytes behind the last row's start.
+hipError_t bnmk_fc_layer_mfma(const int8_t *act, uint32_t act_stride, const int8_t *rows_lo, const int8_t *rows_hi, uint32_t row_stride,
+                              uint32_t n_output, int32_t *out, uint64_t batch, hipStream_t s) {
+    if (!batch || !n_output) return hipSuccess;
+    if ((row_stride & 31u) || (act_stride & 15u) || ((uintptr_t)act & 15u)) return hipErrorInvalidValue;
+    const uint32_t tiles = (n_output + 31u) / 32u, kt = row_stride / 32u;
+    const uint64_t gx = (batch + 127ull) / 128ull;           // 4 waves = 4 image tiles per workgroup
+    if (gx > 0x7fffffffull) return hipErrorInvalidValue;
+    if (tiles >= 4 && tiles % 4 == 0)
+        fc_layer_mfma_kernel<4><<<dim3((unsigned)gx, tiles / 4u), dim3(256), 0, s>>>(act, act_stride, rows_lo, rows_hi, row_stride, kt, n_output, out, batch);
+    else if (tiles % 2 == 0)
+        fc_layer_mfma_kernel<2><<<dim3((unsigned)gx, tiles / 2u), dim3(256), 0, s>>>(act, act_stride, rows_lo, rows_hi, row_stride, kt, n_output, out, batch);
+    else
+        fc_layer_mfma_kernel<1><<<dim3((unsigned)gx, tiles), dim3(256), 0, s>>>(act, act_stride, rows_lo, rows_hi, row_stride, kt, n_output, out, batch);
+    return hipGetLastError();
+}
+
 // ReLUNorm, one wavefront per vector.  All inputs are read before any output is written, so `out` may
 // alias `in` exactly as BitNetMCU_MNIST_dll.c:80 uses it.
 __global__ __launch_bounds__(256) void relunorm_kernel(const int32_t *in, uint32_t n, int8_t *out, uint32_t out_stride,

@@ -126,10 +126,12 @@ BNM_API void bnm_ctx_destroy(bnm_ctx *c);
 BNM_API int bnm_ctx_device(const bnm_ctx *c);
 
 /* Kernel selection for the whole-model path. */
-#define BNM_PATH_AUTO 0      /* the fastest bit-exact kernel: fused MFMA wherever the model fits it (ternary included), else ALU */
+#define BNM_PATH_AUTO 0      /* the fastest bit-exact kernel: fused MFMA wherever the model fits it (ternary included), else layer-wise */
 #define BNM_PATH_FUSED_MFMA 1
 #define BNM_PATH_LAYERWISE_ALU 2   /* one bit-serial kernel per layer (the reference's structure) */
 #define BNM_PATH_TERNARY_ALU 3     /* fused sign-accumulate kernel, no MFMA (ternary models) */
+#define BNM_PATH_LAYERWISE_MFMA 4  /* one int8 GEMM kernel per layer on the matrix cores + ReLUNorm kernel: ANY widths (what AUTO
+                                    * falls back to for models outside the fused kernels) */
 BNM_API int bnm_ctx_set_path(bnm_ctx *c, int path);
 BNM_API int bnm_ctx_get_path(const bnm_ctx *c);   /* the path AUTO resolved to */
 /* Tuning knobs of the fused kernel: variant id (0 direct loads, 1 LDS-DMA, 2 LDS-DMA with two tiles in flight,

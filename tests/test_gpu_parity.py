@@ -19,6 +19,11 @@ def paths_for(ctx):
     """(label, setup) for every kernel path this model can run."""
     out = [("auto", lambda c: c.set_path(b.PATH_AUTO))]
     out.append(("layerwise", lambda c: c.set_path(b.PATH_LAYERWISE_ALU)))
+    try:        # one int8 GEMM kernel per layer on the matrix cores (every codec the C engine decodes)
+        ctx.set_path(b.PATH_LAYERWISE_MFMA)
+        out.append(("layerwise_mfma", lambda c: c.set_path(b.PATH_LAYERWISE_MFMA)))
+    except b.BnmError:
+        pass
     # 4 = the generic kernel (run-time widths, weights in LDS; 7 / 8 = the same with one / two image tiles per wave forced),
     # 5 / 6 = dual-tile loop with a CU-shared / device-wide work counter
     for v in (0, 1, 2, 3, 4, 5, 6, 7, 8):
@@ -739,14 +744,67 @@ def test_random_cnn_channel_counts_through_the_generic_tail(C, codecs, widths, n
     ctx.close()
 
 
-def test_too_wide_model_falls_back_loudly_and_stays_exact(gpu_ok, orc, capfd):
-    """Shapes beyond the fused kernels (a layer wider than 256) run on the layer-wise path — with a warning, not silently."""
-    rng = np.random.default_rng(9)
-    model = b.Model.from_header_text(_random_model_text(rng, (4, 4, 4, 4), (320, 64, 64)))
+@pytest.mark.parametrize("codecs,widths,n_classes", [
+    ((4, 4, 4, 4), (320, 64, 64), 10),          # one layer wider than 256
+    ((4, 2, 1, 4), (512, 512, 512), 10),        # everything wide: 16 tiles per layer, binary / 2-bit / 4-bit
+    ((16, 16, 16, 16), (300, 200, 100), 26),    # 8-bit, widths that are not multiples of 32
+    ((20, 20, 20, 20), (288, 96, 64), 10),      # FP1.3.0 with +128 present: second weight plane
+    ((64, 64, 64, 64), (384, 120, 96), 10),     # ternary, exporter padding (260 / 390 / 120 / 100 declared inputs)
+    ((4, 4, 4), (272, 40), 47),                 # three layers
+])
+def test_models_outside_the_fused_kernels_run_layerwise_on_the_matrix_cores(codecs, widths, n_classes, gpu_ok, orc, capfd):
+    """Shapes beyond the fused kernels (a layer wider than 256 outputs) used to fall to the bit-serial layer-wise kernels, a
+    500x cliff.  They now run one int8 GEMM kernel per layer on the matrix cores (any widths) - loudly (a warning names the
+    reason), bit-exact in class ids and logits against the oracle, and equal to the bit-serial path."""
+    rng = np.random.default_rng(hash((codecs, widths, n_classes)) % 2**32)
+    model = b.Model.from_header_text(_random_model_text(rng, codecs, widths, n_classes))
     ctx = b.Context(model)
-    assert ctx.path == b.PATH_LAYERWISE_ALU
-    assert "layer-wise ALU" in capfd.readouterr().err
-    x = synth.images(0, 500, DIST_U)
+    assert ctx.path == b.PATH_LAYERWISE_MFMA
+    err = capfd.readouterr().err
+    assert "layer-wise MFMA path" in err and "wider than 256" in err
+    om = util.OracleModel(model, orc)
+    for n in (1, 31, 33, 127, 1000, 4097):
+        x = np.concatenate([synth.images(11, n, DIST_U)[: (n + 1) // 2], synth.images(11, n, DIST_M)[: n // 2]])
+        want = om.infer(x, logits=True)
+        got = ctx.infer(x, logits=True)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (widths, n)
+        assert np.array_equal(ctx.infer(x), want[0])
+    edge = np.concatenate([np.zeros((3, 256), np.int8), np.full((3, 256), -128, np.int8), np.full((3, 256), 127, np.int8)])
+    want = om.infer(edge, logits=True)
+    got = ctx.infer(edge, logits=True)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ctx.set_path(b.PATH_LAYERWISE_ALU)
+    got = ctx.infer(edge, logits=True)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    with pytest.raises(b.BnmError):
+        ctx.set_path(b.PATH_FUSED_MFMA)
+    ctx.close()
+
+
+def test_unknown_codec_keeps_the_bit_serial_path(gpu_ok, orc, capfd):
+    """A codec the C engine does not decode (NF4's id 36: every sum is 0, BitNetMCU_inference.c:202) has no int8 rows: such a model
+    stays on the bit-serial layer-wise kernels, which restate the C branches one by one."""
+    rng = np.random.default_rng(36)
+    model = b.Model.from_header_text(_random_model_text(rng, (4, 36, 4, 4), (64, 64, 64)))
+    ctx = b.Context(model)
+    assert ctx.path == b.PATH_LAYERWISE_ALU and "layer-wise ALU" in capfd.readouterr().err
+    with pytest.raises(b.BnmError):
+        ctx.set_path(b.PATH_LAYERWISE_MFMA)
+    x = synth.images(0, 300, DIST_U)
+    want = util.OracleModel(model, orc).infer(x, logits=True)
+    got = ctx.infer(x, logits=True)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ctx.close()
+
+
+def test_wide_cnn_tail_runs_layerwise_on_the_matrix_cores(gpu_ok, orc):
+    """160 channels: 640-byte act rows are longer than the fused kernels' 512 - the front end (three channel groups) feeds the
+    layer-wise MFMA tail."""
+    rng = np.random.default_rng(160)
+    model = b.Model.from_header_text(_random_cnn_text(rng, 160, (2, 4, 4), (96, 64), 10))
+    ctx = b.Context(model)
+    assert ctx.path == b.PATH_LAYERWISE_MFMA
+    x = np.concatenate([synth.images(3, 150, DIST_U), synth.images(3, 151, DIST_M)])
     want = util.OracleModel(model, orc).infer(x, logits=True)
     got = ctx.infer(x, logits=True)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
