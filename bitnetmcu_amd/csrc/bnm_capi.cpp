@@ -289,7 +289,12 @@ bool stream_is_capturing(hipStream_t s) {
 // return to the free list.  Device-synchronising; called when the per-stream tables have grown to kMaxStreams entries (a host
 // that cycles through short-lived streams would otherwise grow them without bound) - never while `keep` is capturing.
 void evict_other_streams(bnm_ctx *c, hipStream_t keep) {
-    (void)hipDeviceSynchronize();
+    // a device-wide synchronisation would invalidate a stream capture in progress: not while any stream the context knows captures
+    for (auto &kv : c->scratch)
+        if (stream_is_capturing(kv.first)) return;
+    for (auto &kv : c->work_of)
+        if (stream_is_capturing(kv.first)) return;
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return; }
     for (auto it = c->scratch.begin(); it != c->scratch.end();) {
         if (it->first == keep) { ++it; continue; }
         for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat}) b->release();
