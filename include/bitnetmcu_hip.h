@@ -135,10 +135,10 @@ BNM_API int bnm_ctx_device(const bnm_ctx *c);
 BNM_API int bnm_ctx_set_path(bnm_ctx *c, int path);
 BNM_API int bnm_ctx_get_path(const bnm_ctx *c);   /* the path AUTO resolved to */
 /* Tuning knobs of the fused kernel: variant id (0 direct loads, 1 LDS-DMA, 2 LDS-DMA with two tiles in flight,
- * 3 two tiles per wavefront per iteration with a fixed stride, 4 the generic kernel, 5 as 3 with the CU's waves sharing an
- * LDS work counter, 6 as 3 with batches from the device-wide work counter (default where instantiated); -1 keeps the
- * current one) and grid size (workgroups; 0 = default).  BNM_EUNSUPPORTED if the model's shape has no
- * such instantiation. */
+ * 3 two tiles per wavefront per iteration with a fixed stride, 4 the generic kernel (any widths), 5 as 3 with the CU's waves
+ * sharing an LDS work counter, 6 as 3 with batches from the device-wide work counter (default where instantiated), 7 / 8 the
+ * generic kernel with one / two image tiles per wave forced; -1 keeps the current one) and grid size
+ * (workgroups; 0 = default).  BNM_EUNSUPPORTED if the model's shape has no such instantiation. */
 BNM_API int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks);
 /* the fused-kernel variant in use, or -1 when the resolved path is not the fused kernel */
 BNM_API int bnm_ctx_get_variant(const bnm_ctx *c);
@@ -172,12 +172,15 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
  * 2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the all-VALU kernel
  * of round 1 (2, 100 + g and 0 are kept for A/B measurements). */
 BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
-/* Fused kernels that hand their work out from the device-wide counter: 32-image tiles (generic kernel, variant 4; default 4)
- * or 64-image pairs (dual-tile kernel, variant 6; default 2) a wave takes at a time; 0 = default. */
+/* Fused kernels that hand their work out from the device-wide counter: units of one or two 32-image tiles (generic kernel,
+ * variants 4 / 7 / 8; default 4 / 4 / 2) or 64-image pairs (dual-tile kernel, variant 6; default 2) a wave takes at a time;
+ * 0 = default. */
 BNM_API int bnm_ctx_set_work_batch(bnm_ctx *c, int tiles);
-/* Ternary ALU kernel: 2 (default) weights streamed through double-buffered scalar registers, two images per lane, image
- * groups handed out from a device-wide work counter; 1 the same with one image per lane; 12 / 11: as 2 / 1 with a fixed
- * stride per wave; 0 round 1's kernel (1, 11, 12 and 0 are kept for A/B measurements). */
+/* Ternary ALU kernels (BNM_PATH_TERNARY_ALU; ternary FC models 256-H1-H2-H3-N with (H1, H2, H3) one of 96-96-96, 128-128-112,
+ * 64-64-64, 128-128-128).  96-96-96: 2 (default) weights streamed through double-buffered scalar registers, two images per lane,
+ * image groups handed out from a device-wide work counter; 1 the same with one image per lane; 12 / 11: as 2 / 1 with a fixed
+ * stride per wave; 0 the plain ALU kernel (1, 11, 12 and 0 are kept for A/B measurements).  The other shapes: 0 only
+ * (BNM_EUNSUPPORTED otherwise). */
 BNM_API int bnm_ctx_set_ternary_variant(bnm_ctx *c, int variant);
 /* Tuning of the host-pointer path.  mode 0 (default): pipelined page-locked staging; 1: the HIP runtime's own pageable copies,
  * chunk by chunk.  copy_threads: host threads of the staging copy (0 = default).  spin: poll the page-locked result words of the
