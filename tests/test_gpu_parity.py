@@ -781,6 +781,44 @@ def test_models_outside_the_fused_kernels_run_layerwise_on_the_matrix_cores(code
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_random_models_every_available_path(seed, gpu_ok, orc):
+    """Seeded fuzz over what the exporter can produce: 3 or 4 layers, a codec per layer out of all seven, widths from 8 to 320
+    (whatever the next layer's packing allows: n_in x bits a multiple of 32, exportquant.py:97-98), 2 to 64 classes.  The library's
+    own choice of kernel (fused specialised / generic - uniform or general path, any tile class - or layer-wise MFMA) and every
+    other path the model can run must reproduce the oracle's class ids and logits on synthetic + extreme images, ragged sizes."""
+    rng = np.random.default_rng(7000 + seed)
+    n_layers = int(rng.choice([3, 4]))
+    codecs = tuple(int(c) for c in rng.choice([1, 2, 4, 12, 16, 20, 64], size=n_layers))
+    need = {1: 32, 2: 16, 4: 8, 12: 8, 20: 8, 16: 4, 64: 8}       # input count granularity of a layer with this codec
+    widths = []
+    for k in range(1, n_layers):
+        g = need[codecs[k]]
+        hi = int(rng.choice([64, 128, 200, 320]))
+        widths.append(int(rng.integers(1, hi // g + 1)) * g)
+    n_classes = int(rng.integers(2, 65))
+    os.environ["BNM_QUIET"] = "1"
+    try:
+        model = b.Model.from_header_text(_random_model_text(rng, codecs, tuple(widths), n_classes))
+        ctx = b.Context(model)
+    finally:
+        os.environ.pop("BNM_QUIET", None)
+    om = util.OracleModel(model, orc)
+    x = np.concatenate([synth.images(seed, 333, DIST_U), synth.images(seed, 334, DIST_M), np.zeros((2, 256), np.int8),
+                        np.full((2, 256), -128, np.int8), np.full((2, 256), 127, np.int8)])
+    want = om.infer(x, logits=True)
+    assert ctx.path in (b.PATH_FUSED_MFMA, b.PATH_LAYERWISE_MFMA), (codecs, widths)
+    tried = []
+    for label, setup in paths_for(ctx):
+        setup(ctx)
+        for n in (len(x), 65, 1):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (codecs, widths, n_classes, label, n)
+        tried.append(label)
+    assert "auto" in tried and "layerwise" in tried and "layerwise_mfma" in tried, tried
+    ctx.close()
+
+
 def test_unknown_codec_keeps_the_bit_serial_path(gpu_ok, orc, capfd):
     """A codec the C engine does not decode (NF4's id 36: every sum is 0, BitNetMCU_inference.c:202) has no int8 rows: such a model
     stays on the bit-serial layer-wise kernels, which restate the C branches one by one."""
