@@ -819,6 +819,32 @@ def test_fuzz_random_models_every_available_path(seed, gpu_ok, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_random_cnn_models(seed, gpu_ok, orc):
+    """The CNN topology (BitNetMCU_MNIST_dll.c:48-91) with 4 to 96 channels, random conv weights, a random codec per FC layer and
+    random tail widths: front end (MFMA and round 1's VALU kernel) + whichever tail the model gets, ids and logits vs the oracle."""
+    rng = np.random.default_rng(9100 + seed)
+    C = 4 * int(rng.integers(1, 25))
+    codecs = tuple(int(c) for c in rng.choice([1, 2, 4, 12, 16], size=3))
+    need = {1: 32, 2: 16, 4: 8, 12: 8, 16: 4}
+    if (4 * C) % need[codecs[0]]:
+        codecs = (16,) + codecs[1:]          # 4 C act bytes are a multiple of 16: any codec but binary / 2-bit fits every C
+    widths = tuple(int(rng.integers(1, 128 // need[codecs[k]] + 1)) * need[codecs[k]] for k in (1, 2))
+    n_classes = int(rng.integers(2, 41))
+    model = b.Model.from_header_text(_random_cnn_text(rng, C, codecs, widths, n_classes))
+    om = util.OracleModel(model, orc)
+    x = np.concatenate([synth.images(seed, 120, DIST_U), synth.images(seed, 121, DIST_M), np.full((2, 256), -128, np.int8),
+                        np.full((2, 256), 127, np.int8)])
+    want = om.infer(x, logits=True)
+    ctx = b.Context(model)
+    for variant in (1, 0):
+        ctx.set_cnn_variant(variant)
+        for n in (len(x), 5):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, codecs, widths, n_classes, variant, n)
+    ctx.close()
+
+
 def test_unknown_codec_keeps_the_bit_serial_path(gpu_ok, orc, capfd):
     """A codec the C engine does not decode (NF4's id 36: every sum is 0, BitNetMCU_inference.c:202) has no int8 rows: such a model
     stays on the bit-serial layer-wise kernels, which restate the C branches one by one."""
