@@ -245,7 +245,7 @@ def _setup(ctx, path, variant):
 @pytest.mark.parametrize("name,path,variant,n", [("fc_4bitsym_64", 0, 6, 300_007), ("fc_4bitsym_64", 0, 4, 300_007),
                                                  ("tern_96", 3, -1, 150_001), ("tern_96", 1, -1, 150_001), ("cnn_64", 0, -1, 60_013)])
 def test_many_launches_on_three_streams(name, path, variant, n, gpu_ok):
-    """120 launches of ONE context queued on three streams at once, far more than any ring could hold: every stream owns its counter
+    """360 launches of ONE context queued on three streams at once, far more than any ring could hold: every stream owns its counter
     block, and every kernel leaves it zeroed for the stream's next launch (no memset between launches).  A launch that found a dirty
     or shared counter would skip or repeat tiles; every result must equal the single-stream result."""
     import torch
@@ -261,9 +261,10 @@ def test_many_launches_on_three_streams(name, path, variant, n, gpu_ok):
         inputs.append((x, want))
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in range(3)]
-    outs = [(inputs[(k * 7) % 4][1], torch.full((len(inputs[(k * 7) % 4][0]),), -1, dtype=torch.int32, device="cuda")) for k in range(120)]
+    launches = 360
+    outs = [(inputs[(k * 7) % 4][1], torch.full((len(inputs[(k * 7) % 4][0]),), -1, dtype=torch.int32, device="cuda")) for k in range(launches)]
     torch.cuda.synchronize()          # the fills ran on the default stream, which the side streams do not wait for
-    for k in range(120):
+    for k in range(launches):
         with torch.cuda.stream(streams[k % 3]):
             ctx.infer_device(inputs[(k * 7) % 4][0], outs[k][1])
     torch.cuda.synchronize()
