@@ -392,6 +392,10 @@ def main():
             out["extra_configs"] = extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read)
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(b, a.model, a.dist, a.cpu_seconds)
+            if "extra_configs" in out and a.model == "fc_4bitsym_64":
+                # configs[2] / configs[3]: the reference's CPU path on the same host cores, a quarter of the headline's sample each
+                for row, name in (("ternary_alu", "tern_96"), ("cnn_64", "cnn_64")):
+                    out["extra_configs"][row]["cpu_baseline"] = cpu_baseline(b, name, 0, max(1.0, a.cpu_seconds / 4))
         print(json.dumps(out), flush=True)
     if distributed:
         td.barrier()

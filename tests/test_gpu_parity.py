@@ -494,6 +494,8 @@ def test_bench_json_contract(gpu_ok):
             assert ex[k]["roofline"]["frac"] <= ex[k]["roofline"]["pipe_utilisation"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"]
+    for row in ("ternary_alu", "cnn_64"):          # configs[2] / configs[3] carry the reference's CPU rate as well
+        assert ex[row]["cpu_baseline"]["value"] > 0 and ex[row]["cpu_baseline"]["kind"] in ("reference", "port")
 
 
 def _random_model_text(rng, codecs, widths, n_classes=10, trit_digits=None):
