@@ -231,6 +231,27 @@ def test_ten_million_images_per_distribution_ids_and_logits(gpu_ok, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", util.MODEL_NAMES)
+def test_every_zoo_model_id_for_id_on_a_large_batch(name, gpu_ok):
+    """Every model of the zoo (the reference tree's headers, the generated ternary and 12 KB-family models) on 10^6 synthetic images
+    (CNN models: 10^5: their oracle costs 60 us per image and thread), half Dist-U and half Dist-M, through the library's default path: every class id equals the
+    oracle's, computed on the host threads."""
+    import torch
+    from bitnetmcu_amd import DIST_M
+    model = util.load_golden_model(name)
+    n = int(os.environ.get("BNM_ZOO_N", "100000" if model.kind == b.KIND_CNN else "1000000"))
+    ctx = b.Context(model)
+    for dist, first in ((DIST_U, 123_456_789), (DIST_M, 7)):
+        m = n // 2
+        x = torch.empty((m, 256), dtype=torch.int8, device="cuda")
+        synth.fill_device(x, first=first, dist=dist)
+        cls = torch.empty(m, dtype=torch.int32, device="cuda")
+        ctx.infer_device(x, cls)
+        want = _oracle_parallel(model, first, m, dist)
+        assert np.array_equal(cls.cpu().numpy().astype(np.uint32), want), (name, dist)
+    ctx.close()
+
+
 def _full_cpu_digest_enabled():
     """ON by default where the host can do it in about a minute and a half (>= 12 usable cores: 10^8 oracle inferences at
     ~1.2e6/s); BNM_FULL_CPU_DIGEST=1 forces it, =0 skips it (the builder's quick iterations)."""
