@@ -25,6 +25,9 @@
 // lane groups (MI355X_MICROARCH.md, LDS table) then hit 16 distinct 16-byte bank groups for every supported ROW.  The
 // swizzle is applied on the SOURCE address of the DMA (its LDS destination is lane-linear).
 #pragma once
+#include <mutex>
+#include <set>
+#include <utility>
 #include "bnm_fused_tile.hpp"
 #include "bnm_fused_math.hpp"
 
@@ -453,6 +456,19 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
 // ---- per-class launcher: each (tile class, tiles per wave) pair is its own translation unit (bnm_fused_generic_m{2,4,8}[_t2].hip)
 // so that they compile side by side.  Instantiations per row length: doubled hidden weights; plain; plain with FP1.3.0's second
 // weight plane.  T = 2 is instantiated for rows of 128 and 256 bytes (32 / 64 B-operand registers per wave).
+// hipFuncSetAttribute costs about a microsecond per call: launch-bound callers pay it once per kernel and device
+inline hipError_t bnm_generic_allow_big_lds(const void *fn) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({fn, dev})) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert({fn, dev});
+    return e;
+}
+
 #define BNM_GENERIC_PICK(MMAX, K0, T)                                                                                       \
     if (kt0 == K0) {                                                                                                        \
         if (sp == 1 && dbl) fn = fused_fc_generic_kernel<MMAX, K0, 1, true, T, bnmk_generic_wps(MMAX, K0, 1, T)>;           \
@@ -468,9 +484,8 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
 #define BNM_GENERIC_LAUNCHER_END                                                                                             \
         if (!fn) return hipErrorInvalidValue;                                                                                \
         if (!blocks) return hipSuccess;   /* probe: is there an instantiation? */                                            \
-        /* opt in to > 64 KiB of dynamic LDS (a per-device function attribute; a host call of about a microsecond) */        \
-        hipError_t err = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
-        if (err != hipSuccess) return err;                                                                                   \
+        /* opt in to > 64 KiB of dynamic LDS: a per-device function attribute, set once per (kernel, device) */               \
+        if (hipError_t err = bnm_generic_allow_big_lds((const void *)fn); err != hipSuccess) return err;                     \
         fn<<<dim3(blocks), dim3(threads), lds, s>>>(images, n, (const i32x4 *)frags, d, cls, logits, counter, batch);        \
         return hipGetLastError();                                                                                            \
     }
