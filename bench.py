@@ -120,7 +120,9 @@ def kernel_name(b, ctx, model):
     v = ctx.variant
     fused = {3: "fused_fc_dual_kernel", 5: "fused_fc_dual_kernel", 6: "fused_fc_dual_kernel", 4: "fused_fc_generic_kernel", 7: "fused_fc_generic_kernel",
              8: "fused_fc_generic_kernel"}.get(v, "fused_fc_kernel")
-    tern = "ternary_stream_kernel" if getattr(ctx, "ternary_variant", 2) else "ternary_alu_kernel"
+    hidden = [li.n_output for _, li in model.fc_layers()][:-1]
+    # the streamed kernel exists for 96-96-96; every other shape of the ALU table runs the plain ALU kernel
+    tern = "ternary_stream_kernel" if (getattr(ctx, "ternary_variant", 2) and hidden == [96, 96, 96]) else "ternary_alu_kernel"
     k = {1: fused, 2: "fc_layer_bitserial_kernel+relunorm_kernel", 3: tern}.get(ctx.path, "?")
     cnn = "cnn_front_mfma_kernel" if getattr(ctx, "cnn_variant", 1) else "cnn_front_kernel"
     return k + ("+" + cnn if model.kind == b.KIND_CNN else "")
