@@ -120,9 +120,9 @@ def kernel_name(b, ctx, model):
     v = ctx.variant
     fused = {3: "fused_fc_dual_kernel", 5: "fused_fc_dual_kernel", 6: "fused_fc_dual_kernel", 4: "fused_fc_generic_kernel", 7: "fused_fc_generic_kernel",
              8: "fused_fc_generic_kernel"}.get(v, "fused_fc_kernel")
-    hidden = [li.n_output for _, li in model.fc_layers()][:-1]
-    # the streamed kernel exists for 96-96-96; every other shape of the ALU table runs the plain ALU kernel
-    tern = "ternary_stream_kernel" if (getattr(ctx, "ternary_variant", 2) and hidden == [96, 96, 96]) else "ternary_alu_kernel"
+    # the streamed kernel is the default for every shape of the ALU table (two images per lane for 96-96-96, one for the others);
+    # variant 0 selects the plain ALU kernel
+    tern = "ternary_stream_kernel" if getattr(ctx, "ternary_variant", 2) % 10 else "ternary_alu_kernel"
     k = {1: fused, 2: "fc_layer_bitserial_kernel+relunorm_kernel", 3: tern}.get(ctx.path, "?")
     cnn = "cnn_front_mfma_kernel" if getattr(ctx, "cnn_variant", 1) else "cnn_front_kernel"
     return k + ("+" + cnn if model.kind == b.KIND_CNN else "")
@@ -477,6 +477,10 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     for nm in ("doc12k_binary", "doc12k_ternary", "doc12k_2bit", "doc12k_8bit"):
         r, _ = run(nm, nm, n, 10, 3, note="reference docs' 12 KB model family")
         hbm_entry(nm, r, BYTES_PER_INFERENCE)
+    # ... and its ternary member (128-128-112) on the no-MFMA kernel: streamed weights, one image per lane
+    r, m = run("doc12k_ternary_alu", "doc12k_ternary", n, 3, 1, path=b.PATH_TERNARY_ALU,
+               note="the documented 12 KB ternary shape on the no-MFMA kernel, selected explicitly")
+    res["doc12k_ternary_alu"]["roofline"] = valu(r, None, BYTES_PER_INFERENCE, m)
     # headline model, class ids + logits (300 B per inference)
     if n <= 100_000_000:
         r, _ = run("fc_logits", "fc_4bitsym_64", n, 10, 3, want_logits=True)

@@ -186,7 +186,8 @@ struct bnm_ctx {
     // ternary ALU path
     bool tern_ok = false;
     int *tern_stream = nullptr;   // the trits in the streamed kernel's consumption order (bnmk_ternary_stream_build)
-    int tern_variant = 2;         // 2: streamed weights, two images per lane (default); 1: one image per lane; 0: round 1's kernel
+    int tern_variant = 2;         // 2: streamed weights, two images per lane (default where it exists); 1: one image per lane; 0: round 1's kernel
+    bool tern_two = false;        // the two-images-per-lane kernel exists for this model's widths
     int requested_path = BNM_PATH_AUTO, path = BNM_PATH_LAYERWISE_ALU;
     bool warned_layerwise = false;
     bool all_known = false;       // every FC layer's codec is one the C engine decodes (=> int8 rows, the MFMA layer-wise path)
@@ -506,14 +507,13 @@ int ctx_build(bnm_ctx *c) {
             a.n_out[i] = c->fc[i].info.n_output;
         }
         if (bnmk_ternary_alu_supported(a.n_in, a.n_out) && a.n_out[3] <= 64) {
-            if (bnmk_ternary_stream_supported(a.n_out)) {
-                void *p = nullptr;
-                if (int e = dev_alloc(c, &p, (size_t)bnmk_ternary_stream_dwords(a.n_out) * 4u)) return e;
-                c->tern_stream = (int *)p;
-                HIP_TRY(bnmk_ternary_stream_build(a, c->tern_stream, s));
-            } else {
-                c->tern_variant = 0;      // the plain ALU kernel (the streamed one exists for 96-96-96)
-            }
+            void *p = nullptr;
+            if (int e = dev_alloc(c, &p, (size_t)bnmk_ternary_stream_dwords(a.n_out) * 4u)) return e;
+            c->tern_stream = (int *)p;
+            HIP_TRY(bnmk_ternary_stream_build(a, c->tern_stream, s));
+            // two images per lane where that kernel exists (96-96-96), one per lane for the other shapes of the table
+            c->tern_two = bnmk_ternary_stream_supported(a.n_out, 2);
+            c->tern_variant = c->tern_two ? 2 : 1;
             c->tern_ok = true;
         }
     }
@@ -822,8 +822,8 @@ int bnm_ctx_set_work_batch(bnm_ctx *c, int tiles) {
 int bnm_ctx_set_ternary_variant(bnm_ctx *c, int variant) {
     if (!c || variant < 0 || (variant > 2 && variant != 11 && variant != 12)) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
-    if (variant != 0 && c->tern_ok && !c->tern_stream)
-        return fail(BNM_EUNSUPPORTED, "the streamed ternary kernels exist for 96-96-96 only; this model runs the plain ALU kernel (variant 0)");
+    if (variant % 10 == 2 && c->tern_ok && !c->tern_two)
+        return fail(BNM_EUNSUPPORTED, "the two-images-per-lane ternary kernel exists for 96-96-96 only; this model runs variant 1 (one image per lane) or 0");
     c->tern_variant = variant % 10;
     c->tern_dynamic = variant < 10;
     return BNM_OK;

@@ -140,9 +140,9 @@ struct BnmTernArgs {
     uint32_t *counter;      // counter block (word 0 hands the image groups out; all zero on entry, left all zero); nullptr: fixed stride
 };
 // shapes of the ALU path: 256 real inputs, hidden widths out of the instantiation table (bnm_ternary.hip); the streamed kernel
-// (variants 1, 2) exists for 96-96-96 only
+// exists with one image per lane (variant 1) for every shape of the table, with two per lane (variant 2) for 96-96-96
 bool bnmk_ternary_alu_supported(const uint32_t n_in[4], const uint32_t n_out[4]);
-bool bnmk_ternary_stream_supported(const uint32_t n_out[4]);
+bool bnmk_ternary_stream_supported(const uint32_t n_out[4], int images_per_lane);
 uint32_t bnmk_ternary_stream_dwords(const uint32_t n_out[4]);
 hipError_t bnmk_ternary_stream_build(const BnmTernArgs &a, int *d_stream, hipStream_t s);
 hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s);

@@ -229,11 +229,16 @@ BNM_DEVICE int tern_norm4(uint32_t p01, uint32_t p23, uint32_t rnd2, uint32_t sh
     return (int)__builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, ub), __builtin_bit_cast(uint32_t, ua), 0x06040200u);
 }
 
-template <int G, int H, int QL>
+// NA >= H / 4: extent of the activation array (the classifier layer reads whole 8-dword chunks: 112 outputs = 28 dwords are
+// padded to 32, the padding dwords are zero and meet zero weights)
+template <int G, int H, int QL, int NA = H / 4>
 BNM_DEVICE void tern_norm(const uint32_t *col, const uint32_t (&tail)[G][(H / 4 - QL) * 2 + 1], const int (&mx)[G],
-                          int (&act)[G][H / 4]) {
+                          int (&act)[G][NA]) {
+    static_assert(NA >= H / 4, "activation array too short");
 #pragma unroll
     for (int g = 0; g < G; g++) {
+#pragma unroll
+        for (int q = H / 4; q < NA; q++) act[g][q] = 0;
         uint32_t t = (uint32_t)mx[g] >> 7;                    // mx >= 0
         uint32_t sh = t ? 32u - (uint32_t)__builtin_clz(t) : 0u;
         uint32_t rnd = (1u << sh) >> 1;
@@ -301,12 +306,17 @@ BNM_DEVICE void tern_layer_s(const int (&x)[G][NX], TernW &a, TernW &b, const in
     });
 }
 
-template <int G, int H1, int H2, int H3, int QL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(G == 1 ? 3 : 2, G == 1 ? 3 : 2)))
+// H1, H2: multiples of 32 (whole 8-dword chunks of activations for the next layer); H3: a multiple of 4, padded to KQ3 dwords for
+// the classifier layer; QL <= H / 4 quads of every hidden layer park their sums in the LDS column, the rest in registers.
+// WPE: waves per SIMD the register budget is compiled for (G = 2: 2; G = 1: 3 for 96-wide layers, 2 for 128-wide ones).
+template <int G, int H1, int H2, int H3, int QL, int WPE = (G == 1 ? 3 : 2)>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const int *__restrict__ wstream,
                            uint32_t n_classes, uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out,
                            uint32_t *__restrict__ counter) {
-    static_assert(H1 == H2 && H2 == H3, "one LDS column geometry for all hidden layers");
+    static_assert(H1 % 32 == 0 && H2 % 32 == 0 && H3 % 4 == 0, "hidden widths: whole chunks for the next layer");
+    static_assert(QL <= H1 / 4 && QL <= H2 / 4 && QL <= H3 / 4, "the LDS column holds QL quads of every hidden layer");
+    constexpr int KQ3 = (H3 / 4 + 7) / 8 * 8;      // activation dwords the classifier layer reads (zero-padded)
     __shared__ uint32_t s_col[G * QL * 2 * 64];
     const int lane = threadIdx.x;
     uint32_t *col = s_col + lane;
@@ -344,18 +354,18 @@ void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const 
         const int *p = wstream;
         if (counter != nullptr && lane == 0)
             nxt_v = (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t tail[G][(H1 / 4 - QL) * 2 + 1];
+        uint32_t tail[G][(H1 / 4 - QL) * 2 + 1], tail2[G][(H2 / 4 - QL) * 2 + 1], tail3[G][(H3 / 4 - QL) * 2 + 1];
         int mx[G];
-        int a1[G][H1 / 4], a2[G][H2 / 4], a3[G][H3 / 4];
+        int a1[G][H1 / 4], a2[G][H2 / 4], a3[G][KQ3];
         tern_layer_s<G, 64, 64, H1, QL>(x0, wa, wb, p, col, tail, mx);
         const uint64_t next_base = counter != nullptr
             ? ((uint64_t)gridDim.x + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(nxt_v)) * (64ull * G) : base + stride;
         if (next_base < n) request(next_base);      // lands under layers 2-4
         tern_norm<G, H1, QL>(col, tail, mx, a1);
-        tern_layer_s<G, H1 / 4, H1 / 4, H2, QL>(a1, wa, wb, p, col, tail, mx);
-        tern_norm<G, H2, QL>(col, tail, mx, a2);
-        tern_layer_s<G, H2 / 4, H2 / 4, H3, QL>(a2, wa, wb, p, col, tail, mx);
-        tern_norm<G, H3, QL>(col, tail, mx, a3);
+        tern_layer_s<G, H1 / 4, H1 / 4, H2, QL>(a1, wa, wb, p, col, tail2, mx);
+        tern_norm<G, H2, QL>(col, tail2, mx, a2);
+        tern_layer_s<G, H2 / 4, H2 / 4, H3, QL>(a2, wa, wb, p, col, tail3, mx);
+        tern_norm<G, H3, QL, KQ3>(col, tail3, mx, a3);
         // classifier layer (first strict maximum = ReLUNorm's return value): quads of classes, 3 chunks each; the stream
         // wraps to its first chunk after the last class quad, so `wa` is ready for the next images
         int bv[G];
@@ -369,7 +379,7 @@ void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const 
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int g = 0; g < G; g++) acc[i][g] = 0;
-            tern_quad<G, H3 / 4, H3 / 4, af>(a3, wa, wb, pq, acc);
+            tern_quad<G, KQ3, KQ3, af>(a3, wa, wb, pq, acc);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const uint32_t c = 4u * q + (uint32_t)i;
@@ -383,18 +393,25 @@ void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const 
                 }
             }
         };
-        constexpr int NC3 = H3 / 32;   // chunks per class quad
-        static_assert(NC3 % 2 == 1, "the class loop below alternates the buffers per quad");
+        constexpr int NC3 = KQ3 / 8;   // chunks per class quad
         // the stream ends with a copy of its first chunk, so the prefetch after the last class quad leaves the next
-        // images' first chunk landed - in wb after an odd number of quads (copied over: both buffers have landed)
-        for (uint32_t q = 0; q < nq4; q += 2u) {
-            classes(std::true_type{}, q, p);
-            p += NC3 * 32;
-            if (q + 1u < nq4) {
-                classes(std::false_type{}, q + 1u, p);
+        // images' first chunk landed.  Odd chunk counts alternate the buffers per quad: after an odd number of quads the
+        // chunk sits in wb (copied over: both buffers have landed); even counts start and end every quad in wa.
+        if constexpr (NC3 % 2 == 1) {
+            for (uint32_t q = 0; q < nq4; q += 2u) {
+                classes(std::true_type{}, q, p);
                 p += NC3 * 32;
-            } else {
-                wa = wb;
+                if (q + 1u < nq4) {
+                    classes(std::false_type{}, q + 1u, p);
+                    p += NC3 * 32;
+                } else {
+                    wa = wb;
+                }
+            }
+        } else {
+            for (uint32_t q = 0; q < nq4; q++) {
+                classes(std::true_type{}, q, p);
+                p += NC3 * 32;
             }
         }
 #pragma unroll
@@ -410,33 +427,39 @@ void ternary_stream_kernel(const int8_t *__restrict__ images, uint64_t n, const 
 // ---- weight stream of the streamed kernel -----------------------------------------------------------------------
 // per layer: for each quad of neurons, for each slice of 8 activation dwords: [4 neurons][8 dwords]; after the last layer
 // one more chunk = a copy of the first (the prefetch that follows the last class quad).  Rows past n_out are zero.
+// A layer's K is padded to whole chunks (kq dwords; kq_real of them exist in the rows - 112 inputs = 28 dwords -> 32).
 __global__ void tern_stream_kernel(const int8_t *__restrict__ rows, uint32_t stride, uint32_t n_out, uint32_t kq,
-                                   uint32_t n_quads, int *__restrict__ out) {
+                                   uint32_t kq_real, uint32_t n_quads, int *__restrict__ out) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nc = kq / 8u;
     if (idx >= n_quads * nc * 32u) return;
     const uint32_t chunk = idx / 32u, d = idx % 32u;
     const uint32_t neuron = 4u * (chunk / nc) + d / 8u, k = 8u * (chunk % nc) + d % 8u;
-    out[idx] = neuron < n_out ? ((const int *)(rows + (size_t)neuron * stride))[k] : 0;
+    out[idx] = (neuron < n_out && k < kq_real) ? ((const int *)(rows + (size_t)neuron * stride))[k] : 0;
 }
+
+namespace {
+uint32_t tern_kq(uint32_t n_in) { return (n_in / 4u + 7u) / 8u * 8u; }
+}  // namespace
 
 uint32_t bnmk_ternary_stream_dwords(const uint32_t n_out[4]) {
     uint32_t dw = 0, kq = 64;
     for (int i = 0; i < 4; i++) {
         dw += ((n_out[i] + 3u) / 4u) * (kq / 8u) * 32u;
-        kq = n_out[i] / 4u;
+        kq = tern_kq(n_out[i]);
     }
     return dw + 32u;
 }
 
 hipError_t bnmk_ternary_stream_build(const BnmTernArgs &a, int *d_stream, hipStream_t s) {
-    uint32_t off = 0, kq = 64;
+    uint32_t off = 0, kq = 64, kq_real = 64;
     for (int i = 0; i < 4; i++) {
         const uint32_t nq = (a.n_out[i] + 3u) / 4u, dw = nq * (kq / 8u) * 32u;
-        tern_stream_kernel<<<dim3((dw + 255u) / 256u), dim3(256), 0, s>>>(a.rows[i], a.stride[i], a.n_out[i], kq, nq,
+        tern_stream_kernel<<<dim3((dw + 255u) / 256u), dim3(256), 0, s>>>(a.rows[i], a.stride[i], a.n_out[i], kq, kq_real, nq,
                                                                         d_stream + off);
         off += dw;
-        kq = a.n_out[i] / 4u;
+        kq = tern_kq(a.n_out[i]);
+        kq_real = a.n_out[i] / 4u;
     }
     hipError_t e = hipMemcpyAsync(d_stream + off, d_stream, 128, hipMemcpyDeviceToDevice, s);
     return e != hipSuccess ? e : hipGetLastError();
@@ -451,15 +474,18 @@ hipError_t bnmk_ternary_stream_build(const BnmTernArgs &a, int *d_stream, hipStr
 namespace {
 typedef void (*tern_fn)(const int8_t *, uint64_t, const int8_t *, const int8_t *, const int8_t *, const int8_t *, uint32_t, uint32_t,
                         uint32_t, uint32_t, uint32_t, uint32_t *, int32_t *);
+typedef void (*tern_stream_fn)(const int8_t *, uint64_t, const int *, uint32_t, uint32_t *, int32_t *, uint32_t *);
 struct TernShape {
     uint32_t h[3];
-    tern_fn fn;
+    tern_fn fn;                 // variant 0: the plain ALU kernel
+    tern_stream_fn stream1;     // variant 1: streamed weights, one image per lane
+    uint32_t stream1_wpc;       // ... and its resident waves per CU
 };
 const TernShape kTernShapes[] = {
-    {{96, 96, 96}, ternary_alu_kernel<96, 96, 96>},
-    {{128, 128, 112}, ternary_alu_kernel<128, 128, 112>},
-    {{64, 64, 64}, ternary_alu_kernel<64, 64, 64>},
-    {{128, 128, 128}, ternary_alu_kernel<128, 128, 128>},
+    {{96, 96, 96}, ternary_alu_kernel<96, 96, 96>, ternary_stream_kernel<1, 96, 96, 96, 24>, 12},
+    {{128, 128, 112}, ternary_alu_kernel<128, 128, 112>, ternary_stream_kernel<1, 128, 128, 112, 24>, 12},
+    {{64, 64, 64}, ternary_alu_kernel<64, 64, 64>, ternary_stream_kernel<1, 64, 64, 64, 16>, 12},
+    {{128, 128, 128}, ternary_alu_kernel<128, 128, 128>, ternary_stream_kernel<1, 128, 128, 128, 24>, 12},
 };
 const TernShape *find_tern(const uint32_t n_out[4]) {
     for (const TernShape &t : kTernShapes)
@@ -471,24 +497,29 @@ const TernShape *find_tern(const uint32_t n_out[4]) {
 bool bnmk_ternary_alu_supported(const uint32_t n_in[4], const uint32_t n_out[4]) {
     return n_in[0] == 256 && n_in[1] == n_out[0] && n_in[2] == n_out[1] && n_in[3] == n_out[2] && find_tern(n_out) != nullptr;
 }
-bool bnmk_ternary_stream_supported(const uint32_t n_out[4]) { return n_out[0] == 96 && n_out[1] == 96 && n_out[2] == 96; }
+// the streamed kernel: one image per lane for every shape of the table, two per lane (the default where it exists) for 96-96-96
+bool bnmk_ternary_stream_supported(const uint32_t n_out[4], int images_per_lane) {
+    if (images_per_lane == 2) return n_out[0] == 96 && n_out[1] == 96 && n_out[2] == 96;
+    return images_per_lane == 1 && find_tern(n_out) != nullptr;
+}
 
 hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s) {
     if (!a.n) return hipSuccess;
     if (a.n_layers != 4 || !bnmk_ternary_alu_supported(a.n_in, a.n_out)) return hipErrorInvalidValue;
     const bool stream = a.variant != 0;
-    if (stream && !bnmk_ternary_stream_supported(a.n_out)) return hipErrorInvalidValue;
     const int G = a.variant == 2 ? 2 : 1;
+    if (stream && !bnmk_ternary_stream_supported(a.n_out, G)) return hipErrorInvalidValue;
+    const TernShape *shape = find_tern(a.n_out);
     const uint64_t per = 64ull * (uint64_t)G;
     const uint64_t want = (a.n + per - 1ull) / per;
     // resident waves per CU: the streamed kernels 8 / 12; the plain kernel's LDS column is max(H) * 128 bytes per wave
     uint32_t hm = a.n_out[0] > a.n_out[1] ? a.n_out[0] : a.n_out[1];
     hm = hm > a.n_out[2] ? hm : a.n_out[2];
-    const uint64_t wpc = stream ? (a.variant == 2 ? 8ull : 12ull) : (uint64_t)((160u * 1024u) / (hm * 128u) < 12u ? (160u * 1024u) / (hm * 128u) : 12u);
+    const uint64_t wpc = stream ? (a.variant == 2 ? 8ull : (uint64_t)shape->stream1_wpc) : (uint64_t)((160u * 1024u) / (hm * 128u) < 12u ? (160u * 1024u) / (hm * 128u) : 12u);
     const uint64_t cap = grid_blocks > 0 ? (uint64_t)grid_blocks : (uint64_t)bnm_num_cus() * wpc;
     const unsigned blocks = (unsigned)(want < cap ? want : cap);
     if (!stream) {
-        find_tern(a.n_out)->fn<<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.rows[0], a.rows[1], a.rows[2], a.rows[3], a.stride[0],
+        shape->fn<<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.rows[0], a.rows[1], a.rows[2], a.rows[3], a.stride[0],
                                                                  a.stride[1], a.stride[2], a.stride[3], a.n_out[3], a.cls, a.logits);
     } else {
         if (!a.wstream || want >= (1ull << 32)) return hipErrorInvalidValue;
@@ -496,8 +527,7 @@ hipError_t bnmk_ternary_alu(const BnmTernArgs &a, int grid_blocks, hipStream_t s
             ternary_stream_kernel<2, 96, 96, 96, 20><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.wstream, a.n_out[3],
                                                                                          a.cls, a.logits, a.counter);
         else
-            ternary_stream_kernel<1, 96, 96, 96, 24><<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.wstream, a.n_out[3],
-                                                                                         a.cls, a.logits, a.counter);
+            shape->stream1<<<dim3(blocks), dim3(64), 0, s>>>(a.images, a.n, a.wstream, a.n_out[3], a.cls, a.logits, a.counter);
     }
     return hipGetLastError();
 }

@@ -71,12 +71,14 @@ def test_full_size_properties(gpu_ok, orc):
     ctx.close()
 
 
-def test_ternary_full_size_all_kernels(gpu_ok, orc):
+@pytest.mark.parametrize("name,variants", [("tern_96", (0, 11, 12, 1, 2)), ("doc12k_ternary", (0, 11, 1))])
+def test_ternary_full_size_all_kernels(name, variants, gpu_ok, orc):
     """BASELINE configs[2] at its stated N: the five ALU kernels (streamed weights with two / one image per lane, work counter /
     fixed stride; round 1's kernel) and the MFMA path - independent implementations - give the same digest and histogram over
-    all N class ids; head / tail / strided sample and the first 10^6 images id for id against the oracle."""
+    all N class ids; head / tail / strided sample and the first 10^6 images id for id against the oracle.  The same for the
+    reference's documented 12 KB ternary shape (128-128-112; one image per lane only)."""
     import torch
-    model = util.load_golden_model("tern_96")
+    model = util.load_golden_model(name)
     ctx = b.Context(model)
     n = N_FULL
     imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
@@ -87,7 +89,7 @@ def test_ternary_full_size_all_kernels(gpu_ok, orc):
     ctx.infer_device(imgs, cls)
     digests["mfma"] = synth.digest_device(cls, first=0, n_bins=10).cpu().numpy()
     ctx.set_path(b.PATH_TERNARY_ALU)
-    for tv in (0, 11, 12, 1, 2):          # the default last: everything below runs on it
+    for tv in variants:                   # the default last: everything below runs on it
         ctx.set_ternary_variant(tv)
         cls.fill_(-1)
         ctx.infer_device(imgs, cls)

@@ -641,10 +641,16 @@ def test_ternary_alu_kernel_other_widths(widths, signs, gpu_ok, orc):
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     ctx.set_path(b.PATH_TERNARY_ALU)
     with pytest.raises(b.BnmError):
-        ctx.set_ternary_variant(2)                # the streamed kernels exist for 96-96-96 only
-    for n in (len(x), 129, 64, 1):
-        got = ctx.infer(x[:n], logits=True)
-        assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (widths, signs, n)
+        ctx.set_ternary_variant(2)                # two images per lane: 96-96-96 only
+    # 1: streamed weights, one image per lane, work counter (the default for these shapes); 11: fixed stride; 0: plain kernel
+    for variant in (None, 1, 11, 0):
+        if variant is not None:
+            ctx.set_ternary_variant(variant)
+        for n in (len(x), 129, 64, 1):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (widths, signs, variant, n)
+            got = ctx.infer(x[:n])
+            assert np.array_equal(got, want[0][:n]), (widths, signs, variant, n)
     ctx.close()
 
 
