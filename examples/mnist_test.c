@@ -1,0 +1,80 @@
+/* C host that drives the reference's kernel symbols ONE BY ONE on the GPU library - the way a program written against
+ * BitNetMCU_inference.h does (the reference's own such program is BitNetMCU_MNIST_test.c; it #includes BitNetMCU_inference.c
+ * textually, this one links the same symbols from libbitnetmcu_hip.so instead).
+ *
+ *   gcc -std=c99 -I<dir with BitNetMCU_model.h and BitNetMCU_MNIST_test_data.h> -Iinclude examples/mnist_test.c \
+ *       -Lbitnetmcu_amd -lbitnetmcu_hip -Wl,-rpath,$PWD/bitnetmcu_amd -o mnist_test && ./mnist_test
+ *
+ * BitNetMCU_model.h: the exporter's header (its L<k>_* macros and weight arrays, BitNetMCU_model_fc.h / _cnn.h dialect);
+ * BitNetMCU_MNIST_test_data.h: `int8_t input_data_<k>[256]` / `uint8_t label_<k>` for k = 0..9 (the reference's layout).
+ * Output: one line per image, "label: <l> predicted: <p>" - what BitNetMCU_MNIST_test.c:17-40 prints.
+ * Every call is a round trip to the GPU: this is symbol-level compatibility, not the fast path (examples/batch_infer.c).
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "BitNetMCU_model.h"
+#include "BitNetMCU_MNIST_test_data.h"
+#include "bitnetmcu_hip.h"
+
+typedef struct {
+    const void *weights;
+    int32_t codec;
+    uint32_t n_in, n_out;
+} fc_layer;
+
+#define FC(k) {L##k##_weights, L##k##_bitperweight, L##k##_incoming_weights, L##k##_outgoing_weights}
+
+#if defined(MODEL_CNNMNIST)
+/* conv (1 -> C) / depthwise conv / pool / depthwise conv / pool, then three fully connected layers */
+static const fc_layer fc_chain[] = {FC(11), FC(13), FC(15)};
+enum { CHANNELS = L7_out_channels, FEATURES_PER_CHANNEL = L9_outgoing_x * L9_outgoing_y, CONV_SHIFT = 4 };
+#elif defined(MODEL_FCMNIST)
+#ifdef L4_active
+static const fc_layer fc_chain[] = {FC(1), FC(2), FC(3), FC(4)};
+#else
+static const fc_layer fc_chain[] = {FC(1), FC(2), FC(3)};
+#endif
+#else
+#error "BitNetMCU_model.h defines neither MODEL_FCMNIST nor MODEL_CNNMNIST"
+#endif
+
+static uint32_t classify(const int8_t *image) {
+    static int32_t sums[4 * MAX_N_ACTIVATIONS];
+    static int8_t act[4 * MAX_N_ACTIVATIONS];
+    uint32_t winner = 0;
+#if defined(MODEL_CNNMNIST)
+    static int32_t plane[16 * 16];
+    int32_t *features = sums, *next = sums;
+    for (uint32_t c = 0; c < CHANNELS; c++) {
+        for (int i = 0; i < 256; i++) plane[i] = image[i];
+        /* every stage works in place on the channel's plane; the last pool appends its 2x2 block to the feature row */
+        processconv33ReLU(plane, L2_weights + 9 * c, L2_incoming_x, CONV_SHIFT, plane);
+        processconv33ReLU(plane, L4_weights + 9 * c, L4_incoming_x, CONV_SHIFT, plane);
+        processmaxpool22(plane, L6_incoming_x, plane);
+        processconv33ReLU(plane, L7_weights + 9 * c, L7_incoming_x, CONV_SHIFT, plane);
+        next = processmaxpool22(plane, L9_incoming_x, next);
+    }
+    ReLUNorm(features, act, (uint32_t)(next - features));
+#else
+    memcpy(act, image, 256);
+#endif
+    for (size_t k = 0; k < sizeof fc_chain / sizeof fc_chain[0]; k++) {
+        const fc_layer *l = &fc_chain[k];
+        processfclayer(act, (const uint32_t *)l->weights, l->codec, l->n_in, l->n_out, sums);
+        winner = ReLUNorm(sums, act, l->n_out);
+    }
+    return winner;
+}
+
+int main(void) {
+#define IMAGE(k) {input_data_##k, &label_##k}
+    static const struct {
+        const int8_t *pixels;
+        const uint8_t *label;
+    } tests[] = {IMAGE(0), IMAGE(1), IMAGE(2), IMAGE(3), IMAGE(4), IMAGE(5), IMAGE(6), IMAGE(7), IMAGE(8), IMAGE(9)};
+    for (size_t t = 0; t < sizeof tests / sizeof tests[0]; t++)
+        printf("label: %d predicted: %d\n", (int)*tests[t].label, (int)classify(tests[t].pixels));
+    return 0;
+}

@@ -97,3 +97,22 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
                            f"-Wl,-rpath,{libdir}", "-o", str(exe)])
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.parametrize("name", ["fc_4bitsym_64", "mcu_1k", "tern_96", "cnn_64"])
+def test_layer_by_layer_c_host_compiles_and_refuses_to_run_without_a_gpu(name, tmp_path):
+    """examples/mnist_test.c (the call sequence of BitNetMCU_MNIST_test.c:43-139 on the reference's symbols) compiles warning-free
+    against exporter-dialect headers of 3- / 4-layer FC, ternary and CNN models; without a HIP device the first kernel symbol
+    aborts with a message - there is no CPU fallback (the GPU run: tests/test_gpu_dropin.py)."""
+    import numpy as np
+    import torch
+    import util
+    import bitnetmcu_amd as b
+    r = np.load(os.path.join(util.GOLDEN, "real_images.npz"))
+    (tmp_path / "BitNetMCU_model.h").write_text(b.Model.from_zoo(name).to_header_text())
+    (tmp_path / "BitNetMCU_MNIST_test_data.h").write_text(util.test_data_header(r["images"][:10], r["labels"][:10]))
+    exe = util.compile_c_host("mnist_test.c", tmp_path)
+    if torch.cuda.is_available():
+        return
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode != 0 and out.stdout == "" and "no CPU fallback" in out.stderr

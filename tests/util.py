@@ -154,3 +154,26 @@ def parse_c_int8_arrays(text):
         lm = re.search(r"label_%s\s*=\s*(\d+)" % m.group(1), text)
         labels.append(int(lm.group(1)))
     return np.stack(imgs), np.array(labels, dtype=np.uint32)
+
+
+def test_data_header(images, labels):
+    """`int8_t input_data_<k>[256]` / `uint8_t label_<k>` blocks in the layout of the reference's BitNetMCU_MNIST_test_data.h."""
+    out = ["#include <stdint.h>"]
+    for k, (img, lab) in enumerate(zip(images, labels)):
+        out.append(f"int8_t input_data_{k}[256] = {{" + ", ".join(str(int(v)) for v in img) + "};")
+        out.append(f"uint8_t label_{k} = {int(lab)};")
+    return "\n".join(out) + "\n"
+
+
+test_data_header.__test__ = False
+
+
+def compile_c_host(source, include_dir):
+    """gcc a C host under examples/ against include/ + `include_dir` and link it with the GPU library; returns the executable."""
+    import subprocess
+    exe = os.path.join(str(include_dir), os.path.splitext(source)[0])
+    libdir = os.path.join(REPO, "bitnetmcu_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I", str(include_dir), "-I", os.path.join(REPO, "include"),
+                           os.path.join(REPO, "examples", source), "-L", libdir, "-lbitnetmcu_hip", f"-Wl,-rpath,{libdir}",
+                           "-o", exe])
+    return exe
