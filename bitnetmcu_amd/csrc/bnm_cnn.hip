@@ -289,6 +289,17 @@ BNM_DEVICE int wave_max_nonneg(int v) {
     return max(max(a, b), max(c, d));
 }
 
+// PAIR mode: lanes 0-15 / 32-47 hold one image, lanes 16-31 / 48-63 another: the maximum of the lane's own image
+BNM_DEVICE int pair_max_nonneg(int v, bool second) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return second ? max(b, d) : max(a, c);
+}
+
 // SAFE: the patch loads of image row 15, column 13 reach one byte past the image; for the LAST image of the caller's buffer
 // that byte may not exist.  The launcher runs that one image through the SAFE instantiation (clamped address, bytes shifted
 // into place: 2 extra VALU per load) and every other image through the plain one — no run-time test in the hot loop.
@@ -299,7 +310,13 @@ __device__ uint64_t *g_cnn_rec = nullptr;
 hipError_t bnmk_diag_cnn_set_record(uint64_t *d_rec) { return hipMemcpyToSymbol(HIP_SYMBOL(g_cnn_rec), &d_rec, sizeof(d_rec)); }
 #define CNN_STAMP() __builtin_readcyclecounter()
 #endif
-template <bool FUSE, bool SAFE>
+// PAIR (models with <= 16 channels): an item is TWO consecutive images, `n` counts pairs.  Lane columns 0..15 are the channels
+// of the pair's first image, columns 16..31 the same channels of its second image: the A operand's K-slots 0..15 (lane half
+// 0) carry the first image's patch, K-slots 16..31 (lane half 1) the second image's, and the weight table holds a channel's
+// conv1 weights in K-slots 0..15 for columns 0..15 and in K-slots 16..31 for columns 16..31 (zero elsewhere): the MFMA
+// computes both images' conv1 at the price of one.  Everything after it is per lane and does not care which image a lane
+// belongs to; the ReLUNorm maximum and the output addresses are per column group.
+template <bool FUSE, bool SAFE, bool PAIR = false>
 __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                              const int *__restrict__ wtab, uint32_t C_pad, uint32_t C, uint32_t c0,
                                                              uint32_t n_shift, int8_t *__restrict__ acts, uint32_t acts_stride,
@@ -309,7 +326,9 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
     const uint32_t wave_id = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nwaves = gridDim.x * 4u;
     const uint32_t n32 = (uint32_t)n;           // the launcher refuses n >= 2^31
-    const uint32_t nblk = (C - c0) > 32u ? 2u : 1u;
+    static_assert(!(PAIR && SAFE), "the pair mode has no SAFE instantiation (the launcher keeps the last images out of it)");
+    const uint32_t nblk = PAIR ? 1u : ((C - c0) > 32u ? 2u : 1u);
+    constexpr uint32_t IMG_BYTES = PAIR ? 512u : 256u;      // bytes of an item's image(s)
 
     // A-operand addressing (the same for every image): A row i of tile t is window position 16t + q of band beta
     // (band 1 rows compute conv1 at image row 13 - wr with the kernel the right way up: only the ORDER in which the window
@@ -325,10 +344,13 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         o1p[t >> 2] |= (uint32_t)(16 * g + x) << (8 * (t & 3));
     }
     // (extracted behind an opaque copy, or hipcc hoists the seven extractions out of the item loop - seven registers again)
+    const uint32_t pair_off = PAIR ? (uint32_t)h << 8 : 0u;      // lane half 1 reads the pair's second image
     auto o1 = [&](int t) -> uint32_t {
         uint32_t w = o1p[t >> 2];
         asm volatile("" : "+v"(w));
-        return (w >> (8 * (t & 3))) & 0xFFu;
+        const uint32_t o = (w >> (8 * (t & 3))) & 0xFFu;
+        if constexpr (PAIR) return o | pair_off;
+        else return o;
     };
     const int vshift = (int)n_shift;
     const int partner = (lane ^ 32) << 2;        // ds_bpermute address of the lane that owns the other band of this channel
@@ -350,7 +372,7 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
             // offset.  (As plain pointer arithmetic hipcc formed a 64-bit lane address per tile - one more VALU per tile and
             // seven register PAIRS carried across the item loop.)  512 bytes are in range: the one-byte overrun of the last
             // row belongs to the next image, which exists for every image this instantiation sees.
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)ip, 0, 512, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)ip, 0, 256 + IMG_BYTES, 0x00020000);
             va = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o, 0, 0);
             vb = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + 16u), 0, 0);
             vc = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + 32u), 0, 0);
@@ -378,7 +400,7 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         hd.q2 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 32, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.q3 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 48, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.q4 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 64, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
-        hd.a0 = load_A(images + (uint64_t)im * 256ull, o1(0));
+        hd.a0 = load_A(images + (uint64_t)im * IMG_BYTES, o1(0));
         return hd;
     };
     // landing zone of the next-image touch: an LDS-DMA load has no register destination to keep reserved
@@ -401,16 +423,22 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         return l;
     };
-    auto store_off = [&]() -> int {
+    // (PAIR: `row` = bytes from the first image's output row to the second's; lanes of channels >= C get an offset out of range)
+    auto store_off = [&](uint32_t row) -> int {
         const int l = lane_now();
-        return 4 * (int)c0 + 4 * (l & 31) + 2 * (l >> 5);
+        if constexpr (PAIR) {
+            const int ch = l & 15;
+            return (uint32_t)ch < C ? ((l >> 4) & 1) * (int)row + 4 * (int)c0 + 4 * ch + 2 * (l >> 5) : 0x7FFFFF00;
+        } else {
+            return 4 * (int)c0 + 4 * (l & 31) + 2 * (l >> 5);
+        }
     };
     auto flush_pending = [&]() {
         if (!pend) return;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)pend_row, 0, (int)(4u * C), 0x00020000);
-        const int st_off = store_off();
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)pend_row, 0, (int)((PAIR ? acts_stride : 0u) + 4u * C), 0x00020000);
+        const int st_off = store_off(acts_stride);
         __builtin_amdgcn_raw_buffer_store_b16((short)(pend_v & 0xFFFFu), rs, st_off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((short)(pend_v >> 16), rs, st_off, 128, 0);     // block 1: scalar offset
+        if constexpr (!PAIR) __builtin_amdgcn_raw_buffer_store_b16((short)(pend_v >> 16), rs, st_off, 128, 0);     // block 1: scalar offset
         pend = false;
     };
 #ifdef BNM_DIAG_TIMING
@@ -426,7 +454,7 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         const uint32_t img = cur_batch + (off >> blk_shift);
         if (img >= n32) break;                // batches are handed out in increasing order: nothing is left for this wave
         const uint32_t blk = off & (nblk - 1u);
-        const int8_t *__restrict__ ip = images + (uint64_t)img * 256ull;          // wave-uniform
+        const int8_t *__restrict__ ip = images + (uint64_t)img * IMG_BYTES;       // wave-uniform
         // the batch after this one is requested at the start of this one; the answer is needed `grab` images later
         if (off == 0 && counter != nullptr && lane_now() == 0)
             nxt_v = (int)__hip_atomic_fetch_add(counter, grab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -438,11 +466,14 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
                 ni = counter != nullptr ? (grab > 1u ? nwaves * grab + (uint32_t)__builtin_amdgcn_readfirstlane(nxt_v) : n32)
                                         : cur_batch + nwaves * grab;
             if (ni < n32) {
-                const int8_t *np = images + (uint64_t)ni * 256ull;
+                const int8_t *np = images + (uint64_t)ni * IMG_BYTES;
                 uint32_t keep;
                 const int lane4 = lane_now() * 4;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(lane4), "s"(touch_lds), "s"(np) : "memory");
+                if constexpr (PAIR)
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3 offset:256\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(lane4), "s"(touch_lds), "s"(np) : "memory");
             }
         }
         const Head cur = fetch(img, blk);
@@ -559,16 +590,19 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         if (blk + 1 == nblk) {
             // ---- outputs: lane (j, h), block b: channel c0 + 32 b + j, values t = 2h, 2h + 1 ---------------------------------
             if (feat) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(feat + (uint64_t)img * (4ull * C)), 0, (int)(16u * C), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(feat + (uint64_t)img * ((PAIR ? 8ull : 4ull) * C)), 0,
+                                                                                   (int)((PAIR ? 32u : 16u) * C), 0x00020000);
                 typedef int i32x2 __attribute__((ext_vector_type(2)));
-                const int f_off = 4 * store_off();
+                const int f_off = 4 * store_off(4u * C);
                 __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[0][0], fo[0][1]}, rs, f_off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[1][0], fo[1][1]}, rs, f_off, 512, 0);
+                if constexpr (!PAIR) __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[1][0], fo[1][1]}, rs, f_off, 512, 0);
             }
             if constexpr (FUSE) {
                 // fused ReLUNorm over the 4*C features (all >= 0; channels >= C have zero weights and contribute 0)
                 const int mxl = max(max(fo[0][0], fo[0][1]), nblk == 2u ? max(fo[1][0], fo[1][1]) : 0);
-                const int mx = wave_max_nonneg(mxl);
+                int mx;
+                if constexpr (PAIR) mx = pair_max_nonneg(mxl, (lane_now() & 16) != 0);
+                else mx = wave_max_nonneg(mxl);
                 const uint32_t tt = (uint32_t)mx >> 7;
                 const int sh = tt ? 32 - __builtin_clz(tt) : 0;
                 const int rnd = (1 << sh) >> 1;
@@ -576,7 +610,7 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
 #pragma unroll
                 for (uint32_t bb = 0; bb < 2; bb++)
                     pend_v |= ((uint32_t)min((fo[bb][0] + rnd) >> sh, 127) | ((uint32_t)min((fo[bb][1] + rnd) >> sh, 127) << 8)) << (16 * bb);
-                pend_row = acts + (uint64_t)img * (uint64_t)acts_stride;
+                pend_row = acts + (uint64_t)img * ((PAIR ? 2ull : 1ull) * (uint64_t)acts_stride);
                 pend = true;
             }
         }
@@ -603,13 +637,20 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
 // ---- launchers -------------------------------------------------------------------------------------------------
 // Host-side weight table for cnn_front_mfma_kernel (layout above).  w1/w2/w3: int8 [C][9] as in the header; out:
 // 2 * C_pad * 20 ints with C_pad = C rounded up to 64 (surplus channels: zero weights).
+// C <= 16 (the pair mode's layout, which the one-image instantiations read just as well): lane columns 16..31 repeat channels
+// 0..15, and a column's conv1 weights sit in the K-half of its column group - K-slots 0..15 (band 0's entry) for columns 0..15,
+// K-slots 16..31 (band 1's entry) for columns 16..31.  With one image in both K-halves of the A operand the columns 16..31
+// merely recompute channels 0..15 (their stores fall outside the 4 C valid output bytes).
 void bnm_cnn_weight_table(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int *out) {
     const uint32_t C_pad = (C + 63u) / 64u * 64u;
     for (uint32_t i = 0; i < 2u * C_pad * CNN_WTAB_DWORDS; i++) out[i] = 0;
+    const bool pair = C <= 16u;
     for (uint32_t band = 0; band < 2; band++)
-        for (uint32_t c = 0; c < C; c++) {
-            int *e = out + ((size_t)band * C_pad + c) * CNN_WTAB_DWORDS;
-            if (band == 0) {
+        for (uint32_t col = 0; col < (pair ? 32u : C); col++) {
+            const uint32_t c = pair ? (col & 15u) : col;
+            if (c >= C) continue;
+            int *e = out + ((size_t)band * C_pad + col) * CNN_WTAB_DWORDS;
+            if (band == (pair ? col >> 4 : 0u)) {
                 uint8_t bytes[16] = {0};
                 for (int dy = 0; dy < 3; dy++)
                     for (int dx = 0; dx < 3; dx++) bytes[4 * dy + dx] = (uint8_t)w1[9u * c + 3 * dy + dx];
@@ -647,6 +688,20 @@ hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, co
     // MFMA kernel: batches of `grab` images from word 0 of the counter block (all zero between launches: the waves' first batches
     // are static, the counter hands out what follows); counter == nullptr or grab == 0: fixed shares of single images
     if (!counter || !grab) { counter = nullptr; grab = 1; }
+    if (C <= 16 && wtab) {
+        // two images per item: images [0, 2 * pairs) through the pair instantiation, the last one or two through the SAFE one
+        const uint64_t pairs = (n - 1) / 2, rest = n - 2 * pairs;
+        if (pairs) {
+            uint64_t pb = (pairs + 3) / 4;
+            if (pb > cap) pb = cap;
+            cnn_front_mfma_kernel<true, false, true><<<dim3((unsigned)pb), b, 0, s>>>(images, pairs, wtab, C_pad, C, 0, n_shift, acts, acts_stride, feat,
+                                                                                     counter, grab);
+        }
+        cnn_front_mfma_kernel<true, true><<<dim3(1), b, 0, s>>>(images + 2 * pairs * 256ull, rest, wtab, C_pad, C, 0, n_shift,
+                                                              acts + 2 * pairs * (uint64_t)acts_stride, acts_stride,
+                                                              feat ? feat + 2 * pairs * 4ull * C : nullptr, nullptr, 1);
+        return hipGetLastError();
+    }
     if (C <= 64) {
         if (wtab) {
             if (n_main) {
