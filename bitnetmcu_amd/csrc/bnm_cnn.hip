@@ -316,19 +316,27 @@ hipError_t bnmk_diag_cnn_set_record(uint64_t *d_rec) { return hipMemcpyToSymbol(
 // conv1 weights in K-slots 0..15 for columns 0..15 and in K-slots 16..31 for columns 16..31 (zero elsewhere): the MFMA
 // computes both images' conv1 at the price of one.  Everything after it is per lane and does not care which image a lane
 // belongs to; the ReLUNorm maximum and the output addresses are per column group.
-template <bool FUSE, bool SAFE, bool PAIR = false>
+// MODE 2 (TRI, models with 33..48 channels, FUSE only): a unit is again a pair of images, done as THREE items - channels 0..31 of
+// the first image, channels 0..31 of the second, and channels 32..47 of both in the pair layout - instead of two items per
+// image with the second one half empty.
+template <bool FUSE, bool SAFE, int MODE = 0>
 __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                              const int *__restrict__ wtab, uint32_t C_pad, uint32_t C, uint32_t c0,
                                                              uint32_t n_shift, int8_t *__restrict__ acts, uint32_t acts_stride,
-                                                             int32_t *__restrict__ feat, uint32_t *__restrict__ counter, uint32_t grab) {
+                                                             int32_t *__restrict__ feat, uint32_t feat_stride, uint32_t *__restrict__ counter,
+                                                             uint32_t grab) {
+    // (C: one past the last channel this launch computes - the model's channel count, or the end of a channel segment when the
+    // launcher splits the channels; feat_stride: ints per image in `feat`)
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const uint32_t wave_id = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nwaves = gridDim.x * 4u;
     const uint32_t n32 = (uint32_t)n;           // the launcher refuses n >= 2^31
-    static_assert(!(PAIR && SAFE), "the pair mode has no SAFE instantiation (the launcher keeps the last images out of it)");
-    const uint32_t nblk = PAIR ? 1u : ((C - c0) > 32u ? 2u : 1u);
-    constexpr uint32_t IMG_BYTES = PAIR ? 512u : 256u;      // bytes of an item's image(s)
+    constexpr bool PAIR = MODE == 1, TRI = MODE == 2;
+    static_assert(!(MODE && SAFE), "the two-image modes have no SAFE instantiation (the launcher keeps the last images out of them)");
+    static_assert(!TRI || FUSE, "the three-item mode serves whole 33..48-channel models");
+    const uint32_t nblk = PAIR ? 1u : TRI ? 3u : ((C - c0) > 32u ? 2u : 1u);
+    constexpr uint32_t IMG_BYTES = MODE ? 512u : 256u;      // bytes of a work unit's image(s); `n` counts units
 
     // A-operand addressing (the same for every image): A row i of tile t is window position 16t + q of band beta
     // (band 1 rows compute conv1 at image row 13 - wr with the kernel the right way up: only the ORDER in which the window
@@ -344,12 +352,12 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         o1p[t >> 2] |= (uint32_t)(16 * g + x) << (8 * (t & 3));
     }
     // (extracted behind an opaque copy, or hipcc hoists the seven extractions out of the item loop - seven registers again)
-    const uint32_t pair_off = PAIR ? (uint32_t)h << 8 : 0u;      // lane half 1 reads the pair's second image
+    uint32_t pair_off = PAIR ? (uint32_t)h << 8 : 0u;      // lane half 1 reads the pair's second image (TRI: set per item)
     auto o1 = [&](int t) -> uint32_t {
         uint32_t w = o1p[t >> 2];
         asm volatile("" : "+v"(w));
         const uint32_t o = (w >> (8 * (t & 3))) & 0xFFu;
-        if constexpr (PAIR) return o | pair_off;
+        if constexpr (MODE != 0) return o | pair_off;
         else return o;
     };
     const int vshift = (int)n_shift;
@@ -361,8 +369,6 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
     // after the other (measured, profiles/cnn_wait_timing.py: the fastest wave of a launch took 3.9 M cycles, the slowest
     // 8.3 M for the same 512 items) and the last quarter of the launch runs at one wave per SIMD with every latency exposed.
     // With the counter every wave works until the images run out.  counter == nullptr: fixed shares (single-image launches).
-    const uint32_t blk_shift = nblk == 2u ? 1u : 0u;
-    const uint32_t per_batch = grab << blk_shift;
     // A operand of a tile: bytes 0-3, 4-7, 8-11 of the lane's 16 K-bytes = image rows g, g+1, g+2 at columns x..x+3
     // (K-slots 12..15 meet zero weights); three L1-resident dword loads, reloaded per channel block.
     auto load_A = [&](const int8_t *ip, uint32_t o) -> i32x4 {
@@ -393,26 +399,27 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
     // the weight table through a wave-uniform descriptor + one 32-bit lane offset (the channel block is a scalar offset)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wtab, 0, (int)(2u * C_pad * CNN_WTAB_DWORDS * 4u), 0x00020000);
     const int wvoff = (int)(((uint32_t)h * C_pad + c0 + (uint32_t)j) * (CNN_WTAB_DWORDS * 4u));
-    auto fetch = [&](uint32_t im, uint32_t bb) -> Head {
+    auto fetch = [&](const int8_t *ip0, uint32_t bb) -> Head {
         Head hd;
         hd.q0 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.q1 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 16, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.q2 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 32, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.q3 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 48, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
         hd.q4 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 64, (int)(bb * 32u * CNN_WTAB_DWORDS * 4u), 0);
-        hd.a0 = load_A(images + (uint64_t)im * IMG_BYTES, o1(0));
+        hd.a0 = load_A(ip0, o1(0));
         return hd;
     };
     // landing zone of the next-image touch: an LDS-DMA load has no register destination to keep reserved
     __shared__ int s_touch[4][64];
     const uint32_t touch_lds = (uint32_t)(uintptr_t)&s_touch[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0];
-    int fo[2][2] = {{0, 0}, {0, 0}};          // the lane's pooled outputs: [block][t & 1], t = 2h + (t & 1)
+    int fo[TRI ? 3 : 2][2] = {};              // the lane's pooled outputs: [block][t & 1], t = 2h + (t & 1)
     // The act bytes of an image are stored at the START of the next item, not at the end of their own: vmcnt counts stores,
     // and the wait hipcc places on the loop's back edge would otherwise park the wave for the write acknowledgement of a
     // store it has just issued (measured: as long as the whole arithmetic of an image).  Deferred, whatever that wait
     // covers is thousands of cycles old.
     const int8_t *pend_row = acts;            // wave-uniform: the pending image's act row
     uint32_t pend_v = 0;                      // block 0's two bytes | block 1's two bytes << 16
+    uint32_t pend_w = 0;                      // TRI: block 2's two bytes
     bool pend = false;
     // stores go through a wave-uniform descriptor of the image's act row (4 C valid bytes) + the lane's constant offset: the
     // range check drops the lanes of channels >= C (and the whole second block of a <= 32-channel model), no lane addresses
@@ -428,14 +435,25 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         const int l = lane_now();
         if constexpr (PAIR) {
             const int ch = l & 15;
-            return (uint32_t)ch < C ? ((l >> 4) & 1) * (int)row + 4 * (int)c0 + 4 * ch + 2 * (l >> 5) : 0x7FFFFF00;
+            return c0 + (uint32_t)ch < C ? ((l >> 4) & 1) * (int)row + 4 * (int)c0 + 4 * ch + 2 * (l >> 5) : 0x1FFFFF00;
         } else {
             return 4 * (int)c0 + 4 * (l & 31) + 2 * (l >> 5);
         }
     };
     auto flush_pending = [&]() {
         if (!pend) return;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)pend_row, 0, (int)((PAIR ? acts_stride : 0u) + 4u * C), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)pend_row, 0, (int)((MODE ? acts_stride : 0u) + 4u * C), 0x00020000);
+        if constexpr (TRI) {
+            // blocks 0 / 1: channel l & 31 of the first / second image; block 2: channel 32 + (l & 15) of the image of the column group
+            const int l = lane_now();
+            const int o01 = 4 * (l & 31) + 2 * (l >> 5);
+            const int o2 = 32u + (uint32_t)(l & 15) < C ? ((l >> 4) & 1) * (int)acts_stride + 128 + 4 * (l & 15) + 2 * (l >> 5) : 0x1FFFFF00;
+            __builtin_amdgcn_raw_buffer_store_b16((short)(pend_v & 0xFFFFu), rs, o01, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((short)(pend_v >> 16), rs, o01, (int)acts_stride, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((short)pend_w, rs, o2, 0, 0);
+            pend = false;
+            return;
+        }
         const int st_off = store_off(acts_stride);
         __builtin_amdgcn_raw_buffer_store_b16((short)(pend_v & 0xFFFFu), rs, st_off, 0, 0);
         if constexpr (!PAIR) __builtin_amdgcn_raw_buffer_store_b16((short)(pend_v >> 16), rs, st_off, 128, 0);     // block 1: scalar offset
@@ -445,24 +463,24 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
     uint64_t t_head = 0, t_tile = 0, t_xchg = 0;
     const uint64_t t_start = CNN_STAMP();
 #endif
-    uint32_t cur_batch = wave_id * grab, off = 0;
+    uint32_t cur_batch = wave_id * grab, unit = 0, blk = 0;      // unit: image (pair) within the batch; blk: its item
 #ifdef BNM_DIAG_TIMING
     uint32_t n_items = 0;
 #endif
     int nxt_v = 0;                            // lane 0: the counter before this wave's add = first image of its next batch - nwaves * grab
     for (;;) {
-        const uint32_t img = cur_batch + (off >> blk_shift);
+        const uint32_t img = cur_batch + unit;
         if (img >= n32) break;                // batches are handed out in increasing order: nothing is left for this wave
-        const uint32_t blk = off & (nblk - 1u);
-        const int8_t *__restrict__ ip = images + (uint64_t)img * IMG_BYTES;       // wave-uniform
+        const int8_t *__restrict__ ip = images + (uint64_t)img * IMG_BYTES + (TRI && blk == 1u ? 256u : 0u);       // wave-uniform
+        if constexpr (TRI) pair_off = blk == 2u ? ((uint32_t)lane_now() & 32u) << 3 : 0u;
         // the batch after this one is requested at the start of this one; the answer is needed `grab` images later
-        if (off == 0 && counter != nullptr && lane_now() == 0)
+        if (unit == 0 && blk == 0 && counter != nullptr && lane_now() == 0)
             nxt_v = (int)__hip_atomic_fetch_add(counter, grab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // Touch the wave's NEXT image (64 lanes x 4 B = its 256 bytes) so that its patch loads hit the cache instead of waiting
         // a microsecond for HBM.  The data is never used: an LDS-DMA load drops it into a per-wave landing zone.
         if (blk == 0) {
             uint32_t ni = img + 1u;
-            if ((off >> blk_shift) + 1u == grab)     // last image of the batch: the next one opens the next batch
+            if (unit + 1u == grab)                   // last image of the batch: the next one opens the next batch
                 ni = counter != nullptr ? (grab > 1u ? nwaves * grab + (uint32_t)__builtin_amdgcn_readfirstlane(nxt_v) : n32)
                                         : cur_batch + nwaves * grab;
             if (ni < n32) {
@@ -471,12 +489,12 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
                 const int lane4 = lane_now() * 4;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(lane4), "s"(touch_lds), "s"(np) : "memory");
-                if constexpr (PAIR)
+                if constexpr (MODE != 0)
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3 offset:256\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep) : "v"(lane4), "s"(touch_lds), "s"(np) : "memory");
             }
         }
-        const Head cur = fetch(img, blk);
+        const Head cur = fetch(ip, TRI ? (blk == 2u ? 1u : 0u) : blk);
 #ifdef BNM_DIAG_TIMING
         {
             const uint64_t t0 = CNN_STAMP();
@@ -586,31 +604,58 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
             const int v = max(max(m, ob3[2 * x + 1]), 0) >> n_shift;
             fo[0][x] = blk == 0 ? v : fo[0][x];
             fo[1][x] = blk == 1 ? v : fo[1][x];
+            if constexpr (TRI) fo[2][x] = blk == 2 ? v : fo[2][x];
         }
         if (blk + 1 == nblk) {
             // ---- outputs: lane (j, h), block b: channel c0 + 32 b + j, values t = 2h, 2h + 1 ---------------------------------
             if (feat) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(feat + (uint64_t)img * ((PAIR ? 8ull : 4ull) * C)), 0,
-                                                                                   (int)((PAIR ? 32u : 16u) * C), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(feat + (uint64_t)img * ((MODE ? 2ull : 1ull) * feat_stride)), 0,
+                                                                                   (int)((MODE ? 4u * feat_stride : 0u) + 16u * C), 0x00020000);
                 typedef int i32x2 __attribute__((ext_vector_type(2)));
-                const int f_off = 4 * store_off(4u * C);
-                __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[0][0], fo[0][1]}, rs, f_off, 0, 0);
-                if constexpr (!PAIR) __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[1][0], fo[1][1]}, rs, f_off, 512, 0);
+                if constexpr (TRI) {
+                    const int l = lane_now();
+                    const int o01 = 16 * (l & 31) + 8 * (l >> 5);
+                    const int o2 = 32u + (uint32_t)(l & 15) < C ? ((l >> 4) & 1) * 4 * (int)feat_stride + 512 + 16 * (l & 15) + 8 * (l >> 5) : 0x7FFFFC00;
+                    __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[0][0], fo[0][1]}, rs, o01, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[1][0], fo[1][1]}, rs, o01, (int)(4u * feat_stride), 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[2][0], fo[2][1]}, rs, o2, 0, 0);
+                } else {
+                    const int f_off = 4 * store_off(feat_stride);
+                    __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[0][0], fo[0][1]}, rs, f_off, 0, 0);
+                    if constexpr (!PAIR) __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo[1][0], fo[1][1]}, rs, f_off, 512, 0);
+                }
             }
             if constexpr (FUSE) {
                 // fused ReLUNorm over the 4*C features (all >= 0; channels >= C have zero weights and contribute 0)
-                const int mxl = max(max(fo[0][0], fo[0][1]), nblk == 2u ? max(fo[1][0], fo[1][1]) : 0);
-                int mx;
-                if constexpr (PAIR) mx = pair_max_nonneg(mxl, (lane_now() & 16) != 0);
-                else mx = wave_max_nonneg(mxl);
-                const uint32_t tt = (uint32_t)mx >> 7;
-                const int sh = tt ? 32 - __builtin_clz(tt) : 0;
-                const int rnd = (1 << sh) >> 1;
-                pend_v = 0;
+                auto norm2 = [](int a, int b2, int sh, int rnd) -> uint32_t {
+                    return (uint32_t)min((a + rnd) >> sh, 127) | ((uint32_t)min((b2 + rnd) >> sh, 127) << 8);
+                };
+                auto shift_of = [](int mx) -> int {
+                    const uint32_t tt = (uint32_t)mx >> 7;
+                    return tt ? 32 - __builtin_clz(tt) : 0;
+                };
+                if constexpr (TRI) {
+                    // first image: block 0 + column group 0 of block 2; second image: block 1 + column group 1 of block 2
+                    const bool second = (lane_now() & 16) != 0;
+                    const int m2 = max(fo[2][0], fo[2][1]);
+                    const int ma = wave_max_nonneg(max(max(fo[0][0], fo[0][1]), second ? 0 : m2));
+                    const int mb = wave_max_nonneg(max(max(fo[1][0], fo[1][1]), second ? m2 : 0));
+                    const int sa = shift_of(ma), sb = shift_of(mb);
+                    const int s2 = second ? sb : sa;
+                    pend_v = norm2(fo[0][0], fo[0][1], sa, (1 << sa) >> 1) | (norm2(fo[1][0], fo[1][1], sb, (1 << sb) >> 1) << 16);
+                    pend_w = norm2(fo[2][0], fo[2][1], s2, (1 << s2) >> 1);
+                } else {
+                    const int mxl = max(max(fo[0][0], fo[0][1]), nblk == 2u ? max(fo[1][0], fo[1][1]) : 0);
+                    int mx;
+                    if constexpr (PAIR) mx = pair_max_nonneg(mxl, (lane_now() & 16) != 0);
+                    else mx = wave_max_nonneg(mxl);
+                    const int sh = shift_of(mx);
+                    const int rnd = (1 << sh) >> 1;
+                    pend_v = 0;
 #pragma unroll
-                for (uint32_t bb = 0; bb < 2; bb++)
-                    pend_v |= ((uint32_t)min((fo[bb][0] + rnd) >> sh, 127) | ((uint32_t)min((fo[bb][1] + rnd) >> sh, 127) << 8)) << (16 * bb);
-                pend_row = acts + (uint64_t)img * ((PAIR ? 2ull : 1ull) * (uint64_t)acts_stride);
+                    for (uint32_t bb = 0; bb < 2; bb++) pend_v |= norm2(fo[bb][0], fo[bb][1], sh, rnd) << (16 * bb);
+                }
+                pend_row = acts + (uint64_t)img * ((MODE ? 2ull : 1ull) * (uint64_t)acts_stride);
                 pend = true;
             }
         }
@@ -618,9 +663,12 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
 #ifdef BNM_DIAG_TIMING
         n_items++;
 #endif
-        if (++off == per_batch) {
-            off = 0;
-            cur_batch = counter != nullptr ? nwaves * grab + (uint32_t)__builtin_amdgcn_readfirstlane(nxt_v) : cur_batch + nwaves * grab;
+        if (++blk == nblk) {
+            blk = 0;
+            if (++unit == grab) {
+                unit = 0;
+                cur_batch = counter != nullptr ? nwaves * grab + (uint32_t)__builtin_amdgcn_readfirstlane(nxt_v) : cur_batch + nwaves * grab;
+            }
         }
     }
     flush_pending();
@@ -635,22 +683,34 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------
+// Channel segments of a model with C channels: whole groups of 64 (two 32-channel items per image), then the remainder R:
+// R <= 16 one PAIR segment (two images per item), R <= 32 one 32-channel item, R <= 48 a 32-channel item + a PAIR segment,
+// else two 32-channel items.  `pair0` = first channel of the PAIR segment (== C: none).
+static uint32_t cnn_pair_segment_start(uint32_t C) {
+    const uint32_t R = C % 64u;
+    if (R == 0u) return C;
+    if (R <= 16u) return C - R;
+    if (R > 32u && R <= 48u) return C - R + 32u;
+    return C;
+}
+
 // Host-side weight table for cnn_front_mfma_kernel (layout above).  w1/w2/w3: int8 [C][9] as in the header; out:
 // 2 * C_pad * 20 ints with C_pad = C rounded up to 64 (surplus channels: zero weights).
-// C <= 16 (the pair mode's layout, which the one-image instantiations read just as well): lane columns 16..31 repeat channels
-// 0..15, and a column's conv1 weights sit in the K-half of its column group - K-slots 0..15 (band 0's entry) for columns 0..15,
-// K-slots 16..31 (band 1's entry) for columns 16..31.  With one image in both K-halves of the A operand the columns 16..31
-// merely recompute channels 0..15 (their stores fall outside the 4 C valid output bytes).
+// The PAIR segment's 32 table columns (the pair mode's layout, which the one-image instantiations read just as well): columns
+// 16..31 repeat the segment's channels, and a column's conv1 weights sit in the K-half of its column group - K-slots 0..15
+// (band 0's entry) for columns 0..15, K-slots 16..31 (band 1's entry) for columns 16..31.  With one image in both K-halves of
+// the A operand the columns 16..31 merely recompute the segment's channels (their stores fall outside the valid output bytes).
 void bnm_cnn_weight_table(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int *out) {
     const uint32_t C_pad = (C + 63u) / 64u * 64u;
     for (uint32_t i = 0; i < 2u * C_pad * CNN_WTAB_DWORDS; i++) out[i] = 0;
-    const bool pair = C <= 16u;
+    const uint32_t pair0 = cnn_pair_segment_start(C);
     for (uint32_t band = 0; band < 2; band++)
-        for (uint32_t col = 0; col < (pair ? 32u : C); col++) {
-            const uint32_t c = pair ? (col & 15u) : col;
+        for (uint32_t col = 0; col < (pair0 < C ? pair0 + 32u : C); col++) {
+            const bool pair = col >= pair0;
+            const uint32_t c = pair ? pair0 + ((col - pair0) & 15u) : col;
             if (c >= C) continue;
             int *e = out + ((size_t)band * C_pad + col) * CNN_WTAB_DWORDS;
-            if (band == (pair ? col >> 4 : 0u)) {
+            if (band == (pair ? (col - pair0) >> 4 : 0u)) {
                 uint8_t bytes[16] = {0};
                 for (int dy = 0; dy < 3; dy++)
                     for (int dx = 0; dx < 3; dx++) bytes[4 * dy + dx] = (uint8_t)w1[9u * c + 3 * dy + dx];
@@ -688,47 +748,74 @@ hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, co
     // MFMA kernel: batches of `grab` images from word 0 of the counter block (all zero between launches: the waves' first batches
     // are static, the counter hands out what follows); counter == nullptr or grab == 0: fixed shares of single images
     if (!counter || !grab) { counter = nullptr; grab = 1; }
-    if (C <= 16 && wtab) {
-        // two images per item: images [0, 2 * pairs) through the pair instantiation, the last one or two through the SAFE one
-        const uint64_t pairs = (n - 1) / 2, rest = n - 2 * pairs;
-        if (pairs) {
-            uint64_t pb = (pairs + 3) / 4;
-            if (pb > cap) pb = cap;
-            cnn_front_mfma_kernel<true, false, true><<<dim3((unsigned)pb), b, 0, s>>>(images, pairs, wtab, C_pad, C, 0, n_shift, acts, acts_stride, feat,
-                                                                                     counter, grab);
+    if (!wtab) {      // round 1's all-VALU kernel
+        if (C <= 64) {
+            cnn_front_kernel<true><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, 0, n_shift, acts, acts_stride, feat);
+            return hipGetLastError();
         }
+        if (!feat) return hipErrorInvalidValue;
+        for (uint32_t c0 = 0; c0 < C; c0 += 64) {
+            cnn_front_kernel<false><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, c0, n_shift, acts, acts_stride, feat);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        return bnmk_relunorm(feat, 4u * C, acts, acts_stride, nullptr, n, s);
+    }
+    // PAIR segments: images [0, 2 * pairs) two per item, the last one or two through the SAFE one-image instantiation
+    const uint64_t pairs = (n - 1) / 2, rest = n - 2 * pairs;
+    uint64_t pb = (pairs + 3) / 4;
+    if (pb > cap) pb = cap;
+    const dim3 gp((unsigned)pb);
+    const uint32_t pair0 = cnn_pair_segment_start(C);
+    if (C <= 16) {
+        if (pairs)
+            cnn_front_mfma_kernel<true, false, 1><<<gp, b, 0, s>>>(images, pairs, wtab, C_pad, C, 0, n_shift, acts, acts_stride, feat, 4u * C,
+                                                                    counter, grab);
         cnn_front_mfma_kernel<true, true><<<dim3(1), b, 0, s>>>(images + 2 * pairs * 256ull, rest, wtab, C_pad, C, 0, n_shift,
                                                               acts + 2 * pairs * (uint64_t)acts_stride, acts_stride,
-                                                              feat ? feat + 2 * pairs * 4ull * C : nullptr, nullptr, 1);
+                                                              feat ? feat + 2 * pairs * 4ull * C : nullptr, 4u * C, nullptr, 1);
+        return hipGetLastError();
+    }
+    if (C > 32 && C <= 48) {
+        // three items per image pair (the third: channels 32..47 of both images); the last one or two images one per item
+        if (pairs)
+            cnn_front_mfma_kernel<true, false, 2><<<gp, b, 0, s>>>(images, pairs, wtab, C_pad, C, 0, n_shift, acts, acts_stride, feat, 4u * C, counter, grab);
+        cnn_front_mfma_kernel<true, true><<<dim3(1), b, 0, s>>>(images + 2 * pairs * 256ull, rest, wtab, C_pad, C, 0, n_shift,
+                                                              acts + 2 * pairs * (uint64_t)acts_stride, acts_stride,
+                                                              feat ? feat + 2 * pairs * 4ull * C : nullptr, 4u * C, nullptr, 1);
         return hipGetLastError();
     }
     if (C <= 64) {
-        if (wtab) {
-            if (n_main) {
-                cnn_front_mfma_kernel<true, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, 0, n_shift, acts, acts_stride, feat, counter, grab);
-            }
-            cnn_front_mfma_kernel<true, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, C, 0, n_shift,
-                                                                  acts + n_main * (uint64_t)acts_stride, acts_stride,
-                                                                  feat ? feat + n_main * 4ull * C : nullptr, nullptr, 1);
-        } else {
-            cnn_front_kernel<true><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, 0, n_shift, acts, acts_stride, feat);
-        }
+        if (n_main)
+            cnn_front_mfma_kernel<true, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, 0, n_shift, acts, acts_stride, feat, 4u * C, counter, grab);
+        cnn_front_mfma_kernel<true, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, C, 0, n_shift,
+                                                              acts + n_main * (uint64_t)acts_stride, acts_stride,
+                                                              feat ? feat + n_main * 4ull * C : nullptr, 4u * C, nullptr, 1);
         return hipGetLastError();
     }
+    // several channel segments: every segment writes its int32 features, ReLUNorm runs as its own kernel over the complete vector.
+    // The launches of one call share the counter block: each one leaves it zeroed for the next (stream order).
     if (!feat) return hipErrorInvalidValue;
-    for (uint32_t c0 = 0; c0 < C; c0 += 64) {
-        if (wtab) {
-            if (n_main) {
-                cnn_front_mfma_kernel<false, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, C, c0, n_shift, acts, acts_stride, feat, counter, grab);
-            }
-            cnn_front_mfma_kernel<false, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, C, c0, n_shift,
-                                                                   acts + n_main * (uint64_t)acts_stride, acts_stride, feat + n_main * 4ull * C,
-                                                                   nullptr, 1);
+    for (uint32_t c0 = 0; c0 < C;) {
+        const bool pair = c0 == pair0;
+        const uint32_t c_end = pair ? C : (c0 + 64u <= pair0 ? c0 + 64u : (pair0 < C ? pair0 : C));
+        if (pair) {
+            if (pairs)
+                cnn_front_mfma_kernel<false, false, 1><<<gp, b, 0, s>>>(images, pairs, wtab, C_pad, c_end, c0, n_shift, acts, acts_stride, feat, 4u * C,
+                                                                         counter, grab);
+            cnn_front_mfma_kernel<false, true><<<dim3(1), b, 0, s>>>(images + 2 * pairs * 256ull, rest, wtab, C_pad, c_end, c0, n_shift,
+                                                                   acts + 2 * pairs * (uint64_t)acts_stride, acts_stride,
+                                                                   feat + 2 * pairs * 4ull * C, 4u * C, nullptr, 1);
         } else {
-            cnn_front_kernel<false><<<g, b, 0, s>>>(images, n, w1, w2, w3, C, c0, n_shift, acts, acts_stride, feat);
+            if (n_main)
+                cnn_front_mfma_kernel<false, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, c_end, c0, n_shift, acts, acts_stride, feat, 4u * C, counter, grab);
+            cnn_front_mfma_kernel<false, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, c_end, c0, n_shift,
+                                                                   acts + n_main * (uint64_t)acts_stride, acts_stride, feat + n_main * 4ull * C,
+                                                                   4u * C, nullptr, 1);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
+        c0 = c_end;
     }
     return bnmk_relunorm(feat, 4u * C, acts, acts_stride, nullptr, n, s);
 }

@@ -118,6 +118,9 @@ hipError_t bnmk_maxpool22(const int32_t *d_in, uint32_t xy, int32_t *d_out, hipS
 // nullptr to run the all-VALU kernel of round 1 (kept for A/B measurements, bnm_ctx_set_cnn_variant)
 // d_counter / grab: the MFMA kernel's waves take batches of `grab` images from word 0 of this counter block (all zero on entry,
 // left all zero); nullptr / 0: a fixed share per wave
+// Channel segments (MFMA kernel): a model's last <= 16 channels beyond a multiple of 32 (C <= 16; 33..48; 65..80; ...) run TWO
+// images per item - up to 48 channels inside the one fused launch, beyond 64 as one of several channel segments that each
+// write d_feat (REQUIRED then), ReLUNorm running as its own kernel afterwards
 hipError_t bnmk_cnn_front(const int8_t *d_images, uint64_t n, const int8_t *d_w1, const int8_t *d_w2,
                           const int8_t *d_w3, const int *d_wtab, uint32_t C, uint32_t n_shift, int8_t *d_acts,
                           uint32_t acts_stride, int32_t *d_feat, uint32_t *d_counter, uint32_t grab, hipStream_t s);

@@ -201,7 +201,8 @@ def test_cnn_front_end_both_kernels(name, gpu_ok, orc):
     want = om.infer(x, logits=True)
     for variant in (1, 0):
         ctx.set_cnn_variant(variant)
-        for n in (len(x), 1, 5):
+        # (<= 16 channels: two images per item, the last one or two images through the single-image instantiation)
+        for n in (len(x), 1, 5, 2, 3, 4, 1000):
             got = ctx.infer(x[:n], logits=True)
             assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (name, variant, n)
     ctx.close()
@@ -735,18 +736,28 @@ def test_random_shapes_through_the_generic_fused_kernel(codecs, widths, n_classe
     (24, (2, 4, 4), (96, 64), 10),      # 96-byte act rows -> padded to 128
     (40, (4, 4, 4), (64, 32), 10),      # 160 -> 256
     (80, (2, 4, 4), (96, 64), 10),      # the 80-wide CNN of docs/documentation.md:898: 320 -> 512, two channel groups
-    (8, (4, 4, 4), (32, 32), 37),       # 32 -> 64
+    (8, (4, 4, 4), (32, 32), 37),       # 32 -> 64; <= 16 channels: two images per front-end item
+    (12, (16, 4, 4), (32, 32), 10),     # 48 -> 64
+    (44, (4, 4, 4), (64, 32), 10),      # 32 channels one image per item + 12 channels two images per item, separate ReLUNorm
+    (48, (2, 4, 4), (96, 64), 10),
+    (72, (2, 4, 4), (96, 64), 10),      # 64 + 8
+    (112, (4, 4, 4), (64, 64), 10),     # 64 + 32 + 16: all three kinds of segment
+    (100, (16, 4, 4), (64, 64), 10),    # 64 + 32 + 4
 ])
 def test_random_cnn_channel_counts_through_the_generic_tail(C, codecs, widths, n_classes, gpu_ok, orc):
     rng = np.random.default_rng(C * 1000 + n_classes)
     model = b.Model.from_header_text(_random_cnn_text(rng, C, codecs, widths, n_classes))
     om = util.OracleModel(model, orc)
     ctx = b.Context(model)
-    assert ctx.path == b.PATH_FUSED_MFMA and ctx.variant == 4
-    x = np.concatenate([synth.images(3, 700, DIST_U), synth.images(3, 701, DIST_M)])
+    assert ctx.path == b.PATH_FUSED_MFMA
+    x = np.concatenate([synth.images(3, 700, DIST_U), synth.images(3, 701, DIST_M), np.full((1, 256), -128, np.int8)])
     want = om.infer(x, logits=True)
-    got = ctx.infer(x, logits=True)
-    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # front end: fixed shares, round 1's kernel, the default (dynamic batches)
+    for cv in (2, 0, 1):
+        ctx.set_cnn_variant(cv)
+        for n in (len(x), 1, 2, 3, 4, 7):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, cv, n)
     ctx.set_path(b.PATH_LAYERWISE_ALU)
     got = ctx.infer(x, logits=True)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
