@@ -469,6 +469,10 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     # configs[3]: CNN 64-wide
     r, m = run("cnn_64", "cnn_64", n_cnn, 3, 1, note="BASELINE configs[3]")
     res["cnn_64"]["roofline"] = valu(r, "cnn_front_mfma_kernel", BYTES_PER_INFERENCE, m)
+    # the reference's smaller published CNNs (mcu/BitNetMCU_model_cnn_16.h, _48.h): their last <= 16 channels run two images per item
+    for nm in ("mcu_cnn_16", "mcu_cnn_48"):
+        r, m = run(nm, nm, n_cnn, 3, 1, note="reference's published CNN family; two images per work item for the last <= 16 channels")
+        res[nm]["roofline"] = valu(r, None, BYTES_PER_INFERENCE, m)
     # headline model through the generic kernel (what any non-zoo 64-wide export would get)
     r, _ = run("fc_generic_kernel", "fc_4bitsym_64", n, 10, 3, variant=4)
     hbm_entry("fc_generic_kernel", r, BYTES_PER_INFERENCE)
