@@ -499,33 +499,38 @@ def test_bench_json_contract(gpu_ok):
         assert ex[row]["cpu_baseline"]["value"] > 0 and ex[row]["cpu_baseline"]["kind"] in ("reference", "port")
 
 
+def _fc_layer_lines(rng, k, bpw, n_in, n_out, trit_digits=None):
+    """One FC layer of an exporter-dialect header with RANDOM packed weights.  Ternary layers get the exporter's padding to a
+    multiple of 10 (pad trits = 0); trit_digits(layer, n_out, n_in) -> base-3 digits (0: +1, 1: -1, 2: 0) replaces the random trits."""
+    if bpw == 64:
+        padded = (n_in + 9) // 10 * 10
+        trits = rng.integers(0, 3, size=(n_out, padded))
+        if trit_digits is not None:
+            trits[:, :n_in] = trit_digits(k, n_out, n_in)
+        trits[:, n_in:] = 2                                   # pad = zero weight (exportquant.py:132-137)
+        # base-3, most significant trit first, per 10-trit group (exportquant.py:146-156)
+        g = trits.reshape(n_out, padded // 10, 10)
+        v = np.zeros((n_out, padded // 10), np.int64)
+        for t in range(10):
+            v = v * 3 + g[:, :, t]
+        w = ((v * 65536 + 59048) // 59049).astype(np.uint16).ravel()
+        decl, n_decl = "uint16_t", padded
+    else:
+        fb = {1: 1, 2: 2, 4: 4, 12: 4, 20: 4, 16: 8}.get(bpw, 4)
+        w = rng.integers(0, 2**32, size=n_out * (n_in * fb // 32), dtype=np.uint32)
+        decl, n_decl = "uint32_t", n_in
+    return [f"#define L{k}_active", f"#define L{k}_bitperweight {bpw}", f"#define L{k}_incoming_weights {n_decl}",
+            f"#define L{k}_outgoing_weights {n_out}", f"const {decl} L{k}_weights[] = {{" + ",".join(hex(int(x)) for x in w) + "};"]
+
+
 def _random_model_text(rng, codecs, widths, n_classes=10, trit_digits=None):
     """Header text of an FC model with RANDOM packed weights: every codec id through the whole-model kernels, in
-    shapes of the fused table.  Ternary layers get the exporter's padding to a multiple of 10 (pad trits = 0).
-    trit_digits(layer, n_out, n_in) -> base-3 digits (0: +1, 1: -1, 2: 0) replaces the random trits of ternary layers."""
+    shapes of the fused table."""
     lines = ["#include <stdint.h>", "#define MODEL_FCMNIST", "#define NUM_LAYERS %d" % len(codecs), "#define MAX_N_ACTIVATIONS 256"]
     n_in = 256
     outs = list(widths) + [n_classes]
     for k, (bpw, n_out) in enumerate(zip(codecs, outs), start=1):
-        if bpw == 64:
-            padded = (n_in + 9) // 10 * 10
-            trits = rng.integers(0, 3, size=(n_out, padded))
-            if trit_digits is not None:
-                trits[:, :n_in] = trit_digits(k, n_out, n_in)
-            trits[:, n_in:] = 2                                   # pad = zero weight (exportquant.py:132-137)
-            # base-3, most significant trit first, per 10-trit group (exportquant.py:146-156)
-            g = trits.reshape(n_out, padded // 10, 10)
-            v = np.zeros((n_out, padded // 10), np.int64)
-            for t in range(10):
-                v = v * 3 + g[:, :, t]
-            w = ((v * 65536 + 59048) // 59049).astype(np.uint16).ravel()
-            decl, n_decl = "uint16_t", padded
-        else:
-            fb = {1: 1, 2: 2, 4: 4, 12: 4, 20: 4, 16: 8}.get(bpw, 4)
-            w = rng.integers(0, 2**32, size=n_out * (n_in * fb // 32), dtype=np.uint32)
-            decl, n_decl = "uint32_t", n_in
-        lines += [f"#define L{k}_active", f"#define L{k}_bitperweight {bpw}", f"#define L{k}_incoming_weights {n_decl}",
-                  f"#define L{k}_outgoing_weights {n_out}", f"const {decl} L{k}_weights[] = {{" + ",".join(hex(int(x)) for x in w) + "};"]
+        lines += _fc_layer_lines(rng, k, bpw, n_in, n_out, trit_digits)
         n_in = n_out
     return "\n".join(lines) + "\n"
 
@@ -688,10 +693,7 @@ def _random_cnn_text(rng, C, codecs, widths, n_classes=10):
     pool(9, 4)
     n_in = 4 * C
     for k, bpw, n_out in zip((11, 13, 15), codecs, list(widths) + [n_classes]):
-        fb = {1: 1, 2: 2, 4: 4, 12: 4, 20: 4, 16: 8}[bpw]
-        w = rng.integers(0, 2**32, size=n_out * (n_in * fb // 32), dtype=np.uint32)
-        lines.extend([f"#define L{k}_active", f"#define L{k}_bitperweight {bpw}", f"#define L{k}_incoming_weights {n_in}",
-                      f"#define L{k}_outgoing_weights {n_out}", f"const uint32_t L{k}_weights[] = {{" + ",".join(hex(int(x)) for x in w) + "};"])
+        lines.extend(_fc_layer_lines(rng, k, bpw, n_in, n_out))
         n_in = n_out
     return "\n".join(lines) + "\n"
 
@@ -743,6 +745,11 @@ def test_random_shapes_through_the_generic_fused_kernel(codecs, widths, n_classe
     (72, (2, 4, 4), (96, 64), 10),      # 64 + 8
     (112, (4, 4, 4), (64, 64), 10),     # 64 + 32 + 16: all three kinds of segment
     (100, (16, 4, 4), (64, 64), 10),    # 64 + 32 + 4
+    # the wide CNNs of docs/documentation_cnn.md:186-191: ternary first FC layer (padded input counts 320 / 390 / 520)
+    (80, (64, 4, 4), (96, 64), 10),
+    (96, (64, 4, 4), (96, 64), 10),
+    (128, (64, 4, 4), (96, 64), 10),
+    (64, (64, 4, 4), (96, 64), 10),     # ... and the same tail behind the fused 64-channel front end
 ])
 def test_random_cnn_channel_counts_through_the_generic_tail(C, codecs, widths, n_classes, gpu_ok, orc):
     rng = np.random.default_rng(C * 1000 + n_classes)
