@@ -5,6 +5,19 @@
 #include "bnm_fused_tile.hpp"
 #include "bnm_fused_math.hpp"
 
+// Measurement scaffolding of the diagnostic builds (build.py --diag / --diag-timing; profiles/wait_timing.py, slow_state_probe.py):
+// compiled out of the product library.
+#ifdef BNM_DIAG
+#define DIAG_ONLY(...) __VA_ARGS__
+#else
+#define DIAG_ONLY(...)
+#endif
+#ifdef BNM_DIAG_TIMING
+#define DIAG_TIMING(...) __VA_ARGS__      // shader-clock stamps around the kernel's two waits
+#else
+#define DIAG_TIMING(...)
+#endif
+
 // =================================================================================================
 // Fused whole-model FC kernel.
 //
@@ -421,11 +434,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
     uint64_t img_prev = (pair << 6) + (uint64_t)lane;
     uint32_t cls_prev = 0;
     uint64_t store_mask = 0;      // exec mask of the deferred store: empty in a wave's first iteration
-#ifdef BNM_DIAG_TIMING
-    // diagnostic build only (build.py --diag-timing; profiles/wait_timing.py): shader-clock stamps around the two waits
-    uint64_t t_wait_a = 0, t_wait_b = 0, t_iters = 0;
-    const uint64_t t_start = __builtin_readcyclecounter();
-#endif
+    DIAG_TIMING(uint64_t t_wait_a = 0, t_wait_b = 0, t_iters = 0; const uint64_t t_start = __builtin_readcyclecounter();)
     while (pair < n_pairs) {
         // the refill after the last pair re-reads that pair (keeps the wait counts constant and the body branch-free)
         uint64_t cand;
@@ -441,26 +450,17 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
         const uint64_t next = cand < n_pairs ? cand : pair;
         // outstanding, oldest first: slot 0 (8 pieces), [the deferred store], slot 1 (8 pieces).
         // Loads retire in order among themselves, so "<= 8 left" implies slot 0 has landed.
-#ifdef BNM_DIAG_TIMING
-        const uint64_t t0 = __builtin_readcyclecounter();
-#endif
+        DIAG_TIMING(const uint64_t t0 = __builtin_readcyclecounter();)
         bnm_wait_vmcnt<8>();
-#ifdef BNM_DIAG_TIMING
-        t_wait_a += __builtin_readcyclecounter() - t0;
-        t_iters++;
-#endif
+        DIAG_TIMING(t_wait_a += __builtin_readcyclecounter() - t0; t_iters++;)
         i32x4 bA[KT0], bB[KT0];
         i32x16 a1A[M1], a1B[M1];
         read_tile(0, bA);
         layer_mma<M1, KT0, false>(A1, bA, a1A);
         dma_tile(2ull * next, 0);
-#ifdef BNM_DIAG_TIMING
-        const uint64_t t2 = __builtin_readcyclecounter();
-#endif
+        DIAG_TIMING(const uint64_t t2 = __builtin_readcyclecounter();)
         bnm_wait_vmcnt<8>();     // slot 1 is now the oldest load group
-#ifdef BNM_DIAG_TIMING
-        t_wait_b += __builtin_readcyclecounter() - t2;
-#endif
+        DIAG_TIMING(t_wait_b += __builtin_readcyclecounter() - t2;)
 #ifdef BNM_DIAG
         diag_store(diag_store_mode, cls_out, img_prev, pair_prev, cls_prev, left, batch, lane, store_mask);
 #else
@@ -529,18 +529,14 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
         img_prev = h ? imgB : imgA;
         cls_prev = h ? clsB : clsA;
         store_mask = ~0ull;
-#ifdef BNM_DIAG
-        pair_prev = pair;
-#endif
+        DIAG_ONLY(pair_prev = pair;)
         pair = cand;
         if constexpr (DEVWIDE) left = left != 0u ? left - 1u : batch - 1u;
     }
     // the loop's final take is still in flight: retire it before its result register can be given to anything else
     if constexpr (DEVWIDE) work_take_wait(taken);
     if (any) __builtin_nontemporal_store(cls_prev, cls_out + img_prev);
-#ifdef BNM_DIAG
-    if (diag_store_mode == 6u) asm volatile("s_dcache_wb" ::: "memory");
-#endif
+    DIAG_ONLY(if (diag_store_mode == 6u) asm volatile("s_dcache_wb" ::: "memory");)
     bnm_wait_vmcnt<0>();   // LDS-DMA still in flight must not outlive the workgroup's LDS allocation
     // the launch's counter block goes back to all-zero with the last wave to leave
     if constexpr (DEVWIDE) work_block_leave_s(work, total_waves);
