@@ -633,12 +633,14 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
     // chunks: 2^22 images when the fused tail consumes the act rows directly (1 GiB of act rows; every launch has a ramp and a
     // tail, so fewer, larger launches: +2 % over 2^20), 2^20 when the int32 features are needed as well (> 64 channels, taps)
     // or the layer-wise tail runs (its scratch is sized for kChunk)
-    const bool need_feat = c->channels > 64 || d_acts_tap != nullptr;
-    const uint64_t chunk = (!need_feat && path == BNM_PATH_FUSED_MFMA) ? kCnnChunk : kChunk;
+    // (65..128 channels on the MFMA front end: one fused launch, the feature buffer is two images of scratch)
+    const bool feat_all = d_acts_tap != nullptr || c->channels > 128 || (c->channels > 64 && !c->cnn_variant);
+    const bool need_feat = c->channels > 64 || feat_all;
+    const uint64_t chunk = (!feat_all && path == BNM_PATH_FUSED_MFMA) ? kCnnChunk : kChunk;
     for (uint64_t off = 0; off < n; off += chunk) {
         uint64_t cn = n - off < chunk ? n - off : chunk;
         // the FC tail reads act rows with 16-byte vector loads: keep the buffer padded
-        const size_t feat_bytes = need_feat ? (size_t)cn * W * 4 : 0;
+        const size_t feat_bytes = feat_all ? (size_t)cn * W * 4 : need_feat ? (size_t)2 * W * 4 : 0;
         DevBuf &cnn_feat = stream_scratch(c, s).cnn_feat;
         uint32_t *block = nullptr;
         if (int e = work_block(c, s, &block)) return e;
@@ -646,7 +648,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         int32_t *feat = need_feat ? (int32_t *)cnn_feat.p : nullptr;
         int8_t *acts = (int8_t *)cnn_feat.p + feat_bytes;
         HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,
-                               c->channels, 4, acts, AS, feat, block, c->cnn_grab, s));
+                               c->channels, 4, acts, AS, feat, d_acts_tap != nullptr, block, c->cnn_grab, s));
         uint32_t *cls = d_cls + off;
         int32_t *lg = d_logits ? d_logits + off * ncls : nullptr;
         if (d_acts_tap)

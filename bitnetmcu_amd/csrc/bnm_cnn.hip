@@ -319,6 +319,10 @@ hipError_t bnmk_diag_cnn_set_record(uint64_t *d_rec) { return hipMemcpyToSymbol(
 // MODE 2 (TRI, models with 33..48 channels, FUSE only): a unit is again a pair of images, done as THREE items - channels 0..31 of
 // the first image, channels 0..31 of the second, and channels 32..47 of both in the pair layout - instead of two items per
 // image with the second one half empty.
+// MODE 3 (GEN, 65..128 channels, FUSE only): a unit is a pair of images done as nbf items of the first image (its whole
+// 32-channel blocks), nbf of the second and - when the channel count leaves <= 16 channels beyond a multiple of 32 - one item
+// in the pair layout; the pooled outputs wait in LDS (2 KiB..4.5 KiB per wave) instead of registers for the fused ReLUNorm over
+// the 4 C features of each image, so no int32 features travel through HBM and no separate ReLUNorm kernel runs.
 template <bool FUSE, bool SAFE, int MODE = 0>
 __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                              const int *__restrict__ wtab, uint32_t C_pad, uint32_t C, uint32_t c0,
@@ -332,10 +336,19 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
     const uint32_t wave_id = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nwaves = gridDim.x * 4u;
     const uint32_t n32 = (uint32_t)n;           // the launcher refuses n >= 2^31
-    constexpr bool PAIR = MODE == 1, TRI = MODE == 2;
+    constexpr bool PAIR = MODE == 1, TRI = MODE == 2, GEN = MODE == 3;
     static_assert(!(MODE && SAFE), "the two-image modes have no SAFE instantiation (the launcher keeps the last images out of them)");
-    static_assert(!TRI || FUSE, "the three-item mode serves whole 33..48-channel models");
-    const uint32_t nblk = PAIR ? 1u : TRI ? 3u : ((C - c0) > 32u ? 2u : 1u);
+    static_assert(!(TRI || GEN) || FUSE, "the three-item and the general mode serve whole models");
+    // GEN: first channel of the pair segment (== C: none; the rule of cnn_pair_segment_start) and whole blocks per image
+    uint32_t gen_pair0 = C;
+    if (GEN) {
+        const uint32_t R = C & 63u;
+        if (R != 0u && R <= 16u) gen_pair0 = C - R;
+        else if (R > 32u && R <= 48u) gen_pair0 = C - R + 32u;
+    }
+    const uint32_t nbf = (gen_pair0 + 31u) / 32u;
+    const bool gen_pair = gen_pair0 < C;
+    const uint32_t nblk = PAIR ? 1u : TRI ? 3u : GEN ? 2u * nbf + (gen_pair ? 1u : 0u) : ((C - c0) > 32u ? 2u : 1u);
     constexpr uint32_t IMG_BYTES = MODE ? 512u : 256u;      // bytes of a work unit's image(s); `n` counts units
 
     // A-operand addressing (the same for every image): A row i of tile t is window position 16t + q of band beta
@@ -413,6 +426,10 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
     __shared__ int s_touch[4][64];
     const uint32_t touch_lds = (uint32_t)(uintptr_t)&s_touch[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0];
     int fo[TRI ? 3 : 2][2] = {};              // the lane's pooled outputs: [block][t & 1], t = 2h + (t & 1)
+    constexpr int GEN_BLOCKS = 9;             // GEN keeps them in LDS: up to 4 + 4 + 1 items per image pair
+    __shared__ int s_fo[GEN ? 4 : 1][GEN ? GEN_BLOCKS : 1][2][64];
+    int(*const fo_lds)[2][64] = s_fo[GEN ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0];
+    int pend_sa = 0, pend_sb = 0;             // GEN: ReLUNorm shifts of the pending pair's two images
     // The act bytes of an image are stored at the START of the next item, not at the end of their own: vmcnt counts stores,
     // and the wait hipcc places on the loop's back edge would otherwise park the wave for the write acknowledgement of a
     // store it has just issued (measured: as long as the whole arithmetic of an image).  Deferred, whatever that wait
@@ -443,6 +460,28 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
     auto flush_pending = [&]() {
         if (!pend) return;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)pend_row, 0, (int)((MODE ? acts_stride : 0u) + 4u * C), 0x00020000);
+        if constexpr (GEN) {
+            // the pooled outputs still sit in LDS (the next unit writes its own only at the end of its first item)
+            const int l = lane_now();
+            const bool second = (l & 16) != 0;
+            auto norm2 = [](int a, int b2, int sh) -> short {
+                const int rnd = (1 << sh) >> 1;
+                return (short)((uint32_t)min((a + rnd) >> sh, 127) | ((uint32_t)min((b2 + rnd) >> sh, 127) << 8));
+            };
+            for (uint32_t bq = 0; bq < nbf; bq++) {
+                const uint32_t ch = 32u * bq + (uint32_t)(l & 31);
+                const int o = ch < C ? (int)(4u * ch) + 2 * (l >> 5) : 0x1FFFFF00;
+                __builtin_amdgcn_raw_buffer_store_b16(norm2(fo_lds[bq][0][l], fo_lds[bq][1][l], pend_sa), rs, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(norm2(fo_lds[nbf + bq][0][l], fo_lds[nbf + bq][1][l], pend_sb), rs, o, (int)acts_stride, 0);
+            }
+            if (gen_pair) {
+                const uint32_t ch = gen_pair0 + (uint32_t)(l & 15);
+                const int o = ch < C ? (second ? (int)acts_stride : 0) + (int)(4u * ch) + 2 * (l >> 5) : 0x1FFFFF00;
+                __builtin_amdgcn_raw_buffer_store_b16(norm2(fo_lds[2u * nbf][0][l], fo_lds[2u * nbf][1][l], second ? pend_sb : pend_sa), rs, o, 0, 0);
+            }
+            pend = false;
+            return;
+        }
         if constexpr (TRI) {
             // blocks 0 / 1: channel l & 31 of the first / second image; block 2: channel 32 + (l & 15) of the image of the column group
             const int l = lane_now();
@@ -471,8 +510,11 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
     for (;;) {
         const uint32_t img = cur_batch + unit;
         if (img >= n32) break;                // batches are handed out in increasing order: nothing is left for this wave
-        const int8_t *__restrict__ ip = images + (uint64_t)img * IMG_BYTES + (TRI && blk == 1u ? 256u : 0u);       // wave-uniform
-        if constexpr (TRI) pair_off = blk == 2u ? ((uint32_t)lane_now() & 32u) << 3 : 0u;
+        // (TRI / GEN: which image of the pair this item reads, and whether it is the item in the pair layout)
+        const bool pair_item = TRI ? blk == 2u : GEN ? blk == 2u * nbf : false;
+        const bool second_img = TRI ? blk == 1u : GEN ? (blk >= nbf && !pair_item) : false;
+        const int8_t *__restrict__ ip = images + (uint64_t)img * IMG_BYTES + (second_img ? 256u : 0u);       // wave-uniform
+        if constexpr (TRI || GEN) pair_off = pair_item ? ((uint32_t)lane_now() & 32u) << 3 : 0u;
         // the batch after this one is requested at the start of this one; the answer is needed `grab` images later
         if (unit == 0 && blk == 0 && counter != nullptr && lane_now() == 0)
             nxt_v = (int)__hip_atomic_fetch_add(counter, grab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -494,7 +536,7 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
                                  : "=&s"(keep) : "v"(lane4), "s"(touch_lds), "s"(np) : "memory");
             }
         }
-        const Head cur = fetch(ip, TRI ? (blk == 2u ? 1u : 0u) : blk);
+        const Head cur = fetch(ip, TRI ? (blk == 2u ? 1u : 0u) : GEN ? (pair_item ? nbf : second_img ? blk - nbf : blk) : blk);
 #ifdef BNM_DIAG_TIMING
         {
             const uint64_t t0 = CNN_STAMP();
@@ -602,9 +644,13 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
         for (int x = 0; x < 2; x++) {
             int m = max(max(oa3[2 * x], oa3[2 * x + 1]), ob3[2 * x]);
             const int v = max(max(m, ob3[2 * x + 1]), 0) >> n_shift;
-            fo[0][x] = blk == 0 ? v : fo[0][x];
-            fo[1][x] = blk == 1 ? v : fo[1][x];
-            if constexpr (TRI) fo[2][x] = blk == 2 ? v : fo[2][x];
+            if constexpr (GEN) {
+                fo_lds[blk][x][lane_now()] = v;
+            } else {
+                fo[0][x] = blk == 0 ? v : fo[0][x];
+                fo[1][x] = blk == 1 ? v : fo[1][x];
+                if constexpr (TRI) fo[2][x] = blk == 2 ? v : fo[2][x];
+            }
         }
         if (blk + 1 == nblk) {
             // ---- outputs: lane (j, h), block b: channel c0 + 32 b + j, values t = 2h, 2h + 1 ---------------------------------
@@ -612,7 +658,20 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(feat + (uint64_t)img * ((MODE ? 2ull : 1ull) * feat_stride)), 0,
                                                                                    (int)((MODE ? 4u * feat_stride : 0u) + 16u * C), 0x00020000);
                 typedef int i32x2 __attribute__((ext_vector_type(2)));
-                if constexpr (TRI) {
+                if constexpr (GEN) {
+                    const int l = lane_now();
+                    for (uint32_t bq = 0; bq < nbf; bq++) {
+                        const uint32_t ch = 32u * bq + (uint32_t)(l & 31);
+                        const int o = ch < C ? (int)(16u * ch) + 8 * (l >> 5) : 0x7FFFFC00;
+                        __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo_lds[bq][0][l], fo_lds[bq][1][l]}, rs, o, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo_lds[nbf + bq][0][l], fo_lds[nbf + bq][1][l]}, rs, o, (int)(4u * feat_stride), 0);
+                    }
+                    if (gen_pair) {
+                        const uint32_t ch = gen_pair0 + (uint32_t)(l & 15);
+                        const int o = ch < C ? ((l >> 4) & 1) * 4 * (int)feat_stride + (int)(16u * ch) + 8 * (l >> 5) : 0x7FFFFC00;
+                        __builtin_amdgcn_raw_buffer_store_b64(i32x2{fo_lds[2u * nbf][0][l], fo_lds[2u * nbf][1][l]}, rs, o, 0, 0);
+                    }
+                } else if constexpr (TRI) {
                     const int l = lane_now();
                     const int o01 = 16 * (l & 31) + 8 * (l >> 5);
                     const int o2 = 32u + (uint32_t)(l & 15) < C ? ((l >> 4) & 1) * 4 * (int)feat_stride + 512 + 16 * (l & 15) + 8 * (l >> 5) : 0x7FFFFC00;
@@ -634,7 +693,22 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
                     const uint32_t tt = (uint32_t)mx >> 7;
                     return tt ? 32 - __builtin_clz(tt) : 0;
                 };
-                if constexpr (TRI) {
+                if constexpr (GEN) {
+                    const int l = lane_now();
+                    const bool second = (l & 16) != 0;
+                    int va = 0, vb = 0;
+                    for (uint32_t bq = 0; bq < nbf; bq++) {
+                        va = max(va, max(fo_lds[bq][0][l], fo_lds[bq][1][l]));
+                        vb = max(vb, max(fo_lds[nbf + bq][0][l], fo_lds[nbf + bq][1][l]));
+                    }
+                    if (gen_pair) {
+                        const int m2 = max(fo_lds[2u * nbf][0][l], fo_lds[2u * nbf][1][l]);
+                        va = max(va, second ? 0 : m2);
+                        vb = max(vb, second ? m2 : 0);
+                    }
+                    pend_sa = shift_of(wave_max_nonneg(va));
+                    pend_sb = shift_of(wave_max_nonneg(vb));
+                } else if constexpr (TRI) {
                     // first image: block 0 + column group 0 of block 2; second image: block 1 + column group 1 of block 2
                     const bool second = (lane_now() & 16) != 0;
                     const int m2 = max(fo[2][0], fo[2][1]);
@@ -731,8 +805,8 @@ void bnm_cnn_weight_table(const int8_t *w1, const int8_t *w2, const int8_t *w3, 
 // C > 64 (several channel groups: ReLUNorm then runs as its own kernel over the complete vector).
 // wtab != nullptr: conv1 on the matrix cores (cnn_front_mfma_kernel, default); nullptr: the all-VALU kernel of round 1.
 hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, const int8_t *w2, const int8_t *w3, const int *wtab,
-                          uint32_t C, uint32_t n_shift, int8_t *acts, uint32_t acts_stride, int32_t *feat, uint32_t *counter,
-                          uint32_t grab, hipStream_t s) {
+                          uint32_t C, uint32_t n_shift, int8_t *acts, uint32_t acts_stride, int32_t *feat, bool feat_is_output,
+                          uint32_t *counter, uint32_t grab, hipStream_t s) {
     if (!n) return hipSuccess;
     if (C == 0 || C > 256 || n_shift < 4 || n_shift > 15 || acts_stride < 4u * C || (acts_stride & 3u) || n >= (1ull << 31))
         return hipErrorInvalidValue;
@@ -796,26 +870,45 @@ hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, co
     // several channel segments: every segment writes its int32 features, ReLUNorm runs as its own kernel over the complete vector.
     // The launches of one call share the counter block: each one leaves it zeroed for the next (stream order).
     if (!feat) return hipErrorInvalidValue;
-    for (uint32_t c0 = 0; c0 < C;) {
-        const bool pair = c0 == pair0;
-        const uint32_t c_end = pair ? C : (c0 + 64u <= pair0 ? c0 + 64u : (pair0 < C ? pair0 : C));
-        if (pair) {
-            if (pairs)
-                cnn_front_mfma_kernel<false, false, 1><<<gp, b, 0, s>>>(images, pairs, wtab, C_pad, c_end, c0, n_shift, acts, acts_stride, feat, 4u * C,
-                                                                         counter, grab);
-            cnn_front_mfma_kernel<false, true><<<dim3(1), b, 0, s>>>(images + 2 * pairs * 256ull, rest, wtab, C_pad, c_end, c0, n_shift,
-                                                                   acts + 2 * pairs * (uint64_t)acts_stride, acts_stride,
-                                                                   feat + 2 * pairs * 4ull * C, 4u * C, nullptr, 1);
-        } else {
-            if (n_main)
-                cnn_front_mfma_kernel<false, false><<<g, b, 0, s>>>(images, n_main, wtab, C_pad, c_end, c0, n_shift, acts, acts_stride, feat, 4u * C, counter, grab);
-            cnn_front_mfma_kernel<false, true><<<dim3(1), b, 0, s>>>(images + tail_off, 1, wtab, C_pad, c_end, c0, n_shift,
-                                                                   acts + n_main * (uint64_t)acts_stride, acts_stride, feat + n_main * 4ull * C,
-                                                                   4u * C, nullptr, 1);
+    auto segments = [&](const int8_t *im, uint64_t cnt, int8_t *ac, int32_t *ft) -> hipError_t {
+        const uint64_t prs = (cnt - 1) / 2, rst = cnt - 2 * prs, main1 = cnt - 1;
+        uint64_t pbs = (prs + 3) / 4, bl1 = (cnt + 3) / 4;
+        if (pbs > cap) pbs = cap;
+        if (bl1 > cap) bl1 = cap;
+        for (uint32_t c0 = 0; c0 < C;) {
+            const bool pair = c0 == pair0;
+            const uint32_t c_end = pair ? C : (c0 + 64u <= pair0 ? c0 + 64u : (pair0 < C ? pair0 : C));
+            if (pair) {
+                if (prs)
+                    cnn_front_mfma_kernel<false, false, 1><<<dim3((unsigned)pbs), b, 0, s>>>(im, prs, wtab, C_pad, c_end, c0, n_shift, ac, acts_stride, ft,
+                                                                                          4u * C, counter, grab);
+                cnn_front_mfma_kernel<false, true><<<dim3(1), b, 0, s>>>(im + 2 * prs * 256ull, rst, wtab, C_pad, c_end, c0, n_shift,
+                                                                       ac + 2 * prs * (uint64_t)acts_stride, acts_stride, ft + 2 * prs * 4ull * C,
+                                                                       4u * C, nullptr, 1);
+            } else {
+                if (main1)
+                    cnn_front_mfma_kernel<false, false><<<dim3((unsigned)bl1), b, 0, s>>>(im, main1, wtab, C_pad, c_end, c0, n_shift, ac, acts_stride, ft,
+                                                                                       4u * C, counter, grab);
+                cnn_front_mfma_kernel<false, true><<<dim3(1), b, 0, s>>>(im + main1 * 256ull, 1, wtab, C_pad, c_end, c0, n_shift,
+                                                                       ac + main1 * (uint64_t)acts_stride, acts_stride, ft + main1 * 4ull * C, 4u * C,
+                                                                       nullptr, 1);
+            }
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            c0 = c_end;
         }
+        return bnmk_relunorm(ft, 4u * C, ac, acts_stride, nullptr, cnt, s);
+    };
+    if (C <= 128) {
+        // one fused launch over the image pairs (pooled outputs in LDS, fused ReLUNorm); the last one or two images take the
+        // segment path with the feature scratch
+        if (pairs)
+            cnn_front_mfma_kernel<true, false, 3><<<gp, b, 0, s>>>(images, pairs, wtab, C_pad, C, 0, n_shift, acts, acts_stride,
+                                                                 feat_is_output ? feat : nullptr, 4u * C, counter, grab);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        c0 = c_end;
+        return segments(images + 2 * pairs * 256ull, rest, acts + 2 * pairs * (uint64_t)acts_stride,
+                        feat_is_output ? feat + 2 * pairs * 4ull * C : feat);      // (scratch: the rest's rows sit at its start)
     }
-    return bnmk_relunorm(feat, 4u * C, acts, acts_stride, nullptr, n, s);
+    return segments(images, n, acts, feat);
 }

@@ -760,11 +760,15 @@ def test_random_cnn_channel_counts_through_the_generic_tail(C, codecs, widths, n
     x = np.concatenate([synth.images(3, 700, DIST_U), synth.images(3, 701, DIST_M), np.full((1, 256), -128, np.int8)])
     want = om.infer(x, logits=True)
     # front end: fixed shares, round 1's kernel, the default (dynamic batches)
+    taps = {}
     for cv in (2, 0, 1):
         ctx.set_cnn_variant(cv)
         for n in (len(x), 1, 2, 3, 4, 7):
             got = ctx.infer(x[:n], logits=True)
             assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, cv, n)
+        taps[cv] = ctx.activations(x[:301])       # the int8 activations after every ReLUNorm (the front end's 4 C bytes first)
+    # the MFMA front end (pairs of images per item, fused ReLUNorm) against round 1's all-VALU kernel, an independent implementation
+    assert np.array_equal(taps[1], taps[0]) and np.array_equal(taps[2], taps[0]), C
     ctx.set_path(b.PATH_LAYERWISE_ALU)
     got = ctx.infer(x, logits=True)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
