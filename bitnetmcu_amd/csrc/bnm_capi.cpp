@@ -633,8 +633,8 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
     // chunks: 2^22 images when the fused tail consumes the act rows directly (1 GiB of act rows; every launch has a ramp and a
     // tail, so fewer, larger launches: +2 % over 2^20), 2^20 when the int32 features are needed as well (> 64 channels, taps)
     // or the layer-wise tail runs (its scratch is sized for kChunk)
-    // (65..128 channels on the MFMA front end: one fused launch, the feature buffer is two images of scratch)
-    const bool feat_all = d_acts_tap != nullptr || c->channels > 128 || (c->channels > 64 && !c->cnn_variant);
+    // (more than 64 channels on the MFMA front end: one fused launch, the feature buffer is two images of scratch)
+    const bool feat_all = d_acts_tap != nullptr || (c->channels > 64 && !c->cnn_variant);
     const bool need_feat = c->channels > 64 || feat_all;
     const uint64_t chunk = (!feat_all && path == BNM_PATH_FUSED_MFMA) ? kCnnChunk : kChunk;
     for (uint64_t off = 0; off < n; off += chunk) {

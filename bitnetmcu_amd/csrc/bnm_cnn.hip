@@ -319,9 +319,9 @@ hipError_t bnmk_diag_cnn_set_record(uint64_t *d_rec) { return hipMemcpyToSymbol(
 // MODE 2 (TRI, models with 33..48 channels, FUSE only): a unit is again a pair of images, done as THREE items - channels 0..31 of
 // the first image, channels 0..31 of the second, and channels 32..47 of both in the pair layout - instead of two items per
 // image with the second one half empty.
-// MODE 3 (GEN, 65..128 channels, FUSE only): a unit is a pair of images done as nbf items of the first image (its whole
+// MODE 3 (GEN, 65..256 channels, FUSE only): a unit is a pair of images done as nbf items of the first image (its whole
 // 32-channel blocks), nbf of the second and - when the channel count leaves <= 16 channels beyond a multiple of 32 - one item
-// in the pair layout; the pooled outputs wait in LDS (2 KiB..4.5 KiB per wave) instead of registers for the fused ReLUNorm over
+// in the pair layout; the pooled outputs wait in LDS (8.5 KiB per wave) instead of registers for the fused ReLUNorm over
 // the 4 C features of each image, so no int32 features travel through HBM and no separate ReLUNorm kernel runs.
 template <bool FUSE, bool SAFE, int MODE = 0>
 __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const int8_t *__restrict__ images, uint64_t n,
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, SAFE ? 2 : 4) void cnn_front_mfma_kernel(const
     __shared__ int s_touch[4][64];
     const uint32_t touch_lds = (uint32_t)(uintptr_t)&s_touch[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0];
     int fo[TRI ? 3 : 2][2] = {};              // the lane's pooled outputs: [block][t & 1], t = 2h + (t & 1)
-    constexpr int GEN_BLOCKS = 9;             // GEN keeps them in LDS: up to 4 + 4 + 1 items per image pair
+    constexpr int GEN_BLOCKS = 17;            // GEN keeps them in LDS: up to 8 + 8 + 1 items per image pair (34 KiB per workgroup)
     __shared__ int s_fo[GEN ? 4 : 1][GEN ? GEN_BLOCKS : 1][2][64];
     int(*const fo_lds)[2][64] = s_fo[GEN ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0];
     int pend_sa = 0, pend_sb = 0;             // GEN: ReLUNorm shifts of the pending pair's two images
@@ -899,7 +899,7 @@ hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, co
         }
         return bnmk_relunorm(ft, 4u * C, ac, acts_stride, nullptr, cnt, s);
     };
-    if (C <= 128) {
+    {
         // one fused launch over the image pairs (pooled outputs in LDS, fused ReLUNorm); the last one or two images take the
         // segment path with the feature scratch
         if (pairs)
@@ -910,5 +910,4 @@ hipError_t bnmk_cnn_front(const int8_t *images, uint64_t n, const int8_t *w1, co
         return segments(images + 2 * pairs * 256ull, rest, acts + 2 * pairs * (uint64_t)acts_stride,
                         feat_is_output ? feat + 2 * pairs * 4ull * C : feat);      // (scratch: the rest's rows sit at its start)
     }
-    return segments(images, n, acts, feat);
 }

@@ -119,10 +119,10 @@ hipError_t bnmk_maxpool22(const int32_t *d_in, uint32_t xy, int32_t *d_out, hipS
 // d_counter / grab: the MFMA kernel's waves take batches of `grab` images from word 0 of this counter block (all zero on entry,
 // left all zero); nullptr / 0: a fixed share per wave
 // Channel segments (MFMA kernel): a model's last <= 16 channels beyond a multiple of 32 (C <= 16; 33..48; 65..80; ...) run TWO
-// images per item.  Up to 128 channels the whole front end is one fused launch over image pairs (beyond 64 channels the last
-// one or two images of a call take the segment path); beyond 128 the channels are cut into segments that each write d_feat,
-// ReLUNorm running as its own kernel afterwards.  d_feat: REQUIRED for C > 64 - [n][4C] ints when feat_is_output is set or
-// C > 128 (it then holds every image's int32 features), else scratch of [2][4C] ints; optional output for C <= 64
+// images per item.  The whole front end is one fused launch over image pairs; beyond 64 channels the last one or two images of
+// a call take the segment path (channel segments that each write d_feat, ReLUNorm as its own kernel afterwards).  d_feat:
+// REQUIRED for C > 64 - [n][4C] ints when feat_is_output is set (it then holds every image's int32 features), else scratch of
+// [2][4C] ints; optional output for C <= 64.  (The all-VALU kernel, d_wtab == nullptr, needs [n][4C] for C > 64.)
 hipError_t bnmk_cnn_front(const int8_t *d_images, uint64_t n, const int8_t *d_w1, const int8_t *d_w2,
                           const int8_t *d_w3, const int *d_wtab, uint32_t C, uint32_t n_shift, int8_t *d_acts,
                           uint32_t acts_stride, int32_t *d_feat, bool feat_is_output, uint32_t *d_counter, uint32_t grab,

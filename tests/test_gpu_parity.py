@@ -892,17 +892,24 @@ def test_unknown_codec_keeps_the_bit_serial_path(gpu_ok, orc, capfd):
     ctx.close()
 
 
-def test_wide_cnn_tail_runs_layerwise_on_the_matrix_cores(gpu_ok, orc):
-    """160 channels: 640-byte act rows are longer than the fused kernels' 512 - the front end (three channel groups) feeds the
-    layer-wise MFMA tail."""
-    rng = np.random.default_rng(160)
-    model = b.Model.from_header_text(_random_cnn_text(rng, 160, (2, 4, 4), (96, 64), 10))
+@pytest.mark.parametrize("C", [160, 144, 200, 256])
+def test_wide_cnn_tail_runs_layerwise_on_the_matrix_cores(C, gpu_ok, orc):
+    """More than 128 channels: act rows longer than the fused FC kernels' 512 bytes - the front end (one fused launch over image
+    pairs: five whole blocks per image; 4 + a pair item; 6 + a pair item; 8, the maximum) feeds the layer-wise MFMA tail."""
+    rng = np.random.default_rng(C)
+    model = b.Model.from_header_text(_random_cnn_text(rng, C, (2, 4, 4), (96, 64), 10))
     ctx = b.Context(model)
     assert ctx.path == b.PATH_LAYERWISE_MFMA
     x = np.concatenate([synth.images(3, 150, DIST_U), synth.images(3, 151, DIST_M)])
     want = util.OracleModel(model, orc).infer(x, logits=True)
-    got = ctx.infer(x, logits=True)
-    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    taps = {}
+    for cv in (0, 2, 1):
+        ctx.set_cnn_variant(cv)
+        for n in (len(x), 1, 2, 3):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, cv, n)
+        taps[cv] = ctx.activations(x[:100])
+    assert np.array_equal(taps[1], taps[0]) and np.array_equal(taps[2], taps[0])
     ctx.close()
 
 
