@@ -287,7 +287,8 @@ bool bnm_validate_schedule(const bnm_model &m, std::string &err) {
                   " does not match previous width " + std::to_string(width);
             return false;
         }
-        if (li.n_output == 0 || li.n_output > 1024 || li.n_input > 1024) { err = "FC layer too wide (max 1024)"; return false; }
+        // (real inputs: a ternary layer declares its input count padded to a multiple of 10 - 1024 real inputs read 1030)
+        if (li.n_output == 0 || li.n_output > 1024 || real > 1024) { err = "FC layer too wide (max 1024)"; return false; }
         if (bnm_codec_known(li.bits_per_weight)) {
             int fb = bnm_codec_field_bits(li.bits_per_weight);
             if (fb && (li.n_input * (uint32_t)fb) % 32u != 0) {

@@ -850,14 +850,16 @@ def test_fuzz_random_models_every_available_path(seed, gpu_ok, orc):
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(28))
 def test_fuzz_random_cnn_models(seed, gpu_ok, orc):
-    """The CNN topology (BitNetMCU_MNIST_dll.c:48-91) with 4 to 96 channels, random conv weights, a random codec per FC layer and
-    random tail widths: front end (MFMA and round 1's VALU kernel) + whichever tail the model gets, ids and logits vs the oracle."""
+    """The CNN topology (BitNetMCU_MNIST_dll.c:48-91) with 4 to 96 channels (seeds from 12 on: 4 to 256, ternary FC layers among
+    the codecs), random conv weights, a random codec per FC layer and random tail widths: front end (MFMA - one, two or 1.5 .. 8.5
+    items per image - and round 1's VALU kernel) + whichever tail the model gets, ids and logits vs the oracle."""
     rng = np.random.default_rng(9100 + seed)
-    C = 4 * int(rng.integers(1, 25))
-    codecs = tuple(int(c) for c in rng.choice([1, 2, 4, 12, 16], size=3))
-    need = {1: 32, 2: 16, 4: 8, 12: 8, 16: 4}
+    wide = seed >= 12
+    C = 4 * int(rng.integers(1, 65 if wide else 25))
+    codecs = tuple(int(c) for c in rng.choice([1, 2, 4, 12, 16, 64] if wide else [1, 2, 4, 12, 16], size=3))
+    need = {1: 32, 2: 16, 4: 8, 12: 8, 16: 4, 64: 4}
     if (4 * C) % need[codecs[0]]:
         codecs = (16,) + codecs[1:]          # 4 C act bytes are a multiple of 16: any codec but binary / 2-bit fits every C
     widths = tuple(int(rng.integers(1, 128 // need[codecs[k]] + 1)) * need[codecs[k]] for k in (1, 2))
@@ -870,7 +872,7 @@ def test_fuzz_random_cnn_models(seed, gpu_ok, orc):
     ctx = b.Context(model)
     for variant in (1, 0):
         ctx.set_cnn_variant(variant)
-        for n in (len(x), 5):
+        for n in (len(x), 5, 6):
             got = ctx.infer(x[:n], logits=True)
             assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, codecs, widths, n_classes, variant, n)
     ctx.close()
@@ -892,12 +894,13 @@ def test_unknown_codec_keeps_the_bit_serial_path(gpu_ok, orc, capfd):
     ctx.close()
 
 
-@pytest.mark.parametrize("C", [160, 144, 200, 256])
-def test_wide_cnn_tail_runs_layerwise_on_the_matrix_cores(C, gpu_ok, orc):
+@pytest.mark.parametrize("C,codecs", [(160, (2, 4, 4)), (144, (2, 4, 4)), (200, (2, 4, 4)), (256, (2, 4, 4)),
+                                      (256, (64, 4, 4))])     # 1,024 real inputs, declared 1,030 (ternary padding)
+def test_wide_cnn_tail_runs_layerwise_on_the_matrix_cores(C, codecs, gpu_ok, orc):
     """More than 128 channels: act rows longer than the fused FC kernels' 512 bytes - the front end (one fused launch over image
     pairs: five whole blocks per image; 4 + a pair item; 6 + a pair item; 8, the maximum) feeds the layer-wise MFMA tail."""
     rng = np.random.default_rng(C)
-    model = b.Model.from_header_text(_random_cnn_text(rng, C, (2, 4, 4), (96, 64), 10))
+    model = b.Model.from_header_text(_random_cnn_text(rng, C, codecs, (96, 64), 10))
     ctx = b.Context(model)
     assert ctx.path == b.PATH_LAYERWISE_MFMA
     x = np.concatenate([synth.images(3, 150, DIST_U), synth.images(3, 151, DIST_M)])
