@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256) void relunorm_kernel(const int32_t *in, uint32
         for (int t = 0; t < LW_MAXIN / 64; t++) {
             uint32_t i = (uint32_t)lane + 64u * t;
             if (i < n) {
-                int q = x[t] < 0 ? 0 : min((x[t] + rnd) >> sh, 127);
+                // (x + rounding wraps in 32 bits exactly as the compiled C does for inputs within 2^23 of INT32_MAX - no layer sum
+                // gets there; written on unsigned operands so that hipcc may not assume the sum stays non-negative)
+                int q = x[t] < 0 ? 0 : min((int)((uint32_t)x[t] + (uint32_t)rnd) >> sh, 127);
                 dst[i] = (int8_t)q;
             }
         }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void relunorm_big_kernel(const int32_t *__rest
         int8_t *dst = out + v * out_stride;
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
             const int x = src[i];
-            dst[i] = (int8_t)(x < 0 ? 0 : min((x + rnd) >> sh, 127));
+            dst[i] = (int8_t)(x < 0 ? 0 : min((int)((uint32_t)x + (uint32_t)rnd) >> sh, 127));
         }
         if (argmax && threadIdx.x == 0) argmax[v] = bi;
     }

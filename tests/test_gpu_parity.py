@@ -3,6 +3,7 @@ with (i) the committed golden vectors produced by the compiled reference and (ii
 synthetic inputs.  Integer work: the bar is bit-exact, class ids AND all logits AND all int8 activations."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -876,6 +877,17 @@ def test_fuzz_random_cnn_models(seed, gpu_ok, orc):
             got = ctx.infer(x[:n], logits=True)
             assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, codecs, widths, n_classes, variant, n)
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzz_kernel_symbols(seed, gpu_ok, orc):
+    """The reference's four kernel symbols as the library exports them against the oracle's on random arguments far beyond the
+    model shapes (profiles/fuzz_symbols.py): every codec id incl. unknown ones, rows of up to 3,000 inputs, ReLUNorm over 1..6,000
+    values of every magnitude up to INT32_MAX (where the C engine's rounding add wraps), planes up to 96 x 96, in place and not."""
+    sys.path.insert(0, os.path.join(util.REPO, "profiles"))
+    import fuzz_symbols
+    counts, bad = fuzz_symbols.fuzz(seed, 150)
+    assert not bad and counts["fc"] == 150, bad[:5]
 
 
 def test_unknown_codec_keeps_the_bit_serial_path(gpu_ok, orc, capfd):
