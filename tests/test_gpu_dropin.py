@@ -56,3 +56,90 @@ def test_c_host_calling_the_kernel_symbols_one_by_one(name, gpu_ok, orc, tmp_pat
     assert out.returncode == 0, out.stderr
     want = util.OracleModel(model, orc).infer(images)
     assert out.stdout.splitlines() == [f"label: {int(l)} predicted: {int(c)}" for l, c in zip(labels, want)]
+
+
+_COLD_START_SCRIPT = r"""
+import sys, threading
+import numpy as np
+from ctypes import c_int8
+sys.path.insert(0, sys.argv[1])
+from bitnetmcu_amd import harness
+lib = harness.load_inference_dll(sys.argv[2])            # nothing called yet: the GPU context does not exist
+x = np.load(sys.argv[3])
+out = np.full(len(x), 0xFFFFFFFF, np.uint32)
+T = 8
+def work(t):
+    for i in range(t, len(x), T):
+        out[i] = lib.Inference((c_int8 * 256)(*x[i].tolist()))
+threads = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+for th in threads: th.start()                            # eight cold first calls race for the lazy initialisation
+for th in threads: th.join()
+np.save(sys.argv[4], out)
+"""
+
+
+@pytest.mark.parametrize("name", ["fc_4bitsym_64", "cnn_64"])
+def test_dll_cold_start_from_eight_threads(name, gpu_ok, orc, tmp_path):
+    """SURVEY 8(b) threading: the reference DLL is stateless and re-entrant; ours creates its GPU context on the first call.  Eight
+    host threads make their FIRST Inference() call at the same time in a fresh process (ctypes releases the GIL) and go on
+    calling concurrently: every class id equals the oracle's."""
+    import subprocess
+    import sys
+    dll = os.path.join(REPO, "bitnetmcu_amd", "dlls", name, "Bitnet_inf.dll")
+    if not os.path.isfile(dll):
+        pytest.skip(f"{dll} not built")
+    model = util.load_golden_model(name)
+    x = np.concatenate([synth.images(77, 1200, DIST_U), synth.images(77, 1200, DIST_M)])
+    np.save(tmp_path / "x.npy", x)
+    script = tmp_path / "cold.py"
+    script.write_text(_COLD_START_SCRIPT)
+    subprocess.check_call([sys.executable, str(script), REPO, dll, str(tmp_path / "x.npy"), str(tmp_path / "out.npy")], timeout=300)
+    assert np.array_equal(np.load(tmp_path / "out.npy"), util.OracleModel(model, orc).infer(x))
+
+
+def test_one_context_and_the_kernel_symbols_from_many_host_threads(gpu_ok, orc, bnm):
+    """Six host threads share ONE context (batched host-pointer calls of different sizes, the <= 64-image latency path among
+    them) while six more call the reference's kernel symbols: every result equals the oracle's."""
+    import threading
+    model = util.load_golden_model("fc_4bitsym_64")
+    om = util.OracleModel(model, orc)
+    import bitnetmcu_amd as b
+    ctx = b.Context(model)
+    sizes = [1, 17, 64, 65, 5000, 300_000]
+    xs = [synth.images(1000 * k, n, DIST_U) for k, n in enumerate(sizes)]
+    want = [om.infer(x[:20000], logits=True) for x in xs]
+    f_ours, f_ref = util.Funcs(bnm), util.Funcs(orc, "orc_")
+    rng = np.random.default_rng(5)
+    sym_in = [(rng.integers(-128, 128, size=256).astype(np.int8), rng.integers(0, 2**32, size=64 * 32, dtype=np.uint32)) for _ in range(6)]
+    errors = []
+
+    def batch(k):
+        try:
+            for rep in range(6):
+                cls, lg = ctx.infer(xs[k], logits=True)
+                m = min(len(cls), 20000)
+                if not (np.array_equal(cls[:m], want[k][0][:m]) and np.array_equal(lg[:m], want[k][1][:m])):
+                    errors.append(("batch", k, rep))
+        except Exception as e:       # noqa: BLE001
+            errors.append(("batch", k, repr(e)))
+
+    def symbols(k):
+        try:
+            act, w = sym_in[k]
+            ref_sum = f_ref.processfclayer(act, w, 4, 256, 64)
+            ref_out = f_ref.relunorm(ref_sum)
+            for rep in range(150):
+                s = f_ours.processfclayer(act, w, 4, 256, 64)
+                o = f_ours.relunorm(s)
+                if not (np.array_equal(s, ref_sum) and np.array_equal(o[0], ref_out[0]) and o[1] == ref_out[1]):
+                    errors.append(("symbols", k, rep))
+        except Exception as e:       # noqa: BLE001
+            errors.append(("symbols", k, repr(e)))
+
+    threads = [threading.Thread(target=batch, args=(k,)) for k in range(6)] + [threading.Thread(target=symbols, args=(k,)) for k in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    ctx.close()
+    assert not errors, errors[:5]
