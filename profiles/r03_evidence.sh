@@ -20,5 +20,8 @@ timeout 400 bash profiles/pmc_kernel.sh ${TAG}_tern_generic --model tern_96 --im
 timeout 400 bash profiles/pmc_kernel.sh ${TAG}_binary160 --model doc12k_binary --images 20000000 > "$OUT/pmc_doc12k_binary.md" 2>&1
 timeout 400 bash profiles/pmc_kernel.sh ${TAG}_cnn --model cnn_64 --images 1048576 > "$OUT/pmc_cnn.md" 2>&1
 timeout 400 bash profiles/pmc_kernel.sh ${TAG}_tern_alu --model tern_96 --path 3 --images 20000000 > "$OUT/pmc_tern_alu.md" 2>&1
-for t in dual fc_generic tern_generic binary160 cnn tern_alu; do cp "gpurun_out/pmc_${TAG}_$t/table.json" "$OUT/table_$t.json" 2>/dev/null; done
+timeout 400 bash profiles/pmc_kernel.sh ${TAG}_cnn16 --model mcu_cnn_16 --images 1048576 > "$OUT/pmc_cnn16.md" 2>&1
+timeout 400 bash profiles/pmc_kernel.sh ${TAG}_cnn48 --model mcu_cnn_48 --images 1048576 > "$OUT/pmc_cnn48.md" 2>&1
+timeout 400 bash profiles/pmc_kernel.sh ${TAG}_tern128_alu --model doc12k_ternary --path 3 --images 20000000 > "$OUT/pmc_tern128_alu.md" 2>&1
+for t in dual fc_generic tern_generic binary160 cnn tern_alu cnn16 cnn48 tern128_alu; do cp "gpurun_out/pmc_${TAG}_$t/table.json" "$OUT/table_$t.json" 2>/dev/null; done
 tail -c 400 "$OUT/bench.json"; cat "$OUT/rocprof_kernel_trace_headline.md"
