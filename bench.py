@@ -412,7 +412,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     ck = None if a.no_verify else checker()
     rd_rate = stream_read["GB/s"]
 
-    def valu(rate, kernel, bpi, model):
+    def valu(rate, kernel, bpi, model, model_key=None):
         """VALU-bound kernels.  frac = ALGORITHMIC fraction of the VALU issue roofline: the model's multiply-accumulates at 4 per
         lane of a v_dot4 (the densest integer VALU form), i.e. MACs / 256 wave instructions per image - it falls when the kernel
         spends instructions on anything else.  pipe_utilisation = the kernel's own instruction count x rate / peak (how busy the
@@ -424,7 +424,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
              "frac": rate * alg / VALU_PEAK_WAVE_INSTR_PER_S,
              "definition": "frac = MACs per image / (4 MACs x 64 lanes per wave64 v_dot4) x inferences/s / (1024 SIMDs x 2.4 GHz / 4 cycles)",
              "hbm_frac": rate * bpi / 1e9 / HBM_PEAK_GBS}
-        c = cj.get(kernel)
+        c = cj.get(f"{kernel}@{model_key}") if model_key else cj.get(kernel)
         if c and "valu_per_image" in c:
             r.update({"valu_per_image": c["valu_per_image"],
                       "pipe_utilisation": rate * c["valu_per_image"] / VALU_PEAK_WAVE_INSTR_PER_S,
@@ -472,7 +472,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     # the reference's smaller published CNNs (mcu/BitNetMCU_model_cnn_16.h, _48.h): their last <= 16 channels run two images per item
     for nm in ("mcu_cnn_16", "mcu_cnn_48"):
         r, m = run(nm, nm, n_cnn, 3, 1, note="reference's published CNN family; two images per work item for the last <= 16 channels")
-        res[nm]["roofline"] = valu(r, None, BYTES_PER_INFERENCE, m)
+        res[nm]["roofline"] = valu(r, "cnn_front_mfma_kernel", BYTES_PER_INFERENCE, m, nm)
     # headline model through the generic kernel (what any non-zoo 64-wide export would get)
     r, _ = run("fc_generic_kernel", "fc_4bitsym_64", n, 10, 3, variant=4)
     hbm_entry("fc_generic_kernel", r, BYTES_PER_INFERENCE)
@@ -484,7 +484,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     # ... and its ternary member (128-128-112) on the no-MFMA kernel: streamed weights, one image per lane
     r, m = run("doc12k_ternary_alu", "doc12k_ternary", n, 3, 1, path=b.PATH_TERNARY_ALU,
                note="the documented 12 KB ternary shape on the no-MFMA kernel, selected explicitly")
-    res["doc12k_ternary_alu"]["roofline"] = valu(r, None, BYTES_PER_INFERENCE, m)
+    res["doc12k_ternary_alu"]["roofline"] = valu(r, "ternary_stream_kernel", BYTES_PER_INFERENCE, m, "doc12k_ternary")
     # headline model, class ids + logits (300 B per inference)
     if n <= 100_000_000:
         r, _ = run("fc_logits", "fc_4bitsym_64", n, 10, 3, want_logits=True)

@@ -2,7 +2,7 @@
 """Turn the per-kernel JSON tables of profiles/pmc_table.py (--json) into the two small files bench.py replays:
   profiles/pmc_traffic.json   HBM bytes per launch of the headline kernel (FETCH_SIZE x1024 x2 + WRITE_SIZE x1024)
   profiles/pmc_counters.json  per kernel: VALU instructions per image, MFMA busy fraction, wait shares
-usage: python profiles/make_counters_json.py <tag> name=table.json:images_per_launch [...]
+usage: python profiles/make_counters_json.py <tag> name[@model]=table.json:images_per_launch [...]
   e.g. make_counters_json.py r02k fused_fc_dual_kernel=gpurun_out/pmc_dual/table.json:100000000 ..."""
 import json
 import os
@@ -19,6 +19,9 @@ def main():
         out = json.load(open(pc))
     for spec in sys.argv[2:]:
         name, rest = spec.split("=")
+        alias = name
+        if "@" in name:                      # kernel@model: stored under that key (bench.py looks "kernel@model" up first)
+            name = name.split("@")[0]
         path, images = rest.rsplit(":", 1)
         images = float(images)
         tab = json.load(open(path))
@@ -55,7 +58,7 @@ def main():
                            "images_per_launch": images,
                            "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section: gfx950 reports half the bytes of 16 B/lane reads)"},
                           open(os.path.join(REPO, "profiles", "pmc_traffic.json"), "w"))
-        out[name] = e
+        out[alias] = e
     json.dump(out, open(pc, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
