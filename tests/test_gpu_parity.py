@@ -784,10 +784,11 @@ def test_random_cnn_channel_counts_through_the_generic_tail(C, codecs, widths, n
     ((64, 64, 64, 64), (384, 120, 96), 10),     # ternary, exporter padding (260 / 390 / 120 / 100 declared inputs)
     ((4, 4, 4), (272, 40), 47),                 # three layers
 ])
-def test_models_outside_the_fused_kernels_run_layerwise_on_the_matrix_cores(codecs, widths, n_classes, gpu_ok, orc, capfd):
+def test_models_outside_the_fused_kernels_run_layerwise_on_the_matrix_cores(codecs, widths, n_classes, gpu_ok, orc, capfd, monkeypatch):
     """Shapes beyond the fused kernels (a layer wider than 256 outputs) used to fall to the bit-serial layer-wise kernels, a
     500x cliff.  They now run one int8 GEMM kernel per layer on the matrix cores (any widths) - loudly (a warning names the
     reason), bit-exact in class ids and logits against the oracle, and equal to the bit-serial path."""
+    monkeypatch.delenv("BNM_QUIET", raising=False)          # the warning is part of what is tested
     rng = np.random.default_rng(hash((codecs, widths, n_classes)) % 2**32)
     model = b.Model.from_header_text(_random_model_text(rng, codecs, widths, n_classes))
     ctx = b.Context(model)
@@ -890,9 +891,10 @@ def test_fuzz_kernel_symbols(seed, gpu_ok, orc):
     assert not bad and counts["fc"] == 150, bad[:5]
 
 
-def test_unknown_codec_keeps_the_bit_serial_path(gpu_ok, orc, capfd):
+def test_unknown_codec_keeps_the_bit_serial_path(gpu_ok, orc, capfd, monkeypatch):
     """A codec the C engine does not decode (NF4's id 36: every sum is 0, BitNetMCU_inference.c:202) has no int8 rows: such a model
     stays on the bit-serial layer-wise kernels, which restate the C branches one by one."""
+    monkeypatch.delenv("BNM_QUIET", raising=False)
     rng = np.random.default_rng(36)
     model = b.Model.from_header_text(_random_model_text(rng, (4, 36, 4, 4), (64, 64, 64)))
     ctx = b.Context(model)
