@@ -751,6 +751,12 @@ def test_random_shapes_through_the_generic_fused_kernel(codecs, widths, n_classe
     (96, (64, 4, 4), (96, 64), 10),
     (128, (64, 4, 4), (96, 64), 10),
     (64, (64, 4, 4), (96, 64), 10),     # ... and the same tail behind the fused 64-channel front end
+    # odd channel counts (8-bit first FC layer: 4 C inputs need no padding): partly filled pair segments and blocks
+    (5, (16, 4, 4), (32, 32), 10),
+    (21, (16, 4, 4), (32, 32), 10),
+    (37, (16, 4, 4), (64, 32), 10),
+    (69, (16, 4, 4), (64, 32), 10),
+    (127, (16, 4, 4), (64, 32), 10),
 ])
 def test_random_cnn_channel_counts_through_the_generic_tail(C, codecs, widths, n_classes, gpu_ok, orc):
     rng = np.random.default_rng(C * 1000 + n_classes)
