@@ -28,7 +28,7 @@ def main():
         sys.exit("set BNM_LIBRARY to the --diag-timing build (see the docstring)")
     n = int(os.environ.get("N", 1 << 20))
     lib = b.load()
-    model = util.load_golden_model("cnn_64")
+    model = util.load_golden_model(os.environ.get("MODEL", "cnn_64"))
     ctx = b.Context(model)
     imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
     synth.fill_device(imgs, first=0, dist=b.DIST_U)
