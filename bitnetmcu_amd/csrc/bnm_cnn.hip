@@ -310,7 +310,9 @@ __device__ uint64_t *g_cnn_rec = nullptr;
 hipError_t bnmk_diag_cnn_set_record(uint64_t *d_rec) { return hipMemcpyToSymbol(HIP_SYMBOL(g_cnn_rec), &d_rec, sizeof(d_rec)); }
 #define CNN_STAMP() __builtin_readcyclecounter()
 #endif
-// PAIR (models with <= 16 channels): an item is TWO consecutive images, `n` counts pairs.  Lane columns 0..15 are the channels
+// MODE 0: an item is one image x 32 channels (one or two items per image), `n` counts images.
+// MODE 1 (PAIR, models with <= 16 channels, or the last <= 16 channels of a segmented model): an item is TWO consecutive images,
+// `n` counts pairs.  Lane columns 0..15 are the channels
 // of the pair's first image, columns 16..31 the same channels of its second image: the A operand's K-slots 0..15 (lane half
 // 0) carry the first image's patch, K-slots 16..31 (lane half 1) the second image's, and the weight table holds a channel's
 // conv1 weights in K-slots 0..15 for columns 0..15 and in K-slots 16..31 for columns 16..31 (zero elsewhere): the MFMA
