@@ -284,7 +284,8 @@ def test_many_launches_on_three_streams(name, path, variant, n, gpu_ok):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,path,variant,n", [("fc_4bitsym_64", 0, 6, 300_007), ("fc_4bitsym_64", 0, 4, 100_003), ("cnn_64", 0, -1, 30_011)])
+@pytest.mark.parametrize("name,path,variant,n", [("fc_4bitsym_64", 0, 6, 300_007), ("fc_4bitsym_64", 0, 4, 100_003), ("cnn_64", 0, -1, 30_011),
+                                                 ("mcu_cnn_16", 0, -1, 30_011), ("mcu_cnn_48", 0, -1, 30_012)])   # two images per front-end item
 def test_graph_replays_next_to_eager_launches(name, path, variant, n, gpu_ok):
     """A captured launch keeps a counter block of its own: the graph replayed on one stream while eager launches of the same
     context run on the CAPTURING stream and on a third one - 30 rounds, every result equal to the single-stream result.
@@ -329,7 +330,7 @@ def test_graph_replays_next_to_eager_launches(name, path, variant, n, gpu_ok):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["fc_4bitsym_64", "tern_96", "cnn_64"])
+@pytest.mark.parametrize("name", ["fc_4bitsym_64", "tern_96", "cnn_64", "mcu_cnn_16small", "mcu_cnn_48"])
 def test_infer_device_under_graph_capture(name, gpu_ok, orc):
     """bnm_infer_device enqueues only stream work (kernels; scratch is allocated per stream on first use), so a
     launch-bound small-batch loop can be captured into a HIP graph once and replayed: warm up on the capture stream, capture,
