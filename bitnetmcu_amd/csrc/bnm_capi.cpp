@@ -260,6 +260,26 @@ int resolve_path(bnm_ctx *c) {
     return BNM_OK;
 }
 
+// The entry points work on the context's device and leave the calling thread's current device as they found it (a host that
+// drives several GPUs from one thread - or PyTorch with another current device - must not find it changed behind its back).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != dev) {
+            err = hipSetDevice(dev);
+            changed = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 int dev_alloc(bnm_ctx *c, void **p, size_t bytes) {
     HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
     c->owned.push_back(*p);
@@ -738,7 +758,8 @@ int bnm_ctx_create(const bnm_model *m, int device, bnm_ctx **out) {
     if (ndev <= 0) return fail(BNM_EHIP, "no HIP device visible");
     if (device < 0) HIP_TRY(hipGetDevice(&device));
     if (device >= ndev) return fail(BNM_EINVAL, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard dg(device);
+    HIP_TRY(dg.err);
     bnm_ctx *c = new bnm_ctx();
     c->device = device;
     c->model = *m;
@@ -755,7 +776,7 @@ int bnm_ctx_create(const bnm_model *m, int device, bnm_ctx **out) {
 
 void bnm_ctx_destroy(bnm_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     for (void *p : c->owned) (void)hipFree(p);
     for (auto &kv : c->scratch)
         for (DevBuf *b : {&kv.second.act_a, &kv.second.act_b, &kv.second.out32, &kv.second.cnn_feat}) b->release();
@@ -844,14 +865,16 @@ int bnm_ctx_set_host_tuning(bnm_ctx *c, int mode, int copy_threads, int spin) {
 int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls, int32_t *d_logits, void *stream) {
     if (!c) return fail(BNM_EINVAL, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard dg(c->device);
+    HIP_TRY(dg.err);
     return infer_device_locked(c, d_images, n, d_cls, d_logits, nullptr, 0, (hipStream_t)stream);
 }
 
 int bnm_ctx_release_stream(bnm_ctx *c, void *stream) {
     if (!c) return fail(BNM_EINVAL, "null ctx");
     std::lock_guard<std::mutex> g(c->mu);
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard dg(c->device);
+    HIP_TRY(dg.err);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipStreamSynchronize(s));
     auto it = c->scratch.find(s);
@@ -981,7 +1004,8 @@ static int infer_host_impl(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
     if (!c) return fail(BNM_EINVAL, "null ctx");
     if (n && (!images || (!cls && !acts))) return fail(BNM_EINVAL, "null host pointer");
     std::lock_guard<std::mutex> g(c->mu);
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard dg(c->device);
+    HIP_TRY(dg.err);
     if (!n) return BNM_OK;
     if (!acts) {
         if (n <= kLatencyMax) return infer_host_small(c, images, n, cls, logits);
@@ -1154,6 +1178,12 @@ int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, in
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail(BNM_EHIP, "no HIP device visible");
+    int caller_dev = 0;
+    if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = 0;
+    struct Restore {       // the loops below walk over the devices: the caller's current device comes back at every exit
+        int dev;
+        ~Restore() { (void)hipSetDevice(dev); }
+    } restore{caller_dev};
     const int G = (n_gpus <= 0 || n_gpus > ndev) ? ndev : n_gpus;
     struct Shard {
         bnm_ctx *ctx = nullptr;
@@ -1229,6 +1259,14 @@ std::mutex g_mu;
 bnm_ctx *g_default = nullptr;
 DevBuf g_sa, g_sw, g_so, g_sb, g_sarg;   // scratch of the per-function host ABI
 
+// The kernel symbols keep their scratch buffers on ONE device - the calling thread's current device at their first use - and run
+// there whatever the current device is later (a host that switches devices between calls must not mix buffers and launches).
+int g_sym_dev = -1;
+int sym_device() {
+    if (g_sym_dev < 0 && hipGetDevice(&g_sym_dev) != hipSuccess) g_sym_dev = 0;
+    return g_sym_dev;
+}
+
 [[noreturn]] void die(const char *what) {
     std::fprintf(stderr, "bitnetmcu_hip: %s: %s\n(there is no CPU fallback; a HIP device is required)\n", what, g_err.c_str());
     std::abort();
@@ -1294,6 +1332,7 @@ uint32_t Inference(int8_t *input) { return BitMnistInference(input); }
 void processfclayer(int8_t *activations, const uint32_t *weights, int32_t bpw, uint32_t n_input, uint32_t n_output,
                     int32_t *output) {
     std::lock_guard<std::mutex> g(g_mu);
+    DeviceGuard dg(sym_device());
     if (!n_output) return;
     uint64_t cnt = bnm_fc_weight_count(bpw, n_input, n_output);
     if (!bnm_codec_known(bpw)) {
@@ -1314,6 +1353,7 @@ void processfclayer(int8_t *activations, const uint32_t *weights, int32_t bpw, u
 
 uint32_t ReLUNorm(int32_t *input, int8_t *output, uint32_t n_input) {
     std::lock_guard<std::mutex> g(g_mu);
+    DeviceGuard dg(sym_device());
     if (!n_input) return 255;
     if (g_so.ensure((size_t)n_input * 4) || g_sb.ensure(n_input) || g_sarg.ensure(4)) die("ReLUNorm");
     uint32_t pos = 255;
@@ -1328,6 +1368,7 @@ uint32_t ReLUNorm(int32_t *input, int8_t *output, uint32_t n_input) {
 
 int32_t *processconv33ReLU(int32_t *activations, const int8_t *weights, uint32_t xy, uint32_t n_shift, int32_t *output) {
     std::lock_guard<std::mutex> g(g_mu);
+    DeviceGuard dg(sym_device());
     if (xy < 3) return output;      // no output position exists (the reference's loops do not run either)
     uint32_t o = xy - 2;
     if (g_so.ensure((size_t)xy * xy * 4) || g_sw.ensure(16) || g_sa.ensure((size_t)o * o * 4)) die("processconv33ReLU");
@@ -1341,6 +1382,7 @@ int32_t *processconv33ReLU(int32_t *activations, const int8_t *weights, uint32_t
 
 int32_t *processmaxpool22(int32_t *activations, uint32_t xy, int32_t *output) {
     std::lock_guard<std::mutex> g(g_mu);
+    DeviceGuard dg(sym_device());
     if (xy < 2) return output;      // no output position exists
     uint32_t o = xy / 2;
     if (g_so.ensure((size_t)xy * xy * 4) || g_sa.ensure((size_t)o * o * 4)) die("processmaxpool22");

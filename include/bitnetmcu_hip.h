@@ -120,7 +120,9 @@ BNM_API const void *bnm_model_layer_weights(const bnm_model *m, uint32_t i); /* 
 /* ---- context: model uploaded + unpacked on one GPU ---------------------------------------- */
 
 /* device < 0: current HIP device.  Uploads the packed weights and runs the GPU unpack kernels
- * (packed words -> int8 rows -> MFMA operand fragments). */
+ * (packed words -> int8 rows -> MFMA operand fragments).  Every entry point that takes a context works on the context's
+ * device and leaves the calling thread's current HIP device as it found it; the group (A) symbols run on the device that was
+ * current at their first use.  A context may be shared by host threads (calls are serialised by a mutex inside). */
 BNM_API int bnm_ctx_create(const bnm_model *m, int device, bnm_ctx **out);
 BNM_API void bnm_ctx_destroy(bnm_ctx *c);
 BNM_API int bnm_ctx_device(const bnm_ctx *c);
