@@ -200,6 +200,7 @@ struct bnm_ctx {
     // streams must not share feature rows / activation buffers)
     struct StreamScratch {
         DevBuf act_a, act_b, out32, cnn_feat;
+        DevBuf q8;      // bnm_infer_float_device: the quantised images of one chunk
     };
     std::map<hipStream_t, StreamScratch> scratch;
     DevBuf argmax, stage_img, stage_cls, stage_logits;
@@ -318,7 +319,7 @@ void evict_other_streams(bnm_ctx *c, hipStream_t keep) {
     if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return; }
     for (auto it = c->scratch.begin(); it != c->scratch.end();) {
         if (it->first == keep) { ++it; continue; }
-        for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat}) b->release();
+        for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat, &it->second.q8}) b->release();
         it = c->scratch.erase(it);
     }
     for (auto it = c->work_of.begin(); it != c->work_of.end();) {
@@ -779,7 +780,7 @@ void bnm_ctx_destroy(bnm_ctx *c) {
     DeviceGuard dg(c->device);
     for (void *p : c->owned) (void)hipFree(p);
     for (auto &kv : c->scratch)
-        for (DevBuf *b : {&kv.second.act_a, &kv.second.act_b, &kv.second.out32, &kv.second.cnn_feat}) b->release();
+        for (DevBuf *b : {&kv.second.act_a, &kv.second.act_b, &kv.second.out32, &kv.second.cnn_feat, &kv.second.q8}) b->release();
     for (DevBuf *b : {&c->argmax, &c->stage_img, &c->stage_cls, &c->stage_logits})
         b->release();
     for (PinBuf *b : {&c->lat_in, &c->lat_cls, &c->lat_logits}) b->release();
@@ -879,7 +880,7 @@ int bnm_ctx_release_stream(bnm_ctx *c, void *stream) {
     HIP_TRY(hipStreamSynchronize(s));
     auto it = c->scratch.find(s);
     if (it != c->scratch.end()) {
-        for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat}) b->release();
+        for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat, &it->second.q8}) b->release();
         c->scratch.erase(it);
     }
     auto wt = c->work_of.find(s);
@@ -1083,6 +1084,29 @@ int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_out, void 
     if (n && (!d_x || !d_out)) return fail(BNM_EINVAL, "null pointer");
     if (((uintptr_t)d_x & 15u) || ((uintptr_t)d_out & 3u)) return fail(BNM_EINVAL, "d_x must be 16-byte aligned");
     HIP_TRY(bnmk_quantize_input(d_x, n, d_out, (hipStream_t)stream));
+    return BNM_OK;
+}
+
+int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d_cls, int32_t *d_logits, void *stream) {
+    if (!c) return fail(BNM_EINVAL, "null ctx");
+    if (!n) return BNM_OK;
+    if (!d_x || !d_cls) return fail(BNM_EINVAL, "null device pointer");
+    if ((uintptr_t)d_x & 15u) return fail(BNM_EINVAL, "d_x must be 16-byte aligned");
+    std::lock_guard<std::mutex> g(c->mu);
+    DeviceGuard dg(c->device);
+    HIP_TRY(dg.err);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t ncls = c->model.num_classes();
+    // chunks of 2^22 images (1 GiB of int8 scratch per stream): quantise, then the model's kernels, in stream order
+    const uint64_t chunk = 1ull << 22;
+    DevBuf &q8 = stream_scratch(c, s).q8;
+    if (int e = q8.ensure((size_t)(n < chunk ? n : chunk) * 256 + 64)) return e;
+    for (uint64_t off = 0; off < n; off += chunk) {
+        const uint64_t cn = n - off < chunk ? n - off : chunk;
+        HIP_TRY(bnmk_quantize_input(d_x + off * 256, cn, (int8_t *)q8.p, s));
+        if (int e = infer_device_locked(c, (const int8_t *)q8.p, cn, d_cls + off, d_logits ? d_logits + off * ncls : nullptr, nullptr, 0, s))
+            return e;
+    }
     return BNM_OK;
 }
 

@@ -210,6 +210,19 @@ class Context:
                                                       s.cuda_stream), "bnm_infer_device")
         return cls
 
+    def infer_float_device(self, x, cls, logits=None, stream=None):
+        """float32 cuda tensor [n,256] -> class ids (torch.int32 [n]) and optionally the int32 logits: the reference's per-image
+        flow (quantise as test_inference.py:140-141, then Inference()) for a whole batch, asynchronous on the stream."""
+        import torch
+        n = x.numel() // 256
+        assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+        assert cls.is_cuda and cls.is_contiguous() and cls.element_size() == 4 and cls.numel() >= n
+        s = stream if stream is not None else torch.cuda.current_stream(x.device)
+        L.check(self._lib, self._lib.bnm_infer_float_device(self._h, x.data_ptr(), n, cls.data_ptr(),
+                                                            logits.data_ptr() if logits is not None else None, s.cuda_stream),
+                "bnm_infer_float_device")
+        return cls
+
     def quantize_device(self, x, out=None, stream=None):
         """float32 cuda tensor [n,256] -> int8 [n,256] on the GPU with the reference's input quantisation
         (test_inference.py:140-141), bit-identical to harness.quantize_input."""

@@ -210,6 +210,10 @@ BNM_API int bnm_unpack_layer_host(const void *weights, int32_t bits_per_weight, 
  * (test_inference.py:140-141; BitNetMCU.py:435-436): scale = 127/max(max|x|,1e-5), round half to even, clip.
  * d_x: float32 [n][256], d_out: int8 [n][256]; bit-identical to the numpy float32 formula. */
 BNM_API int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_out, void *stream);
+/* The two steps of the reference's per-image Python flow (test_inference.py:140-150: quantise, then Inference()) for a batch of
+ * float images resident on the GPU: d_x float32 [n][256] -> class ids (and the int32 logits if d_logits != NULL), asynchronous on
+ * `stream`; the quantised images live in per-stream scratch of the context (allocated on first use: not under stream capture). */
+BNM_API int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d_cls, int32_t *d_logits, void *stream);
 
 /* ---- QAT forward op ------------------------------------------------------
  * The forward pass of the reference's training layer BitLinear (BitNetMCU.py:198-235):

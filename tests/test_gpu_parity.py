@@ -461,8 +461,26 @@ def test_input_quantisation_matches_numpy_float32(gpu_ok):
     # and the two steps chained on device == the reference's per-image Python flow
     cls = torch.empty(len(x), dtype=torch.int32, device="cuda")
     ctx.infer_device(ctx.quantize_device(torch.from_numpy(x).cuda()), cls)
-    assert np.array_equal(cls.cpu().numpy().astype(np.uint32), util.OracleModel(ctx.model).infer(harness.quantize_input(x)))
+    want_cls, want_lg = util.OracleModel(ctx.model).infer(harness.quantize_input(x), logits=True)
+    assert np.array_equal(cls.cpu().numpy().astype(np.uint32), want_cls)
+    # ... and as ONE call (bnm_infer_float_device), on a side stream, with logits
+    side = torch.cuda.Stream()
+    xd = torch.from_numpy(x).cuda()
+    cls2 = torch.full((len(x),), -1, dtype=torch.int32, device="cuda")
+    lg2 = torch.empty((len(x), ctx.model.num_classes), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        ctx.infer_float_device(xd, cls2, lg2)
+    side.synchronize()
+    assert np.array_equal(cls2.cpu().numpy().astype(np.uint32), want_cls) and np.array_equal(lg2.cpu().numpy(), want_lg)
     ctx.close()
+    # a CNN model through the same call
+    cctx = b.Context(util.load_golden_model("mcu_cnn_16"))
+    cls3 = torch.empty(len(x), dtype=torch.int32, device="cuda")
+    cctx.infer_float_device(xd, cls3)
+    torch.cuda.synchronize()
+    assert np.array_equal(cls3.cpu().numpy().astype(np.uint32), util.OracleModel(cctx.model).infer(harness.quantize_input(x)))
+    cctx.close()
 
 
 def test_bench_json_contract(gpu_ok):
