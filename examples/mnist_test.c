@@ -27,9 +27,15 @@ typedef struct {
 #define FC(k) {L##k##_weights, L##k##_bitperweight, L##k##_incoming_weights, L##k##_outgoing_weights}
 
 #if defined(MODEL_CNNMNIST)
-/* conv (1 -> C) / depthwise conv / pool / depthwise conv / pool, then three fully connected layers */
+/* per channel: conv (1 -> C), depthwise conv + pool, depthwise conv + pool; then three fully connected layers */
+typedef struct {
+    const int8_t *kernels;   /* [channels][9] */
+    uint32_t side;           /* side of the square input plane */
+    uint32_t pool_side;      /* side of the plane the 2x2 pool behind this conv reads; 0: no pool */
+} conv_stage;
+static const conv_stage front[] = {{L2_weights, L2_incoming_x, 0}, {L4_weights, L4_incoming_x, L6_incoming_x}, {L7_weights, L7_incoming_x, L9_incoming_x}};
+enum { N_STAGES = sizeof front / sizeof front[0], CHANNELS = L7_out_channels, CONV_SHIFT = 4 };
 static const fc_layer fc_chain[] = {FC(11), FC(13), FC(15)};
-enum { CHANNELS = L7_out_channels, FEATURES_PER_CHANNEL = L9_outgoing_x * L9_outgoing_y, CONV_SHIFT = 4 };
 #elif defined(MODEL_FCMNIST)
 #ifdef L4_active
 static const fc_layer fc_chain[] = {FC(1), FC(2), FC(3), FC(4)};
@@ -50,11 +56,11 @@ static uint32_t classify(const int8_t *image) {
     for (uint32_t c = 0; c < CHANNELS; c++) {
         for (int i = 0; i < 256; i++) plane[i] = image[i];
         /* every stage works in place on the channel's plane; the last pool appends its 2x2 block to the feature row */
-        processconv33ReLU(plane, L2_weights + 9 * c, L2_incoming_x, CONV_SHIFT, plane);
-        processconv33ReLU(plane, L4_weights + 9 * c, L4_incoming_x, CONV_SHIFT, plane);
-        processmaxpool22(plane, L6_incoming_x, plane);
-        processconv33ReLU(plane, L7_weights + 9 * c, L7_incoming_x, CONV_SHIFT, plane);
-        next = processmaxpool22(plane, L9_incoming_x, next);
+        for (int k = 0; k < N_STAGES; k++) {
+            processconv33ReLU(plane, front[k].kernels + 9 * c, front[k].side, CONV_SHIFT, plane);
+            if (front[k].pool_side && k + 1 < N_STAGES) processmaxpool22(plane, front[k].pool_side, plane);
+            else if (front[k].pool_side) next = processmaxpool22(plane, front[k].pool_side, next);
+        }
     }
     ReLUNorm(features, act, (uint32_t)(next - features));
 #else
