@@ -469,7 +469,7 @@ hipError_t bnmk_ternary_stream_build(const BnmTernArgs &a, int *d_stream, hipStr
 // The ALU path is instantiated per hidden-width triple (a lane keeps a layer's packed activations in H/4 registers and the
 // neuron loop is unrolled over them): the widths the reference documents for ternary models - 96-96-96 (BASELINE configs[2]) and
 // the 12 KB family's 128-128-112 (docs/documentation.md:169-183) - plus 64-64-64 and 128-128-128.  The streamed kernel (weights
-// through scalar registers, two images per lane) exists for 96-96-96; the other shapes run the plain ALU kernel.  Ternary
+// through scalar registers) exists for every shape of the table with one image per lane, with two per lane for 96-96-96.  Ternary
 // layers declare a padded input count (a multiple of 10, exportquant.py:132-137); the kernels read the REAL inputs only.
 namespace {
 typedef void (*tern_fn)(const int8_t *, uint64_t, const int8_t *, const int8_t *, const int8_t *, const int8_t *, uint32_t, uint32_t,
