@@ -34,7 +34,7 @@ def newer(src_list, out):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-SOURCES = (("bnm_fused_fc.hip", True), ("bnm_fused_generic.hip", True), ("bnm_fused_generic_m2.hip", True),
+SOURCES = (("bnm_fused_fc.hip", True), ("bnm_fused_regw.hip", True, ("-mllvm", "-amdgpu-mfma-vgpr-form")), ("bnm_fused_generic.hip", True), ("bnm_fused_generic_m2.hip", True),
            ("bnm_fused_generic_m4.hip", True), ("bnm_fused_generic_m6_k8.hip", True), ("bnm_fused_generic_m8_k2.hip", True), ("bnm_fused_generic_m8_k4.hip", True),
            ("bnm_fused_generic_m8_k8.hip", True), ("bnm_fused_generic_m8_k16.hip", True), ("bnm_fused_generic_m2_t2.hip", True), ("bnm_cnn.hip", True, ("-mllvm", "-amdgpu-mfma-vgpr-form")), ("bnm_ternary.hip", True),
            ("bnm_layerwise.hip", True), ("bnm_support.hip", True), ("bnm_qat.hip", True), ("bnm_capi.cpp", False),

@@ -12,6 +12,7 @@
 #include <thread>
 #include <string>
 #include <vector>
+#include "bnm_device.hpp"
 #include "bnm_kernels.h"
 #include "bnm_model.hpp"
 #ifdef BNM_DIAG
@@ -516,6 +517,8 @@ int ctx_build(bnm_ctx *c) {
         } else if (!c->table_ok) {
             c->fused_reason = "the weight fragments do not fit beside the image tiles in 160 KiB of LDS";
         }
+        // the register-resident-weight kernel takes whole 64-image pairs; the generic kernel finishes its calls
+        if (c->table_ok && c->variant == BNM_FUSED_REGW && !c->generic_ok) c->table_ok = false;
         c->fused_ok = c->table_ok || c->generic_ok;
     }
     // ---- ternary ALU path ------------------------------------------------------------------------------
@@ -552,6 +555,30 @@ int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32
         const int tiles = c->variant == BNM_FUSED_GENERIC_T1 ? 1 : c->variant == BNM_FUSED_GENERIC_T2 ? 2 : 0;
         HIP_TRY(bnmk_fused_generic(c->gdesc, c->shape.dbl, tiles, c->grid_blocks, d_in, n, c->gfrags, d_cls, d_logits, block,
                                    c->work_batch, s));
+        return BNM_OK;
+    }
+    if (c->variant == BNM_FUSED_REGW) {
+        // whole 64-image pairs to the register-resident-weight kernel, the last < 64 images - or all of a call too small to give
+        // every resident wave a pair - to the generic kernel (same stream, same counter block: the launches are ordered and each
+        // leaves the block all-zero)
+        const uint64_t resident_waves = (c->grid_blocks > 0 ? (uint64_t)c->grid_blocks : (uint64_t)bnm_num_cus()) * 4ull;
+        const uint64_t n_main = (n >> 6) < resident_waves ? 0ull : n & ~63ull;
+        if (n_main) {
+            BnmFusedArgs a{};
+            a.images = d_in;
+            a.n = n_main;
+            a.frags = c->frags;
+            a.n_classes = c->model.num_classes();
+            a.cls = d_cls;
+            a.logits = d_logits;
+            a.work = block;
+            a.idle = c->idle_words;
+            a.batch = c->work_batch;
+            HIP_TRY(bnmk_fused_fc(c->shape, c->variant, c->grid_blocks, a, s));
+        }
+        if (n > n_main)
+            HIP_TRY(bnmk_fused_generic(c->gdesc, c->shape.dbl, 0, c->grid_blocks, d_in + n_main * (uint64_t)c->in_width, n - n_main, c->gfrags,
+                                       d_cls + n_main, d_logits ? d_logits + n_main * c->model.num_classes() : nullptr, block, 0, s));
         return BNM_OK;
     }
     BnmFusedArgs a{};

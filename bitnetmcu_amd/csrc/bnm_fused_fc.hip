@@ -78,7 +78,9 @@ BNM_DEVICE void layer_mma(const AFrags<MT, KT *(SPLIT ? 2 : 1)> &A, const i32x4 
 //                 favoured waves finish after ~65 % of the launch and the rest of it runs at one wave per SIMD
 //                 (profiles/r02/wait_timing_hbm_r02s_fixed_stride.json: 4.6 M .. 7.2 M cycles for the same 763 iterations).
 //   6  DUAL_DEVWIDE  the dual-tile loop (two 4-wave workgroups per CU) with batches of pairs from ONE device-wide counter
-enum { FUSED_DIRECT = 0, FUSED_LDSDMA = 1, FUSED_LDSDMA2 = 2, FUSED_DUAL = 3, FUSED_DUAL_SHARED = 5, FUSED_DUAL_DEVWIDE = 6 };
+//   9  REGW         3..5-tile shapes: weights resident in the register file (AccVGPRs) at one wave per SIMD, dual-tile loop,
+//                 two pairs in flight (bnm_fused_regw.hip)
+enum { FUSED_DIRECT = 0, FUSED_LDSDMA = 1, FUSED_LDSDMA2 = 2, FUSED_DUAL = 3, FUSED_DUAL_SHARED = 5, FUSED_DUAL_DEVWIDE = 6, FUSED_REGW = BNM_FUSED_REGW };
 
 template <int KT0, int M1, int M2, int M3, int M4, bool SPLIT, bool DBL, int VARIANT, int NC8>
 __global__ __launch_bounds__(64 * FUSED_WPB, 2) void fused_fc_kernel(const int8_t *__restrict__ images, uint64_t n,
@@ -617,7 +619,9 @@ const FusedEntry *find_fused(const BnmFusedShape &sh, int variant) {
 }
 }  // namespace
 
-bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) { return find_fused(sh, variant) != nullptr; }
+bool bnmk_fused_supported(const BnmFusedShape &sh, int variant) {
+    return variant == FUSED_REGW ? bnmk_regw_supported(sh) : find_fused(sh, variant) != nullptr;
+}
 // measured best first (profiles/r01): the dual-tile kernel wherever it is instantiated (64-wide four-layer shapes:
 // 4.40-4.55 vs 4.63-4.70 ms per 1e8 images; the 16-wide 1k model: 4.29 vs 4.33 ms), then two tiles in flight for
 // shapes whose tiles carry real work, else the plain one-ahead loop
@@ -627,6 +631,7 @@ int bnmk_fused_default_variant(const BnmFusedShape &sh) {
     // ... and batches of 2 pairs from the device-wide counter (split eight ways) 6-7.5 % ahead of the fixed stride
     // (same-process interleaved A/B, profiles/headline_ab.py: profiles/r02/headline_ab_r02x.json ... r02z4.json)
     if (find_fused(sh, FUSED_DUAL_DEVWIDE)) return FUSED_DUAL_DEVWIDE;
+    if (bnmk_regw_supported(sh)) return FUSED_REGW;
     if (find_fused(sh, FUSED_DUAL_SHARED)) return FUSED_DUAL_SHARED;
     if (find_fused(sh, FUSED_DUAL)) return FUSED_DUAL;
     if (sh.M[0] >= 2 && find_fused(sh, FUSED_LDSDMA2)) return FUSED_LDSDMA2;
@@ -634,6 +639,7 @@ int bnmk_fused_default_variant(const BnmFusedShape &sh) {
 }
 
 hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a, hipStream_t s) {
+    if (variant == FUSED_REGW) return bnmk_fused_regw(sh, grid_blocks, a, s);
     const FusedEntry *e = find_fused(sh, variant);
     if (!e) return hipErrorInvalidValue;
     if (a.n == 0) return hipSuccess;

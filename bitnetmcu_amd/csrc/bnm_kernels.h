@@ -65,6 +65,11 @@ bool bnmk_fused_supported(const BnmFusedShape &sh, int variant);
 hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, const BnmFusedArgs &a,
                          hipStream_t s);
 int bnmk_fused_default_variant(const BnmFusedShape &sh);
+// variant 9 (bnm_fused_regw.hip): weights resident in the register file at one wave per SIMD, for the 3..5-tile shapes.  Takes
+// whole 64-image pairs only (n % 64 == 0): the caller (bnm_capi.cpp, run_fused) gives the remainder to the generic kernel.
+constexpr int BNM_FUSED_REGW = 9;
+bool bnmk_regw_supported(const BnmFusedShape &sh);
+hipError_t bnmk_fused_regw(const BnmFusedShape &sh, int grid_blocks, const BnmFusedArgs &a, hipStream_t s);
 
 // ---- generic fused whole-model FC kernel (bnm_fused_generic.hip): run-time layer widths, weights in LDS ----------
 struct BnmGenericDesc {      // passed to the kernel by value
