@@ -93,6 +93,79 @@ BNM_DEVICE void relunorm_pack(const i32x16 (&acc)[MT], i32x4 (&packed)[NP], int 
     }
 }
 
+// ---- relunorm_pack in SLICES ----------------------------------------------------------------------------------------
+// The same arithmetic as relunorm_pack, cut into chunks of 8-9 VALU instructions with a call slot(k), k = 0, 1, ... behind each
+// chunk (k is a std::integral_constant).  A kernel whose wave has its SIMD to itself (bnm_fused_regw.hip) issues one MFMA of an
+// INDEPENDENT chain per slot and pins the order with sched_barrier: an MFMA occupies the matrix core for 32 clocks = 8 VALU
+// issues, and a wave issues in order - two MFMAs back to back would stall its VALU work, a long VALU run leaves the matrix core
+// idle.  Slots: MT (maximum, one per tile) + 1 (shift) + 4 MT (clamp / shift / pack, four values of each output dword's byte
+// lane b per chunk) = 5 MT + 1.
+template <int MT>
+constexpr int relunorm_slots() { return 5 * MT + 1; }
+
+// four values -> byte B of four dwords (sdwa_shift_pack16's instruction, one byte lane); consecutive chunks write the same
+// registers 8+ instructions apart; the s_nop that covers the dst_sel forwarding hazard stands behind the last lane only
+#define BNM_SD4(SEL, UNUSED, NOP)                                                                                                      \
+    asm("v_lshrrev_b32_sdwa %0, %4, %5 dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:DWORD src1_sel:DWORD\n\t"                        \
+        "v_lshrrev_b32_sdwa %1, %4, %6 dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:DWORD src1_sel:DWORD\n\t"                        \
+        "v_lshrrev_b32_sdwa %2, %4, %7 dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:DWORD src1_sel:DWORD\n\t"                        \
+        "v_lshrrev_b32_sdwa %3, %4, %8 dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:DWORD src1_sel:DWORD" NOP                           \
+        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(s), "v"(c0), "v"(c1), "v"(c2), "v"(c3))
+template <int B>
+BNM_DEVICE void sdwa_shift_pack4(int &d0, int &d1, int &d2, int &d3, int c0, int c1, int c2, int c3, int s) {
+    if constexpr (B == 0) {
+        asm("v_lshrrev_b32_sdwa %0, %4, %5 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %1, %4, %6 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %2, %4, %7 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %3, %4, %8 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD"
+            : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(s), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+    } else if constexpr (B == 1) BNM_SD4("BYTE_1", "UNUSED_PRESERVE", "");
+    else if constexpr (B == 2) BNM_SD4("BYTE_2", "UNUSED_PRESERVE", "");
+    else BNM_SD4("BYTE_3", "UNUSED_PRESERVE", "\n\ts_nop 0");      // (the byte lanes' only reader follows this one)
+}
+#undef BNM_SD4
+
+template <int MT, bool DBL, int NP, class SLOT>
+BNM_DEVICE void relunorm_pack_sliced(const i32x16 (&acc)[MT], i32x4 (&packed)[NP], int h, SLOT &&slot) {
+    static_assert(NP >= MT, "output array too short");
+    int mx = acc[0][0];
+    static_for<0, MT>([&](auto M_) {
+        constexpr int m = decltype(M_)::value;
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = max(mx, acc[m][r]);
+        slot(std::integral_constant<int, m>{});
+    });
+    mx = max(max_with_partner32(mx), 0);
+    // DBL: accumulators hold 2x; shift = bitlength(mx >> 8), clamp to [0, 255 * 2^sh - 1], >> sh, then (y + 1) >> 1 by v_lerp_u8
+    // else: shift = bitlength(mx >> 7), (x + 2^(sh-1)) clamped to [0, 128 * 2^sh - 1], >> sh            (see relunorm_pack)
+    const int sh = DBL ? 24 - __builtin_clz((uint32_t)mx | 255u) : 25 - __builtin_clz((uint32_t)mx | 127u);
+    const int rnd = DBL ? 0 : (1 << sh) >> 1;
+    const int hi = DBL ? (255 << sh) - 1 : (128 << sh) - 1;
+    slot(std::integral_constant<int, MT>{});
+    static_for<0, MT>([&](auto M_) {
+        constexpr int m = decltype(M_)::value;
+        int d0, d1, d2, d3;
+        static_for<0, 4>([&](auto B_) {
+            constexpr int b = decltype(B_)::value;
+            int c[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[q] = clamp0_med3(DBL ? acc[m][4 * q + b] : acc[m][4 * q + b] + rnd, hi);
+            sdwa_shift_pack4<b>(d0, d1, d2, d3, c[0], c[1], c[2], c[3], sh);
+            if constexpr (b == 3) {
+                if constexpr (DBL) {
+                    packed[m][0] = (int)__builtin_amdgcn_lerp((uint32_t)d0, 0u, 0x01010101u);
+                    packed[m][1] = (int)__builtin_amdgcn_lerp((uint32_t)d1, 0u, 0x01010101u);
+                    packed[m][2] = (int)__builtin_amdgcn_lerp((uint32_t)d2, 0u, 0x01010101u);
+                    packed[m][3] = (int)__builtin_amdgcn_lerp((uint32_t)d3, 0u, 0x01010101u);
+                } else {
+                    packed[m][0] = d0; packed[m][1] = d1; packed[m][2] = d2; packed[m][3] = d3;
+                }
+            }
+            slot(std::integral_constant<int, MT + 1 + 4 * m + b>{});
+        });
+    });
+}
+
 // first strict maximum over the class rows (ReLUNorm's return value, :25-37).  key = value*256 + (255 - row):
 // the largest key is the largest value and, among equals, the smallest row.  |value| < 2^23 for every layer that
 // can be last (K <= 128, |act| <= 127, |w| <= 128).
