@@ -87,7 +87,7 @@ def build_diag(timing=False):
     stream / pipe-overlap probes (csrc/bnm_diag.h).  timing=True additionally stamps the shader clock around the dual
     kernel's two vmcnt waits and writes the per-wave sums into the logits buffer (profiles/wait_timing.py)."""
     lib = os.path.join(HERE, "libbitnetmcu_hip_timing.so" if timing else "libbitnetmcu_hip_diag.so")
-    flags = ["-DBNM_DIAG"] + (["-DBNM_DIAG_TIMING"] if timing else [])
+    flags = ["-DBNM_DIAG"] + (["-DBNM_DIAG_TIMING", "-DBNM_REGW_TIMING"] if timing else [])
     objs = objects(extra_flags=flags, obj_dir=os.path.join(HERE, "_build_timing" if timing else "_build_diag"),
                    sources=SOURCES + DIAG_SOURCES)
     run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", lib] + objs)

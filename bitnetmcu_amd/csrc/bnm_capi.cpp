@@ -178,7 +178,7 @@ struct bnm_ctx {
     // fused MFMA path: shape-specialised kernels (register-resident weights, bnm_fused_fc.hip) and / or the generic
     // kernel (run-time widths, weights in LDS, bnm_fused_generic.hip; variant id BNM_FUSED_GENERIC)
     bool fused_ok = false;      // at least one of the two can run this model
-    bool table_ok = false, generic_ok = false;
+    bool table_ok = false, generic_ok = false, regw_ok = false;
     BnmFusedShape shape{};
     BnmGenericDesc gdesc{};
     void *frags = nullptr, *gfrags = nullptr;
@@ -496,6 +496,17 @@ int ctx_build(bnm_ctx *c) {
                 if (int e = build_frags(mt, ktp, off, bytes, false, &c->frags)) return e;
                 c->table_ok = true;
                 c->variant = var;
+            } else if (bnmk_regw_supported(sh)) {
+                // shapes of the register-resident-weight kernel (variant 9, selected with bnm_ctx_set_tuning only - DESIGN.md 4.1c
+                // says why it is not the default): the same fragment layout
+                uint32_t mt[4], ktp[4], off[4], bytes = 0, kt = (uint32_t)sh.KT0;
+                for (size_t i = 0; i < nfc; i++) {
+                    mt[i] = (uint32_t)sh.M[i]; ktp[i] = kt; off[i] = bytes;
+                    bytes += mt[i] * kt * 1024u;
+                    kt = mt[i];
+                }
+                if (int e = build_frags(mt, ktp, off, bytes, false, &c->frags)) return e;
+                c->regw_ok = true;
             }
         }
         c->shape = sh;
@@ -518,7 +529,7 @@ int ctx_build(bnm_ctx *c) {
             c->fused_reason = "the weight fragments do not fit beside the image tiles in 160 KiB of LDS";
         }
         // the register-resident-weight kernel takes whole 64-image pairs; the generic kernel finishes its calls
-        if (c->table_ok && c->variant == BNM_FUSED_REGW && !c->generic_ok) c->table_ok = false;
+        c->regw_ok = c->regw_ok && c->generic_ok;
         c->fused_ok = c->table_ok || c->generic_ok;
     }
     // ---- ternary ALU path ------------------------------------------------------------------------------
@@ -847,6 +858,7 @@ int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
         const bool ok = variant == BNM_FUSED_GENERIC ? c->generic_ok
                         : variant == BNM_FUSED_GENERIC_T1 ? (c->generic_ok && bnmk_generic_tiles(c->gdesc, c->shape.dbl, 1, false) == 1)
                         : variant == BNM_FUSED_GENERIC_T2 ? (c->generic_ok && bnmk_generic_tiles(c->gdesc, c->shape.dbl, 2, false) == 2)
+                        : variant == BNM_FUSED_REGW ? c->regw_ok
                         : (c->table_ok && bnmk_fused_supported(c->shape, variant));
         if (!ok) return fail(BNM_EUNSUPPORTED, "fused kernel variant not available for this model shape");
         c->variant = variant;

@@ -631,7 +631,6 @@ int bnmk_fused_default_variant(const BnmFusedShape &sh) {
     // ... and batches of 2 pairs from the device-wide counter (split eight ways) 6-7.5 % ahead of the fixed stride
     // (same-process interleaved A/B, profiles/headline_ab.py: profiles/r02/headline_ab_r02x.json ... r02z4.json)
     if (find_fused(sh, FUSED_DUAL_DEVWIDE)) return FUSED_DUAL_DEVWIDE;
-    if (bnmk_regw_supported(sh)) return FUSED_REGW;
     if (find_fused(sh, FUSED_DUAL_SHARED)) return FUSED_DUAL_SHARED;
     if (find_fused(sh, FUSED_DUAL)) return FUSED_DUAL;
     if (sh.M[0] >= 2 && find_fused(sh, FUSED_LDSDMA2)) return FUSED_LDSDMA2;

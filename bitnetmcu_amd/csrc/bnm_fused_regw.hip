@@ -23,17 +23,32 @@
 #include "bnm_fused_tile.hpp"
 #include "bnm_fused_math.hpp"
 
+// Measurement scaffolding (profiles/r04_regw_timing.py builds a private copy of the library with -DBNM_REGW_TIMING): shader-clock
+// stamps around the two tile waits of the loop body; compiled out of the product library.
+#ifdef BNM_REGW_TIMING
+#define RW_TIMING(...) __VA_ARGS__
+#else
+#define RW_TIMING(...)
+#endif
+
 namespace {
 
 // A fragments of one layer: MT tiles x KS K-steps, (m, s) at fragment index m * KS + s of the layer's image
 template <int MT, int KS>
-struct RegFrags {       // held in registers for the whole persistent loop
+struct RegFrags {       // held in AccVGPRs for the whole persistent loop
     i32x4 a[MT][KS];
+    // Loaded STRAIGHT INTO AccVGPRs by an asm load ("=a"): a value that starts its life in an architectural VGPR (any load hipcc
+    // emits itself) reaches an "a"-constrained asm operand through a COPY per use, and the copies that MachineLICM does not hoist
+    // out of the loop keep their VGPR originals alive in it - 22 fragments = 88 VGPRs and as many v_accvgpr_write per iteration
+    // in the first asm-MFMA build.  hipcc does not count these loads (cdna_hip_programming.md 5.7, form iii): the caller retires
+    // them with loaded() before anything reads a fragment.
     BNM_DEVICE void load(const i32x4 *base, int lane) {
+        const i32x4 *p = base + lane;
 #pragma unroll
         for (int m = 0; m < MT; m++)
 #pragma unroll
-            for (int s = 0; s < KS; s++) a[m][s] = base[(m * KS + s) * 64 + lane];
+            for (int s = 0; s < KS; s++)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(a[m][s]) : "v"(p + (m * KS + s) * 64) : "memory");
     }
     BNM_DEVICE i32x4 get(int m, int s) const { return a[m][s]; }
 };
@@ -42,6 +57,32 @@ struct LdsFrags {       // read from the workgroup's LDS copy, lane-linear ds_re
     const char *p;      // LDS address of the layer's image + 16 * lane
     BNM_DEVICE i32x4 get(int m, int s) const { return *(const i32x4 *)(p + (m * KS + s) * 1024); }
 };
+
+// One MFMA of the pinned loop body, A operand NAMED as an AccVGPR tuple ("a" constraint).  With the builtin hipcc's register
+// allocator is free to give a weight fragment an AccVGPR for one stretch of the loop and architectural VGPRs for another, and it
+// does: ~200 v_accvgpr_read / v_accvgpr_mov per pair of tiles (18 % of the loop's VALU instructions) shuffling loop-invariant
+// weights around (profiles/r04/regw_notes.md).  A value whose every use in the loop asks for an AccVGPR stays in one.
+// hipcc neither schedules nor pads an asm statement (cdna_hip_programming.md 5.7), so the hazards are handled by construction:
+//   * VALU write -> MFMA operand read (2 wait states): every statement opens with s_nop 1, whatever hipcc put in front of it;
+//   * MFMA result -> VALU read (12 wait states for this 8-pass MFMA): the loop body's order is pinned with sched_barrier and an
+//     accumulator's reader (the sliced ReLUNorm of the NEXT block, or the next iteration) is hundreds of instructions behind its
+//     last MFMA; the one short distance - the classifier's argmax - uses the builtin;
+//   * MFMA -> MFMA on the same accumulator (SrcC = vDst, the accumulate chain): no wait states, as in hipcc's own code;
+//   * the B operand is never an MFMA result; a fragment's AccVGPRs are written once, ahead of the loop.
+template <bool INIT>
+BNM_DEVICE void mfma_areg(i32x16 &acc, const i32x4 &w, const i32x4 &b) {
+    if constexpr (INIT) asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+}
+// fragment (m, s) of a layer x b: register-resident layers through mfma_areg, LDS-resident ones through the builtin
+template <bool INIT, int MT, int KS>
+BNM_DEVICE void mfma_frag(i32x16 &acc, const RegFrags<MT, KS> &A, int m, int s, const i32x4 &b) {
+    mfma_areg<INIT>(acc, A.a[m][s], b);
+}
+template <bool INIT, int MT, int KS>
+BNM_DEVICE void mfma_frag(i32x16 &acc, const LdsFrags<MT, KS> &A, int m, int s, const i32x4 &b) {
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A.get(m, s), b, INIT ? zero16() : acc, 0, 0, 0);
+}
 
 template <int MT, int KT, class F>
 BNM_DEVICE void mma(const F &A, const i32x4 (&b)[KT], i32x16 (&acc)[MT]) {
@@ -64,32 +105,39 @@ constexpr int RW_WPB = 4;     // one wave per SIMD, one workgroup per CU
 
 }  // namespace
 
-// Filler plan: how many K-step groups of the NEXT pair's layer 1 (16 groups: 8 K-steps x 2 tiles, M1 MFMAs each) go into each
-// block of the loop body (see the kernel).  Block 0 holds none (its VALU work reads the accumulators the first groups overwrite).
+// Filler plan: first[b] .. first[b + 1] are the K-steps (groups of M1 MFMAs) of the NEXT pair's tile A that block b of the loop
+// body issues beside its own MFMAs (see the kernel); block 0 carries the whole layer 1 of the current pair's tile B instead.
 template <int NL> struct FillerPlan;
-template <> struct FillerPlan<4> { static constexpr int first[8] = {0, 0, 3, 6, 9, 12, 16, 16}; };   // blocks 1..5: 3 3 3 3 4
-template <> struct FillerPlan<3> { static constexpr int first[6] = {0, 0, 5, 10, 15, 16}; };         // blocks 1..4: 5 5 5 1
+template <> struct FillerPlan<4> { static constexpr int first[7] = {0, 0, 2, 4, 6, 7, 8}; };   // blocks 1..5: 2 2 2 1 1
+template <> struct FillerPlan<3> { static constexpr int first[6] = {0, 0, 2, 4, 6, 8}; };      // blocks 1..4: 2 2 2 2
 
 // RL: layers 1..RL keep their fragments in registers, the others in LDS.
 //
-// The loop is software-pipelined BY HAND across iterations, because a wave that owns its SIMD has nobody to hide its stalls:
-//   * layer 1 of the NEXT pair runs one iteration ahead.  Its MFMAs depend on nothing but the image tile, so they are the
-//     filler that keeps the matrix core busy wherever the current pair's dependent chain (ReLUNorm -> MFMAs -> ReLUNorm ...)
-//     has only VALU work: 16 K-step groups spread over the body's blocks (FillerPlan), each reading its B operand from the
-//     tile slot just in time.  The layer-1 sums a1[2][M1] are the only state carried across the back edge, and a group
-//     accumulates straight into the registers the current pair's first ReLUNorm has just vacated;
-//   * the body alternates the two tiles of the current pair at block granularity: the MFMAs of one tile's next layer are
-//     issued in front of the other tile's ReLUNorm, so every VALU block has the critical MFMAs of the other chain plus filler
-//     beside it.  Per pair of a 96-96-96-10 model: 90 MFMAs = 2880 matrix-core clocks under ~930 VALU = 3700 clocks;
-//   * two pair buffers (four 8 KiB tile slots) per wave: the pair whose layer 1 is computed in iteration i was requested in
-//     iteration i-2; a slot is refilled (pair i+3) as soon as its last K-step has been read;
-//   * pairs are assigned with a fixed stride (pair = wave + k * waves): with one wave per SIMD there is no arbitration between
-//     waves of a SIMD (the reason the two-waves-per-SIMD kernels take their work from a counter), and a scalar
-//     atomic in flight would turn every LDS wait of the body (the fillers' operand reads) into a wait for its round trip.
+// The loop is software-pipelined BY HAND, across iterations, because a wave that owns its SIMD has nobody to hide its stalls.
+// A wave issues in order: an MFMA occupies the matrix core for 32 clocks = 8 VALU issues, two MFMAs back to back stall the
+// wave's VALU work, a long VALU run leaves the matrix core idle.  So the body is a sequence of BLOCKS; a block is one tile's
+// sliced ReLUNorm (relunorm_pack_sliced: chunks of 8-9 VALU instructions) with ONE MFMA of an independent chain issued in
+// the slot behind each chunk, order pinned with sched_barrier:
+//   block 0   ReLUNorm of tile A's layer-1 sums (carried in a1A from the previous iteration)  |  layer 1 of tile B: 8 M1 MFMAs
+//   block 1   ReLUNorm of tile B's layer 1                    |  layer 2 of tile A  + K-steps of the NEXT pair's tile A, layer 1
+//   block 2   ReLUNorm of tile A's layer 2                    |  layer 2 of tile B  + ...
+//   block 3   ReLUNorm of tile B's layer 2                    |  layer 3 of tile A  + ...
+//   block 4   ReLUNorm of tile A's layer 3                    |  layer 3 of tile B  + ...
+//   block 5   ReLUNorm of tile B's layer 3                    |  layer 4 of tile A  + ...
+//   block 6   layer 4 of tile B, argmax / logits / class-id store of both tiles
+// Layer 1 depends on nothing but the image tile: it is the filler that keeps the matrix core busy where the dependent chain
+// ReLUNorm -> MFMAs -> ReLUNorm has only VALU work.  Only tile A's layer-1 sums cross the back edge (48 registers for M1 = 3):
+// with both tiles' sums carried, four accumulator sets are live through the middle of the body and hipcc spills.
+// Two pair buffers (four 8 KiB tile slots) per wave; a slot is refilled - with the tile two pairs on - behind the block that
+// read its last K-step, so a tile has more than an iteration to arrive.
+// Pairs are assigned with a fixed stride (pair = wave + k * waves): with one wave per SIMD there is no arbitration between
+// the waves of a SIMD (the reason the two-waves-per-SIMD kernels take their work from a counter), and a scalar
+// atomic in flight would turn every LDS wait of the body (the fillers' operand reads) into a wait for its round trip.
 template <int M1, int M2, int M3, int M4, int RL, bool DBL, int NC8>
 __global__ __launch_bounds__(64 * RW_WPB, 1) void fused_fc_regw_kernel(const int8_t *__restrict__ images, uint64_t n,
                                                                          const i32x4 *__restrict__ frags, uint32_t n_classes,
                                                                          uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out) {
+    using std::integral_constant;
     constexpr int KT0 = 8;
     constexpr int NL = M4 > 0 ? 4 : 3;
     constexpr int MC = M4 > 0 ? M4 : M3;                                             // tiles of the classifier layer
@@ -122,13 +170,15 @@ __global__ __launch_bounds__(64 * RW_WPB, 1) void fused_fc_regw_kernel(const int
         if constexpr (M4 > 0) {
             if constexpr (RL >= 4) A4.load(fp, lane); else A4.p = lp;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the fragments' asm loads (RegFrags::load)
+        __builtin_amdgcn_sched_barrier(0);
     }
     char *const tiles = smem + LDSW + wave * (4 * TILE);
     int32_t *const stage = (int32_t *)(smem + LDSW + RW_WPB * 4 * TILE + wave * 2048);
 
     const uint64_t n_pairs = n >> 6;            // the launcher hands this kernel whole 64-image pairs only
     const uint64_t stride = (uint64_t)gridDim.x * RW_WPB;
-    uint64_t cur = (uint64_t)blockIdx.x * RW_WPB + (uint64_t)wave;      // the pair being finished; its layer-1 sums are in a1
+    uint64_t cur = (uint64_t)blockIdx.x * RW_WPB + (uint64_t)wave;      // the pair being finished; tile A's layer-1 sums are in a1A
 
     uint32_t voff[4];
 #pragma unroll
@@ -142,25 +192,15 @@ __global__ __launch_bounds__(64 * RW_WPB, 1) void fused_fc_regw_kernel(const int
     };
     // a pair index past the end re-reads the wave's current pair: constant wait counts, branch-free body, never out of bounds
     auto clamp_pair = [&](uint64_t p) -> uint64_t { return p < n_pairs ? p : cur; };
+    // B operand of K-step s of the tile in slot `slot_off` (row j, 16-byte slot 2s + h, XOR-swizzled: bnm_fused_fc.hip)
+    auto b_operand = [&](uint32_t slot_off, int s) -> i32x4 { return *(const i32x4 *)(tiles + ((rd_base + slot_off) ^ (32u * (uint32_t)s))); };
     constexpr int NWAIT = 24;     // loads younger than the slot waited for: the three other slots' 8 pieces each
 
-    i32x16 a1[2][M1];
+    i32x16 a1A[M1];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int m = 0; m < M1; m++) a1[t][m] = zero16();
-    // K-step s of tile t from the pair buffer at par_off: a1[t][m] (+)= A1(m, s) x B
-    auto l1_step = [&](uint32_t par_off, auto T_, auto S_) {
-        constexpr int t = decltype(T_)::value, s = decltype(S_)::value;
-        const i32x4 b = *(const i32x4 *)(tiles + ((rd_base + par_off + (uint32_t)t * TILE) ^ (32u * (uint32_t)s)));
-#pragma unroll
-        for (int m = 0; m < M1; m++) {
-            const i32x16 c = s == 0 ? zero16() : a1[t][m];
-            a1[t][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1.get(m, s), b, c, 0, 0, 0);
-        }
-    };
+    for (int m = 0; m < M1; m++) a1A[m] = zero16();
 
-    // ---- prologue: pairs cur and cur + stride requested, layer 1 of cur computed, cur + 2 stride requested -------------
+    // ---- prologue: both buffers requested, layer 1 of the first pair's tile A computed, its slot refilled --------------
     const bool any = cur < n_pairs;
     if (any) {
         dma_tile(2ull * cur, 0);
@@ -168,46 +208,50 @@ __global__ __launch_bounds__(64 * RW_WPB, 1) void fused_fc_regw_kernel(const int
         const uint64_t p1 = clamp_pair(cur + stride);
         dma_tile(2ull * p1, 2 * TILE);
         dma_tile(2ull * p1 + 1ull, 3 * TILE);
-        bnm_wait_vmcnt<16>();
-        static_for<0, 8>([&](auto S_) { l1_step(0u, std::integral_constant<int, 0>{}, S_); });
-        static_for<0, 8>([&](auto S_) { l1_step(0u, std::integral_constant<int, 1>{}, S_); });
-        const uint64_t p2 = clamp_pair(cur + 2ull * stride);
-        dma_tile(2ull * p2, 0);
-        dma_tile(2ull * p2 + 1ull, TILE);
+        bnm_wait_vmcnt<NWAIT>();
+        i32x4 b0[KT0];
+#pragma unroll
+        for (int sk = 0; sk < KT0; sk++) b0[sk] = b_operand(0u, sk);
+        static_for<0, KT0 * M1>([&](auto K_) {
+            constexpr int sk = decltype(K_)::value / M1, m = decltype(K_)::value % M1;
+            mfma_frag<sk == 0>(a1A[m], A1, m, sk, b0[sk]);
+        });
+        dma_tile(2ull * clamp_pair(cur + 2ull * stride), 0);
+#pragma unroll
+        for (int m = 0; m < M1; m++) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a1A[m]));      // asm MFMA result -> first reader
     }
-    uint32_t par_off = 2u * TILE;      // the pair buffer whose tiles go through layer 1 in this iteration (cur + stride)
+    uint32_t par = 0;      // byte offset of the pair buffer that holds the current pair (0 or 2 tiles)
+    RW_TIMING(uint64_t t_wait[2] = {0, 0}, t_iters = 0; const uint64_t t_start = __builtin_readcyclecounter();)
 
     while (cur < n_pairs) {
-        const uint64_t fill = clamp_pair(cur + 3ull * stride);
-        // One block of the body: the MFMAs of one tile's layer (they wait for nothing but the packed activations the previous
-        // block produced) and G filler groups of the next pair's layer 1 (B operands read from the tile slot at the top of the
-        // block, a whole layer of MFMAs ahead of their use), issued ONE PER SLOT of the other tile's sliced ReLUNorm
-        // (relunorm_pack_sliced: 8-9 VALU per slot = the 32 clocks an MFMA occupies the matrix core), critical MFMAs first, K-step
-        // outermost.  The order is pinned with sched_barrier - a wave issues in order, so two MFMAs back to back stall its VALU
-        // work and a long VALU run leaves the matrix core idle; left to its own devices (and to sched_group_barrier) hipcc
-        // produced both.  Filler group g: tile g >> 3, K-step g & 7; a slot is refilled behind the block that read its last K-step.
-        auto block = [&](auto B_, auto KC_, auto MTC_, const auto &AC, const auto &bc, auto &accc, auto MTV_, const auto &accv, auto &pv) {
-            constexpr int blk = decltype(B_)::value, g0 = FillerPlan<NL>::first[blk], g1 = FillerPlan<NL>::first[blk + 1];
+        const uint64_t fill_b = clamp_pair(cur + 2ull * stride), fill_a = clamp_pair(cur + 3ull * stride);
+        const uint32_t slot_b = par + TILE, slot_a = par ^ (2u * TILE);      // tile B of this pair, tile A of the next one
+        // One block: NCRIT = KC * MTC MFMAs of the dependent chain (layer weights AC, B operands bc, sums accc) and the K-steps
+        // [g0, g1) of a layer-1 filler (tile slot fslot, sums accf), one MFMA per slot of the ReLUNorm of accv -> pv.  Critical
+        // MFMAs first, K-step outermost.  The filler's B operands are read at the top of the block, a layer of MFMAs ahead of use.
+        auto block = [&](auto G0_, auto G1_, uint32_t fslot, i32x16 (&accf)[M1], auto KC_, auto MTC_, const auto &AC, const auto &bc, auto &accc,
+                         auto MTV_, const auto &accv, auto &pv) {
+            constexpr int g0 = decltype(G0_)::value, g1 = decltype(G1_)::value;
             constexpr int KC = decltype(KC_)::value, MTC = decltype(MTC_)::value, MTV = decltype(MTV_)::value;
-            constexpr int NG = g1 - g0, NCRIT = KC * MTC, NM = NCRIT + NG * M1, NS = MTV > 0 ? relunorm_slots<MTV>() : 0;
+            constexpr int NG = g1 - g0, NCRIT = KC * MTC, NM = NCRIT + NG * M1, NS = MTV > 0 ? relunorm_slots<MTV>() : 1;
             __builtin_amdgcn_sched_barrier(0);
             i32x4 fb[NG > 0 ? NG : 1];
-            static_for<g0, g1>([&](auto G_) {
-                constexpr int g = decltype(G_)::value, t = g >> 3, sk = g & 7;
-                if constexpr (g == 8) bnm_wait_vmcnt<NWAIT>();      // slot B (slot A: the top of the body)
-                fb[g - g0] = *(const i32x4 *)(tiles + ((rd_base + par_off + (uint32_t)t * TILE) ^ (32u * (uint32_t)sk)));
-            });
+            if constexpr (g0 == 0 && NG > 0) {                                // the filler's tile has landed
+                RW_TIMING(const uint64_t t0 = __builtin_readcyclecounter();)
+                bnm_wait_vmcnt<NWAIT>();
+                RW_TIMING(t_wait[KC == 0 ? 0 : 1] += __builtin_readcyclecounter() - t0;)
+            }
+#pragma unroll
+            for (int g = g0; g < g1; g++) fb[g - g0] = b_operand(fslot, g);
             __builtin_amdgcn_sched_barrier(0);
             auto issue = [&](auto K_) {      // MFMA k of the block
                 constexpr int k = decltype(K_)::value;
                 if constexpr (k < NCRIT) {
                     constexpr int sk = k / MTC, m = k % MTC;
-                    const i32x16 c = sk == 0 ? zero16() : accc[m];
-                    accc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AC.get(m, sk), bc[sk], c, 0, 0, 0);
+                    mfma_frag<sk == 0>(accc[m], AC, m, sk, bc[sk]);
                 } else if constexpr (k < NM) {
-                    constexpr int g = g0 + (k - NCRIT) / M1, m = (k - NCRIT) % M1, t = g >> 3, sk = g & 7;
-                    const i32x16 c = sk == 0 ? zero16() : a1[t][m];
-                    a1[t][m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1.get(m, sk), fb[g - g0], c, 0, 0, 0);
+                    constexpr int sk = g0 + (k - NCRIT) / M1, m = (k - NCRIT) % M1;
+                    mfma_frag<sk == 0>(accf[m], A1, m, sk, fb[sk - g0]);
                 }
             };
             // NM MFMAs over NS slots: slot i issues MFMAs [i * NM / NS, (i + 1) * NM / NS)
@@ -219,24 +263,24 @@ __global__ __launch_bounds__(64 * RW_WPB, 1) void fused_fc_regw_kernel(const int
             if constexpr (MTV > 0) relunorm_pack_sliced<MTV, DBL>(accv, pv, h, slot);
             else static_for<0, NM>(issue);
             __builtin_amdgcn_sched_barrier(0);
-            static_for<g0, g1>([&](auto G_) {
-                constexpr int g = decltype(G_)::value, t = g >> 3, sk = g & 7;
-                if constexpr (sk == 7) dma_tile(2ull * fill + (uint64_t)t, par_off + (uint32_t)t * TILE);
-            });
         };
-        using std::integral_constant;
-        bnm_wait_vmcnt<NWAIT>();        // slot A of the next pair has landed
+        typedef integral_constant<int, 0> I0;
+        typedef integral_constant<int, KT0> I8;
+        typedef FillerPlan<NL> FP;
+#define FILL(B) integral_constant<int, FP::first[B]>{}, integral_constant<int, FP::first[B + 1]>{}, slot_a, a1A
+#define REFILL_A(B) if constexpr (FP::first[B + 1] == KT0 && FP::first[B] < KT0) dma_tile(2ull * fill_a, slot_a)
 
         i32x4 p1A[M1], p1B[M1], p2A[M2], p2B[M2];
-        i32x16 a2A[M2], a2B[M2], a3A[M3], a3B[M3];
-        typedef integral_constant<int, 0> I0;
-        relunorm_pack<M1, DBL>(a1[0], p1A, h);                                                                         // block 0
-        block(integral_constant<int, 1>{}, integral_constant<int, M1>{}, integral_constant<int, M2>{}, A2, p1A, a2A,
-              integral_constant<int, M1>{}, a1[1], p1B);
-        block(integral_constant<int, 2>{}, integral_constant<int, M1>{}, integral_constant<int, M2>{}, A2, p1B, a2B,
-              integral_constant<int, M2>{}, a2A, p2A);
-        block(integral_constant<int, 3>{}, integral_constant<int, M2>{}, integral_constant<int, M3>{}, A3, p2A, a3A,
-              integral_constant<int, M2>{}, a2B, p2B);
+        i32x16 a1B[M1], a2A[M2], a2B[M2], a3A[M3], a3B[M3];
+        // block 0: layer 1 of tile B (no dependent chain: its 8 K-steps ARE the block's MFMAs) beside tile A's first ReLUNorm
+        block(I0{}, I8{}, slot_b, a1B, I0{}, I0{}, A1, p1A, a1B, integral_constant<int, M1>{}, a1A, p1A);
+        dma_tile(2ull * fill_b + 1ull, slot_b);
+        block(FILL(1), integral_constant<int, M1>{}, integral_constant<int, M2>{}, A2, p1A, a2A, integral_constant<int, M1>{}, a1B, p1B);
+        REFILL_A(1);
+        block(FILL(2), integral_constant<int, M1>{}, integral_constant<int, M2>{}, A2, p1B, a2B, integral_constant<int, M2>{}, a2A, p2A);
+        REFILL_A(2);
+        block(FILL(3), integral_constant<int, M2>{}, integral_constant<int, M3>{}, A3, p2A, a3A, integral_constant<int, M2>{}, a2B, p2B);
+        REFILL_A(3);
 
         const uint64_t imgA = (cur << 6) + (uint64_t)j, imgB = imgA + 32ull;
         int32_t *const tile_a = logits_out + (cur << 6) * n_classes, *const tile_b = tile_a + 32u * n_classes;
@@ -244,6 +288,7 @@ __global__ __launch_bounds__(64 * RW_WPB, 1) void fused_fc_regw_kernel(const int
         auto finish = [&](const i32x16 (&accA)[MC], const i32x16 (&accB)[MC]) {
             clsA = argmax_rows<MC, NC8>(accA, h);
             clsB = argmax_rows<MC, NC8>(accB, h);
+#ifndef BNM_REGW_TIMING
             if (logits_out) {
                 if (n_classes <= 16u) {
                     store_logits_tile<MC, NC8, 0>(accA, stage, tile_a, j, h, lane, n_classes);
@@ -253,28 +298,51 @@ __global__ __launch_bounds__(64 * RW_WPB, 1) void fused_fc_regw_kernel(const int
                     store_logits<MC>(accB, tile_b + (uint32_t)j * n_classes, h, n_classes);
                 }
             }
+#endif
+        };
+        // the classifier's sums are read a few instructions behind their last MFMA: 16 wait states between an asm MFMA (whose
+        // latency hipcc does not know) and its first reader
+        auto settle = [&](i32x16 (&acc)[MC]) {
+#pragma unroll
+            for (int m = 0; m < MC; m++) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[m]));
         };
         if constexpr (M4 > 0) {
             i32x4 p3A[M3], p3B[M3];
             i32x16 a4A[MC], a4B[MC];
-            block(integral_constant<int, 4>{}, integral_constant<int, M2>{}, integral_constant<int, M3>{}, A3, p2B, a3B,
-                  integral_constant<int, M3>{}, a3A, p3A);
-            block(integral_constant<int, 5>{}, integral_constant<int, M3>{}, integral_constant<int, MC>{}, A4, p3A, a4A,
-                  integral_constant<int, M3>{}, a3B, p3B);
-            mma<MC, M3>(A4, p3B, a4B);                                                                                 // block 6
+            block(FILL(4), integral_constant<int, M2>{}, integral_constant<int, M3>{}, A3, p2B, a3B, integral_constant<int, M3>{}, a3A, p3A);
+            REFILL_A(4);
+            block(FILL(5), integral_constant<int, M3>{}, integral_constant<int, MC>{}, A4, p3A, a4A, integral_constant<int, M3>{}, a3B, p3B);
+            REFILL_A(5);
+            block(I0{}, I0{}, 0u, a1A, integral_constant<int, M3>{}, integral_constant<int, MC>{}, A4, p3B, a4B, I0{}, a3B, p3B);      // block 6
+            settle(a4B);
             finish(a4A, a4B);
         } else {
-            block(integral_constant<int, 4>{}, integral_constant<int, M2>{}, integral_constant<int, M3>{}, A3, p2B, a3B, I0{}, a3A, p2A);
+            block(FILL(4), integral_constant<int, M2>{}, integral_constant<int, M3>{}, A3, p2B, a3B, I0{}, a2B, p2B);
+            REFILL_A(4);
+            settle(a3B);
             finish(a3A, a3B);
         }
+#undef FILL
+#undef REFILL_A
         // lanes 0..31 store tile A's class ids, lanes 32..63 tile B's: one 256-byte nontemporal store per pair.  It is the
         // youngest vector-memory operation by far when the next waits run (24 younger LOADS are allowed to be outstanding,
         // this store is behind 32 of them), so no wait of the next iteration sits on its acknowledgement.
         __builtin_nontemporal_store(h ? clsB : clsA, cls_out + (h ? imgB : imgA));
         cur += stride;
-        par_off ^= 2u * TILE;
+        par ^= 2u * TILE;
+        RW_TIMING(t_iters++;)
     }
     bnm_wait_vmcnt<0>();        // no LDS-DMA may outlive the workgroup's LDS allocation
+#ifdef BNM_REGW_TIMING
+    // the logits buffer is reused as the record array: 4 x uint64 per wave {loop cycles, wait B (block 0), wait A (block 1), iterations}
+    if (logits_out && lane == 0) {
+        uint64_t *rec = (uint64_t *)logits_out + 4ull * ((uint64_t)blockIdx.x * RW_WPB + (uint64_t)wave);
+        rec[0] = __builtin_readcyclecounter() - t_start;
+        rec[1] = t_wait[0];
+        rec[2] = t_wait[1];
+        rec[3] = t_iters;
+    }
+#endif
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------------------------------
@@ -292,13 +360,19 @@ struct RegwEntry {
 const RegwEntry kRegw[] = {
     // 256-96-96-96-N: the ternary model of BASELINE configs[2] on the MFMA path; 45 fragments, all in registers
     REGW_ANY_AND_10(3, 3, 3, 1, 4, true),
+    // the documented 12 KB shapes (docs/documentation.md:169-183): 112-96-96 2-bit (56 fragments, all in registers), 128-128-112
+    // ternary (68: layers 1-3 = 64 fragments = all 256 AccVGPRs, the classifier's 4 from LDS).  (160-160-160 binary: 95 fragments,
+    // 55 KiB of them in LDS beside four tile slots per wave = 191 KiB: does not fit; it compiles - zero scratch - with two slots.)
+    REGW(4, 3, 3, 1, 4, true, 2),
+    REGW(4, 4, 4, 1, 3, true, 2),
 };
+uint32_t regw_lds_bytes(const RegwEntry &e);
 const RegwEntry *find_regw(const BnmFusedShape &sh) {
     if (sh.KT0 != 8 || sh.split) return nullptr;
     for (int pass = 0; pass < 2; pass++)
         for (const RegwEntry &e : kRegw)
             if (e.M[0] == sh.M[0] && e.M[1] == sh.M[1] && e.M[2] == sh.M[2] && e.M[3] == sh.M[3] && e.dbl == sh.dbl &&
-                e.nc8 == (pass ? 0 : sh.nc8))
+                e.nc8 == (pass ? 0 : sh.nc8) && regw_lds_bytes(e) <= 160u * 1024u)
                 return &e;
     return nullptr;
 }

@@ -139,7 +139,8 @@ BNM_API int bnm_ctx_get_path(const bnm_ctx *c);   /* the path AUTO resolved to *
 /* Tuning knobs of the fused kernel: variant id (0 direct loads, 1 LDS-DMA, 2 LDS-DMA with two tiles in flight,
  * 3 two tiles per wavefront per iteration with a fixed stride, 4 the generic kernel (any widths), 5 as 3 with the CU's waves
  * sharing an LDS work counter, 6 as 3 with batches from the device-wide work counter (default where instantiated), 7 / 8 the
- * generic kernel with one / two image tiles per wave forced; -1 keeps the current one) and grid size
+ * generic kernel with one / two image tiles per wave forced, 9 the register-resident-weight kernel of the 96..128-wide shapes
+ * (one wave per SIMD; opt-in); -1 keeps the current one) and grid size
  * (workgroups; 0 = default).  BNM_EUNSUPPORTED if the model's shape has no such instantiation. */
 BNM_API int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks);
 /* the fused-kernel variant in use, or -1 when the resolved path is not the fused kernel */

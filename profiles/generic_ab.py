@@ -42,7 +42,7 @@ def main():
         model = b.Model.from_zoo(name)
         arms = {}
         ctxs = {}
-        for label, variant in (("default", -1), ("generic_t1", 7), ("generic_t2", 8)):
+        for label, variant in (("default", -1), ("generic_t1", 7), ("generic_t2", 8), ("regw", 9)):
             for wb in [int(v) for v in a.batches.split(",")]:
                 ctx = b.Context(model)
                 try:

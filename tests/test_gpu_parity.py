@@ -754,6 +754,62 @@ def test_random_shapes_through_the_generic_fused_kernel(codecs, widths, n_classe
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["tern_96", "tern_96_sparse", "doc12k_2bit", "doc12k_ternary"])
+def test_register_resident_weight_kernel(name, gpu_ok, orc):
+    """Variant 9 (bnm_fused_regw.hip: weight fragments in AccVGPRs at one wave per SIMD, hand-pipelined dual-tile loop with asm
+    MFMAs; opt-in) on the shapes it is instantiated for - all fragments in registers (96-96-96, 112-96-96) and the hybrid with the
+    classifier's fragments in LDS (128-128-112): class ids and logits == oracle on device-resident images, ragged ends
+    (the last < 64 images go to the generic kernel), calls too small for the kernel (all of it goes there), ids-only calls,
+    the ReLUNorm extremes; == the generic kernel on every one of a million images."""
+    model = b.Model.from_zoo(name)
+    om = util.OracleModel(model, orc)
+    ctx = b.Context(model)
+    ctx.set_tuning(variant=9)
+    assert ctx.variant == 9 and ctx.path == b.PATH_FUSED_MFMA
+    for n in (1, 63, 64, 65, 4097, 65536 + 37, 3 * 65536 + 64 * 5 + 1):
+        x = np.concatenate([synth.images(7, n, DIST_U)[: (n + 1) // 2], synth.images(7, n, DIST_M)[: n // 2]])
+        m = min(n, 70_000)
+        want = om.infer(x[:m], logits=True)
+        got = ctx.infer(x, logits=True)
+        assert np.array_equal(got[0][:m], want[0]) and np.array_equal(got[1][:m], want[1]), (name, n)
+        assert np.array_equal(ctx.infer(x), got[0])           # class ids only (no logits buffer)
+        if n > m:                                             # the tail of the big batches: head of the reversed batch
+            xr = np.ascontiguousarray(x[::-1])
+            gr = ctx.infer(xr, logits=True)
+            assert np.array_equal(gr[0][::-1], got[0]) and np.array_equal(gr[1][::-1], got[1]), (name, n, "order dependence")
+            wt = om.infer(x[-20_000:], logits=True)
+            assert np.array_equal(got[0][-20_000:], wt[0]) and np.array_equal(got[1][-20_000:], wt[1]), (name, n, "tail")
+    edge = np.concatenate([np.zeros((64, 256), np.int8), np.full((64, 256), -128, np.int8), np.full((64, 256), 127, np.int8)] * 400)
+    got, want = ctx.infer(edge, logits=True), om.infer(edge[:192], logits=True)
+    assert np.array_equal(got[0][:192], want[0]) and np.array_equal(got[1][:192], want[1])
+    assert np.array_equal(got[0].reshape(400, 192), np.tile(want[0], (400, 1)))
+    # against the generic kernel on a million images
+    import torch
+    n = 1_000_000 + 77
+    x = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+    b.synth.fill_device(x, first=5, dist=DIST_U)
+    out = {}
+    for variant in (9, 4):
+        ctx.set_tuning(variant=variant)
+        cls = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        lg = torch.full((n, model.num_classes), -7, dtype=torch.int32, device="cuda")
+        ctx.infer_device(x, cls, lg)
+        torch.cuda.synchronize()
+        out[variant] = (cls.cpu().numpy(), lg.cpu().numpy())
+    assert np.array_equal(out[9][0], out[4][0]) and np.array_equal(out[9][1], out[4][1])
+    ctx.close()
+
+
+def test_register_resident_weight_kernel_is_refused_for_other_shapes(gpu_ok):
+    for name in ("fc_4bitsym_64", "doc12k_binary", "cnn_64"):
+        ctx = b.Context(b.Model.from_zoo(name))
+        before = ctx.variant
+        with pytest.raises(b.BnmError):
+            ctx.set_tuning(variant=9)
+        assert ctx.variant == before
+        ctx.close()
+
+
 @pytest.mark.parametrize("C,codecs,widths,n_classes", [
     (24, (2, 4, 4), (96, 64), 10),      # 96-byte act rows -> padded to 128
     (40, (4, 4, 4), (64, 32), 10),      # 160 -> 256
