@@ -36,6 +36,10 @@ BYTES_PER_INFERENCE_LOGITS_10 = 300
 # VALU issue roofline: one wave64 VALU instruction occupies its SIMD for 4 cycles (measured: SQ_ACTIVE_INST_VALU =
 # 4.0 cycles per instruction, profiles/r01/rocprof_r01f_ternary_cnn.md); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
 VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.0
+# dense int8 matrix-core peak in units of the instruction the kernels use: one v_mfma_i32_32x32x32_i8 (65,536 int8 ops) occupies
+# a SIMD's matrix core for 8 passes = 32 clocks -> 1024 SIMDs x 2.4 GHz / 32 = 7.68e10 per second = 5.03 Pop/s, the ~5 PF dense
+# figure of MI355X_MICROARCH.md's MFMA table (I8 runs at twice the BF16 rate); profiles/energy_probe.py measured 7.5e10/s
+MFMA_I8_32X32X32_PEAK_PER_S = 1024 * 2.4e9 / 32.0
 MACS_PER_WAVE_DOT4 = 4 * 64    # one wave64 v_dot4_i32_i8: 4 MACs per lane
 # the oracle's digest / histogram of ALL 1e8 class ids of the headline workload (fc_4bitsym_64, Dist-U, first image 0),
 # computed on the host cores by tests/test_gpu_fullsize.py::test_full_1e8_digest_and_histogram_equal_the_oracle
@@ -101,25 +105,95 @@ def cpu_baseline(b, model_name, dist, seconds):
             "sample": f"{sum(done)} inferences in {el:.1f} s: oracle/bitnet_oracle.c on {cores} threads"}
 
 
-def load_counters():
+def load_counters(lib_path=None):
     """Per-kernel constants measured with rocprofv3 --pmc in separate passes (profiles/pmc_kernel.sh ->
-    profiles/pmc_counters.json, pmc_traffic.json): HBM bytes per launch, VALU instructions per image.  They are properties
-    of the kernel binaries; bench.py REPLAYS them next to its live timing and says so in every field it fills from here."""
-    out = {}
+    profiles/pmc_counters.json, pmc_traffic.json): HBM bytes per launch, VALU instructions per image, matrix-core busy share.
+    They are properties of ONE kernel binary; bench.py REPLAYS them next to its live timing and says so in every field it fills
+    from here.  Every entry carries the machine-code hash of its kernel at measurement time ("code_sha1", written by
+    profiles/make_counters_json.py from bitnetmcu_amd/codeobj.py); an entry whose kernel is absent from the loaded library or
+    hashes differently there describes another binary and is DROPPED (listed under out["dropped"])."""
+    out = {"dropped": []}
+    hashes = None
+    if lib_path and os.path.isfile(lib_path):
+        try:
+            from bitnetmcu_amd import codeobj
+            hashes = codeobj.kernel_hashes(lib_path)
+        except Exception as e:      # an unreadable library image: nothing can be validated, nothing is replayed
+            out["dropped"].append(f"all entries: cannot fingerprint {lib_path}: {e}")
+            return out
+
+    def valid(key, e):
+        if hashes is None:
+            out["dropped"].append(f"{key}: no library to validate against")
+            return False
+        want, name = e.get("code_sha1"), e.get("mangled")
+        if not want or not name:
+            out["dropped"].append(f"{key}: entry carries no code hash (measured before round 4)")
+            return False
+        if hashes.get(name) != want:
+            out["dropped"].append(f"{key}: kernel {e.get('kernel')} is {'absent from' if name not in hashes else 'a different binary in'} the loaded library")
+            return False
+        return True
+
     for name in ("pmc_traffic.json", "pmc_counters.json"):
         p = os.path.join(REPO, "profiles", name)
-        if os.path.isfile(p):
-            try:
-                out[name] = json.load(open(p))
-            except Exception:
-                pass
+        if not os.path.isfile(p):
+            continue
+        try:
+            j = json.load(open(p))
+        except Exception:
+            continue
+        if name == "pmc_traffic.json":
+            if valid(name, j):
+                out[name] = j
+        else:
+            out[name] = {k: e for k, e in j.items() if valid(f"{name}:{k}", e)}
     return out
+
+
+def model_mfmas_per_image(b, model):
+    """v_mfma_i32_32x32x32_i8 instructions per image of the fused MFMA kernels, from the model's shape alone: a layer of
+    ceil(n_out / 32) row tiles over ceil(K / 32) K-steps (K = the previous layer's outputs; 256, or 4 x channels behind the CNN
+    front end, for the first) is tiles x K-steps MFMAs per tile of 32 images - twice that when the model holds an FP1.3.0 +128
+    (second weight plane).  FC stack only: the CNN front end's conv1 MFMAs are not in this count."""
+    k = 4 * model.layer(0).out_channels if model.kind == b.KIND_CNN else 256
+    total, planes = 0, 1
+    for i, li in model.fc_layers():
+        total += ((li.n_output + 31) // 32) * ((k + 31) // 32)
+        k = li.n_output
+        if li.bits_per_weight == 20:
+            w = model.layer_weights(i)
+            if any((((w >> (4 * nib)) & 15) == 7).any() for nib in range(8)):
+                planes = 2
+    return planes * total / 32.0
+
+
+def mfma_roofline(b, ctx, model, rate, kname, counters, model_key=None):
+    """north_star: "for the MFMA path, int8 MFMA utilisation vs gfx950 peak".  Static instruction count x measured rate against
+    the dense int8 peak, next to the matrix cores' busy share from the counter pass of the same kernel binary (replayed, tagged).
+    None when the timed path is not an MFMA kernel."""
+    if ctx.path != b.PATH_FUSED_MFMA:
+        return None
+    per_image = model_mfmas_per_image(b, model)
+    r = {"instruction": "v_mfma_i32_32x32x32_i8", "per_image": per_image, "achieved_per_s": rate * per_image,
+         "peak_per_s": MFMA_I8_32X32X32_PEAK_PER_S, "frac": rate * per_image / MFMA_I8_32X32X32_PEAK_PER_S,
+         "int8_ops_per_s": rate * per_image * 65536.0,
+         "definition": "MFMAs per image (from the model's tile counts) x inferences/s / (1024 SIMDs x 2.4 GHz / 32 clocks per MFMA)"}
+    cj = counters.get("pmc_counters.json", {})
+    base = kname.split("+")[0]
+    c = (cj.get(f"{base}@{model_key}") if model_key else None) or cj.get(base)
+    if c and "mfma_busy_frac" in c:
+        r["busy_frac"] = c["mfma_busy_frac"]
+        r["busy_frac_source"] = (f"SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of {c.get('kernel')}, replayed from "
+                                 f"profiles/pmc_counters.json (rocprofv3 --pmc pass {c.get('source')}, at that pass's clock; same kernel binary: "
+                                 f"code_sha1 {c.get('code_sha1', '')[:12]}); not measured by this run")
+    return r
 
 
 def kernel_name(b, ctx, model):
     v = ctx.variant
     fused = {3: "fused_fc_dual_kernel", 5: "fused_fc_dual_kernel", 6: "fused_fc_dual_kernel", 4: "fused_fc_generic_kernel", 7: "fused_fc_generic_kernel",
-             8: "fused_fc_generic_kernel"}.get(v, "fused_fc_kernel")
+             8: "fused_fc_generic_kernel", 9: "fused_fc_regw_kernel"}.get(v, "fused_fc_kernel")
     # the streamed kernel is the default for every shape of the ALU table (two images per lane for 96-96-96, one for the others);
     # variant 0 selects the plain ALU kernel
     tern = "ternary_stream_kernel" if getattr(ctx, "ternary_variant", 2) % 10 else "ternary_alu_kernel"
@@ -323,7 +397,7 @@ def main():
             verified = verified and int(dg[0].astype(np.uint64)) == ORACLE_DIGEST_1E8
 
     if rank == 0:
-        counters = load_counters()
+        counters = load_counters(b.LIB_PATH)
         total = n_global * a.steps
         bpi = 256 + 4 + (4 * model.num_classes if a.logits else 0)
         avg_ms = float(np.mean(launch_ms))
@@ -337,7 +411,7 @@ def main():
                        "what": "plain nontemporal 16 B/lane loads of this rank's resident images, nothing written; median of 5 launches after 2"}
         traffic, traffic_source = None, None
         tj = counters.get("pmc_traffic.json")
-        if tj and headline and world == 1 and not a.logits and kname == tj.get("kernel", "fused_fc_dual_kernel"):
+        if tj and headline and world == 1 and not a.logits and tj.get("kernel", "").startswith(kname):
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = f"replayed from profiles/pmc_traffic.json (rocprofv3 --pmc pass {tj.get('source')}; not measured by this run)"
         out = {
@@ -381,6 +455,8 @@ def main():
                 "min_launch_ms": float(np.min(launch_ms)),
                 "algorithmic_bytes_per_launch": n * bpi,
                 "fused_variant": ctx.variant,
+                "mfma": mfma_roofline(b, ctx, model, total / elapsed, kname, counters),
+                "counters_dropped": counters.get("dropped") or None,
                 "stream_read": stream_read,
                 # > 1: the kernel takes longer than merely reading its input on this box
                 "time_vs_stream_read": float(np.median(launch_ms)) / rd,
@@ -447,7 +523,8 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         res[name] = {"model": model_name, "images": count, "dist": "U" if dist == 0 else "M", "steps": steps, "warmup": warmup,
                      "value": rate, "unit": "inferences/s", "avg_launch_ms": float(np.mean(ms)), "median_launch_ms": float(np.median(ms)),
                      "min_launch_ms": float(np.min(ms)),
-                     "kernel": kernel_name(b, ctx, model), "path": ctx.path, "fused_variant": ctx.variant, "verified_vs_oracle": ok}
+                     "kernel": kernel_name(b, ctx, model), "path": ctx.path, "fused_variant": ctx.variant, "verified_vs_oracle": ok,
+                     "mfma_per_image": model_mfmas_per_image(b, model) if ctx.path == b.PATH_FUSED_MFMA else None}
         if note:
             res[name]["note"] = note
         ctx.close()
@@ -458,6 +535,10 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         g = rate * bpi / 1e9
         res[name]["roofline"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
                                  "time_vs_stream_read": res[name]["avg_launch_ms"] / (res[name]["images"] * 256 / rd_rate / 1e6)}
+        if res[name].get("mfma_per_image"):
+            per = res[name].pop("mfma_per_image")
+            res[name]["roofline"]["mfma"] = {"per_image": per, "achieved_per_s": rate * per, "peak_per_s": MFMA_I8_32X32X32_PEAK_PER_S,
+                                             "frac": rate * per / MFMA_I8_32X32X32_PEAK_PER_S}
 
     n_cnn = min(n, 10_000_000)
     # configs[2]: ternary 96-96-96, bit-unpack / sign-accumulate ALU kernel, no MFMA — bound by the VALU issue rate
@@ -495,6 +576,8 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         torch.cuda.synchronize()
         r, _ = run("fc_dist_m", "fc_4bitsym_64", n, 10, 3, dist=1)
         hbm_entry("fc_dist_m", r, BYTES_PER_INFERENCE)
+    for e in res.values():
+        e.pop("mfma_per_image", None)      # (consumed by hbm_entry on the MFMA rows)
     return res
 
 

@@ -299,6 +299,31 @@ int work_blocks_grow(bnm_ctx *c) {
     return BNM_OK;
 }
 
+// Key of a stream in the per-stream tables.  Launches that share a key share a counter block and scratch buffers and must be
+// ordered among themselves - true for a real stream handle, NOT for hipStreamPerThread: that is one constant handle value which
+// names a different stream in every host thread, so its key is the address of a thread-local object (one entry per calling thread).
+// tokens made by stream_key() are addresses of thread-local bytes, real handles come from the runtime: the context remembers
+// which keys are tokens
+std::mutex g_token_mu;
+std::vector<const void *> g_tokens;
+bool c_is_stream_handle(hipStream_t key) {
+    std::lock_guard<std::mutex> g(g_token_mu);
+    for (const void *t : g_tokens)
+        if (t == (const void *)key) return false;
+    return true;
+}
+hipStream_t stream_key(hipStream_t s) {
+    static thread_local char per_thread_key;
+    static thread_local bool registered = false;
+    if (s != hipStreamPerThread) return s;
+    if (!registered) {
+        std::lock_guard<std::mutex> g(g_token_mu);
+        g_tokens.push_back(&per_thread_key);
+        registered = true;
+    }
+    return (hipStream_t)(void *)&per_thread_key;
+}
+
 bool stream_is_capturing(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess) {
@@ -313,10 +338,12 @@ bool stream_is_capturing(hipStream_t s) {
 // that cycles through short-lived streams would otherwise grow them without bound) - never while `keep` is capturing.
 void evict_other_streams(bnm_ctx *c, hipStream_t keep) {
     // a device-wide synchronisation would invalidate a stream capture in progress: not while any stream the context knows captures
+    // (keys are stream handles or, for hipStreamPerThread, per-thread tokens - only the former can be asked)
+    auto capturing = [](hipStream_t key) { return c_is_stream_handle(key) && stream_is_capturing(key); };
     for (auto &kv : c->scratch)
-        if (stream_is_capturing(kv.first)) return;
+        if (capturing(kv.first)) return;
     for (auto &kv : c->work_of)
-        if (stream_is_capturing(kv.first)) return;
+        if (capturing(kv.first)) return;
     if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return; }
     for (auto it = c->scratch.begin(); it != c->scratch.end();) {
         if (it->first == keep) { ++it; continue; }
@@ -325,14 +352,18 @@ void evict_other_streams(bnm_ctx *c, hipStream_t keep) {
     }
     for (auto it = c->work_of.begin(); it != c->work_of.end();) {
         if (it->first == keep) { ++it; continue; }
+        // a block is all zero when its last launch left normally; one that did not (a launch that failed half-way) must not
+        // poison the block's next owner: the device is idle here, so zero it on the way back to the free list
+        (void)hipMemset(it->second, 0, sizeof(uint32_t) * BNM_WORK_BLOCK_WORDS);
         c->work_free.push_back(it->second);
         it = c->work_of.erase(it);
     }
 }
 
 // the counter block of a launch on stream s (see bnm_ctx)
-int work_block(bnm_ctx *c, hipStream_t s, uint32_t **out) {
-    const bool capturing = stream_is_capturing(s);
+int work_block(bnm_ctx *c, hipStream_t s_real, uint32_t **out) {
+    const bool capturing = stream_is_capturing(s_real);
+    const hipStream_t s = stream_key(s_real);
     if (!capturing) {
         auto it = c->work_of.find(s);
         if (it != c->work_of.end()) { *out = it->second; return BNM_OK; }
@@ -351,10 +382,11 @@ int work_block(bnm_ctx *c, hipStream_t s, uint32_t **out) {
     return BNM_OK;
 }
 
-bnm_ctx::StreamScratch &stream_scratch(bnm_ctx *c, hipStream_t s) {
+bnm_ctx::StreamScratch &stream_scratch(bnm_ctx *c, hipStream_t s_real) {
+    const hipStream_t s = stream_key(s_real);
     auto it = c->scratch.find(s);
     if (it != c->scratch.end()) return it->second;
-    if (c->scratch.size() >= kMaxStreams && !stream_is_capturing(s)) evict_other_streams(c, s);
+    if (c->scratch.size() >= kMaxStreams && !stream_is_capturing(s_real)) evict_other_streams(c, s);
     return c->scratch[s];
 }
 
@@ -611,7 +643,8 @@ int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32
 
 // FC chain layer by layer on [n][in_stride] int8 inputs; n <= kChunk.  mfma: the layers as int8 GEMMs on the matrix cores
 // (bnmk_fc_layer_mfma; activation rows padded to 32-byte K-steps) instead of the bit-serial kernel.
-int run_layerwise(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32_t *d_logits, int8_t *d_acts_tap,
+// in_stride: bytes between consecutive input rows (256 for FC models; the CNN front end's act-row stride)
+int run_layerwise(bnm_ctx *c, const int8_t *d_in, uint32_t in_stride, uint64_t n, uint32_t *d_cls, int32_t *d_logits, int8_t *d_acts_tap,
                   uint32_t tap_stride, uint32_t tap_off, bool mfma, hipStream_t s) {
     uint32_t maxw = 0;
     for (auto &l : c->fc) maxw = l.info.n_output > maxw ? l.info.n_output : maxw;
@@ -621,7 +654,7 @@ int run_layerwise(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, i
     if (int e = sc.act_b.ensure((size_t)n * maxs + 64)) return e;
     if (int e = sc.out32.ensure((size_t)n * maxw * 4)) return e;
     const int8_t *act = d_in;
-    uint32_t act_stride = c->fc[0].act_stride;
+    uint32_t act_stride = in_stride;
     int8_t *bufs[2] = {(int8_t *)sc.act_a.p, (int8_t *)sc.act_b.p};
     for (size_t i = 0; i < c->fc.size(); i++) {
         const FcDev &d = c->fc[i];
@@ -679,7 +712,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         if (path == BNM_PATH_TERNARY_ALU) return run_ternary(c, d_images, n, d_cls, d_logits, s);
         for (uint64_t off = 0; off < n; off += kChunk) {
             uint64_t cn = n - off < kChunk ? n - off : kChunk;
-            if (int e = run_layerwise(c, d_images + off * 256, cn, d_cls + off, d_logits ? d_logits + off * ncls : nullptr,
+            if (int e = run_layerwise(c, d_images + off * 256, 256u, cn, d_cls + off, d_logits ? d_logits + off * ncls : nullptr,
                                       d_acts_tap ? d_acts_tap + off * tap_stride : nullptr, tap_stride, 0, path == BNM_PATH_LAYERWISE_MFMA, s))
                 return e;
         }
@@ -688,7 +721,10 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
     // CNN: front end (conv/pool/ReLUNorm fused) -> int8 [n][4C] -> FC tail
     const uint32_t W = c->channels * 4u;
     // act rows: 4*C bytes, padded to the generic kernel's row length when that kernel runs the FC tail
-    const uint32_t AS = (path == BNM_PATH_FUSED_MFMA && is_generic(c->variant)) ? c->gdesc.KT0 * 32u : W;
+    // (the layer-wise MFMA tail reads them in 32-byte K-steps with 16-byte loads: rows padded to a multiple of 32 - any channel
+    // count then works, also one that is not a multiple of 4; the bytes between 4C and the stride meet zero weights)
+    const uint32_t AS = (path == BNM_PATH_FUSED_MFMA && is_generic(c->variant)) ? c->gdesc.KT0 * 32u
+                        : path == BNM_PATH_LAYERWISE_MFMA ? round_up(W, 32) : W;
     // chunks: 2^22 images when the fused tail consumes the act rows directly (1 GiB of act rows; every launch has a ramp and a
     // tail, so fewer, larger launches: +2 % over 2^20), 2^20 when the int32 features are needed as well (> 64 channels, taps)
     // or the layer-wise tail runs (its scratch is sized for kChunk)
@@ -715,7 +751,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         if (path == BNM_PATH_FUSED_MFMA) {
             if (int e = run_fused(c, acts, cn, cls, lg, s)) return e;
         } else {
-            if (int e = run_layerwise(c, acts, cn, cls, lg, d_acts_tap ? d_acts_tap + off * tap_stride : nullptr, tap_stride,
+            if (int e = run_layerwise(c, acts, AS, cn, cls, lg, d_acts_tap ? d_acts_tap + off * tap_stride : nullptr, tap_stride,
                                       d_acts_tap ? W : 0, path == BNM_PATH_LAYERWISE_MFMA, s))
                 return e;
         }
@@ -915,8 +951,8 @@ int bnm_ctx_release_stream(bnm_ctx *c, void *stream) {
     std::lock_guard<std::mutex> g(c->mu);
     DeviceGuard dg(c->device);
     HIP_TRY(dg.err);
-    hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    hipStream_t s = stream_key((hipStream_t)stream);
     auto it = c->scratch.find(s);
     if (it != c->scratch.end()) {
         for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat, &it->second.q8}) b->release();

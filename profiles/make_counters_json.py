@@ -9,6 +9,23 @@ import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from bitnetmcu_amd import codeobj  # noqa: E402
+
+# every entry is stamped with the machine-code hash of its kernel in the library the counters were collected from (the in-tree
+# build, which is what travels to the GPU box): bench.py replays an entry only next to that same binary (bench.load_counters)
+LIB = os.environ.get("BNM_LIBRARY") or os.path.join(REPO, "bitnetmcu_amd", "libbitnetmcu_hip.so")
+HASHES = codeobj.kernel_hashes(LIB)
+
+
+def stamp(e):
+    ks = codeobj.find_kernels(HASHES, e["kernel"])
+    if len(ks) == 1:
+        e["mangled"], e["code_sha1"] = ks[0], HASHES[ks[0]]
+    else:
+        print("cannot stamp", e["kernel"], "->", ks)
+    return e
+
 
 
 def main():
@@ -30,7 +47,7 @@ def main():
             print("no kernel", name, "in", path)
             continue
         d = tab[key[0]]
-        e = {"source": tag, "kernel": key[0], "images_per_launch": images}
+        e = stamp({"source": tag, "kernel": key[0], "images_per_launch": images})
         if "SQ_INSTS_VALU" in d:
             e["valu_per_image"] = d["SQ_INSTS_VALU"] / images
         if "SQ_INSTS_MFMA" in d:
@@ -54,7 +71,8 @@ def main():
             wb = d.get("WRITE_SIZE", 0.0) * 1024
             e["hbm_bytes_per_launch"] = fb + wb
             if name.startswith("fused_fc_dual"):
-                json.dump({"hbm_bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb, "source": tag, "kernel": "fused_fc_dual_kernel",
+                json.dump({"hbm_bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb, "source": tag, "kernel": key[0],
+                           "mangled": e.get("mangled"), "code_sha1": e.get("code_sha1"),
                            "images_per_launch": images,
                            "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section: gfx950 reports half the bytes of 16 B/lane reads)"},
                           open(os.path.join(REPO, "profiles", "pmc_traffic.json"), "w"))

@@ -63,3 +63,35 @@ def test_profile_scripts_compile():
     for p in sorted(glob.glob(os.path.join(REPO, "profiles", "*.sh"))):
         r = subprocess.run(["bash", "-n", p], capture_output=True, text=True)
         assert r.returncode == 0, (p, r.stderr)
+
+
+def test_replayed_counters_are_tied_to_the_kernel_binaries_of_the_loaded_library(tmp_path, monkeypatch):
+    """bench.py replays per-kernel constants from separate counter passes (profiles/pmc_*.json).  Every entry carries the
+    machine-code hash of its kernel (bitnetmcu_amd/codeobj.py reads the gfx950 code objects out of the library image); an entry
+    is replayed only when the loaded library holds that very binary - otherwise it is dropped and listed."""
+    import json
+    import bench
+    from bitnetmcu_amd import codeobj, LIB_PATH
+    hashes = codeobj.kernel_hashes(LIB_PATH)
+    assert len(hashes) > 100 and all(len(h) == 40 for h in hashes.values())
+    dual = codeobj.find_kernels(hashes, "fused_fc_dual_kernel<2, 2, 2, 1, true, 2, 4, true>")
+    assert len(dual) == 1 and dual[0].startswith("_Z20fused_fc_dual_kernelILi2ELi2ELi2ELi1ELb1ELi2ELi4ELb1EE")
+    assert codeobj.find_kernels(hashes, "no_such_kernel<1>") == []
+    # the committed files against the in-tree library: the headline kernel's entries are live
+    c = bench.load_counters(LIB_PATH)
+    assert "fused_fc_dual_kernel" in c["pmc_counters.json"] and "pmc_traffic.json" in c
+    assert c["pmc_counters.json"]["fused_fc_dual_kernel"]["code_sha1"] == hashes[dual[0]]
+    # a tampered hash, a missing one and a kernel the library does not hold are dropped, each with its reason
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    good = dict(c["pmc_counters.json"]["fused_fc_dual_kernel"])
+    entries = {"good": good, "stale": dict(good, code_sha1="0" * 40), "unstamped": {k: v for k, v in good.items() if k not in ("code_sha1", "mangled")},
+               "gone": dict(good, mangled="_Z9not_thereILi1EEvv")}
+    (prof / "pmc_counters.json").write_text(json.dumps(entries))
+    (prof / "pmc_traffic.json").write_text(json.dumps(dict(good, code_sha1="1" * 40)))
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    c = bench.load_counters(LIB_PATH)
+    assert list(c["pmc_counters.json"]) == ["good"] and "pmc_traffic.json" not in c
+    text = " | ".join(c["dropped"])
+    assert "stale" in text and "unstamped" in text and "gone" in text and "pmc_traffic.json" in text and "different binary" in text
+    assert bench.load_counters(None)["pmc_counters.json"] == {}

@@ -500,6 +500,13 @@ def test_bench_json_contract(gpu_ok):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "stream_read", "time_vs_stream_read", "median_launch_ms"):
         assert k in d["roofline"]
     assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["stream_read"]["GB/s"] > 0
+    # north_star: int8 MFMA utilisation vs the gfx950 peak on the MFMA path - static count x measured rate, busy share replayed from
+    # a counter pass of the SAME kernel binary (code hash checked by bench.load_counters)
+    mf = d["roofline"]["mfma"]
+    assert mf["per_image"] == 26 / 32 and mf["peak_per_s"] == 1024 * 2.4e9 / 32
+    assert abs(mf["achieved_per_s"] - d["value"] * 26 / 32) < 1e-6 * mf["achieved_per_s"] and 0 < mf["frac"] < 1
+    assert 0 < mf["busy_frac"] < 1 and "code_sha1" in mf["busy_frac_source"]
+    assert d["roofline"]["traffic"] and "replayed" in d["roofline"]["traffic_source"]
     assert d["digest"].startswith("0x") and "header text" in d["config"]["model_source"]
     ex = d["extra_configs"]
     for k in ("ternary_alu", "ternary_mfma_generic", "cnn_64", "fc_generic_kernel", "fc_logits", "fc_dist_m", "doc12k_binary",
@@ -943,6 +950,9 @@ def test_fuzz_random_cnn_models(seed, gpu_ok, orc):
     C = 4 * int(rng.integers(1, 65 if wide else 25))
     codecs = tuple(int(c) for c in rng.choice([1, 2, 4, 12, 16, 64] if wide else [1, 2, 4, 12, 16], size=3))
     need = {1: 32, 2: 16, 4: 8, 12: 8, 16: 4, 64: 4}
+    if seed % 4 == 3:                        # any channel count, not only multiples of 4 (8-bit first FC layer: 4 C inputs always fit)
+        C = max(1, C - int(rng.integers(1, 4)))
+        codecs = (16,) + codecs[1:]
     if (4 * C) % need[codecs[0]]:
         codecs = (16,) + codecs[1:]          # 4 C act bytes are a multiple of 16: any codec but binary / 2-bit fits every C
     widths = tuple(int(rng.integers(1, 128 // need[codecs[k]] + 1)) * need[codecs[k]] for k in (1, 2))
@@ -1008,6 +1018,35 @@ def test_wide_cnn_tail_runs_layerwise_on_the_matrix_cores(C, codecs, gpu_ok, orc
             assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, cv, n)
         taps[cv] = ctx.activations(x[:100])
     assert np.array_equal(taps[1], taps[0]) and np.array_equal(taps[2], taps[0])
+    ctx.close()
+
+
+@pytest.mark.parametrize("C,codecs,widths", [(18, (16, 4, 4), (96, 64)),      # 72 act bytes: not a multiple of 16
+                                              (150, (16, 4, 4), (96, 64)),     # 600 act bytes: beyond the fused kernels, C % 4 = 2
+                                              (130, (16, 16, 4), (64, 32)),    # 520
+                                              (7, (16, 4, 4), (304, 64))])     # a 304-wide layer: beyond the fused kernels, 28 act bytes
+def test_cnn_channel_counts_that_are_not_multiples_of_four_on_every_tail(C, codecs, widths, gpu_ok, orc):
+    """the parser accepts any channel count 1..256 (an 8-bit first FC layer makes 4 C = 72 inputs exportable), and the
+    layer-wise MFMA tail reads act rows in 32-byte K-steps with 16-byte loads - its rows are padded to a multiple of 32 bytes now.
+    Every path the model can take, ids and logits vs the oracle."""
+    rng = np.random.default_rng(1000 + C)
+    model = b.Model.from_header_text(_random_cnn_text(rng, C, codecs, widths, 10))
+    om = util.OracleModel(model, orc)
+    x = np.concatenate([synth.images(C, 130, DIST_U), synth.images(C, 131, DIST_M)])
+    want = om.infer(x, logits=True)
+    ctx = b.Context(model)
+    auto = ctx.path
+    ran = []
+    for path in (b.PATH_AUTO, b.PATH_FUSED_MFMA, b.PATH_LAYERWISE_MFMA, b.PATH_LAYERWISE_ALU):
+        try:
+            ctx.set_path(path)
+        except b.BnmError:
+            continue
+        ran.append(ctx.path)
+        for n in (len(x), 1, 3):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, path, n)
+    assert b.PATH_LAYERWISE_MFMA in ran and b.PATH_LAYERWISE_ALU in ran and auto in ran
     ctx.close()
 
 
