@@ -506,7 +506,7 @@ def test_bench_json_contract(gpu_ok):
     assert mf["per_image"] == 26 / 32 and mf["peak_per_s"] == 1024 * 2.4e9 / 32
     assert abs(mf["achieved_per_s"] - d["value"] * 26 / 32) < 1e-6 * mf["achieved_per_s"] and 0 < mf["frac"] < 1
     assert 0 < mf["busy_frac"] < 1 and "code_sha1" in mf["busy_frac_source"]
-    assert d["roofline"]["traffic"] and "replayed" in d["roofline"]["traffic_source"]
+    assert d["roofline"]["traffic"] is None      # (replayed for the headline workload - 1e8 images - only)
     assert d["digest"].startswith("0x") and "header text" in d["config"]["model_source"]
     ex = d["extra_configs"]
     for k in ("ternary_alu", "ternary_mfma_generic", "cnn_64", "fc_generic_kernel", "fc_logits", "fc_dist_m", "doc12k_binary",
