@@ -281,11 +281,15 @@ BNM_API int bnm_stream_read_device(const void *d_src, uint64_t bytes, uint32_t *
  * Shards the global synthetic image stream [0, n_total) contiguously over the first n_gpus visible devices
  * (n_gpus <= 0: all), generates every shard on its own GPU, runs the whole-model path on all of them concurrently and
  * returns the combined order-independent digest + class histogram (digest_hist[0], digest_hist[1..n_bins]) and the
- * wall-clock seconds of the inference phase (one warm pass over all shards, after an untimed one).  No image byte crosses a link;
- * the model (~13 KB) is uploaded to each device by the host (PyTorch hosts broadcast it over RCCL instead, bench.py).
- * Returns the number of GPUs used (> 0) or a negative BNM_E* code. */
+ * wall-clock seconds of the inference phase (one warm pass over all shards, after an untimed one; the slowest GPU's time).
+ * One host thread and one single-process RCCL communicator per GPU: the model (~13 KB BNMBLOB) is uploaded to GPU 0 only and
+ * reaches the others through ncclBroadcast over xGMI, the digests meet in one ncclAllReduce; no image byte crosses a link.
+ * librccl is bound with dlopen at the first call (the library does not link it); where it cannot be loaded the host uploads the
+ * model to every GPU and sums the digests itself - bnm_multi_gpu_transport() names the transport of the calling thread's last
+ * call ("rccl" or "host").  Returns the number of GPUs used (> 0) or a negative BNM_E* code. */
 BNM_API int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, int dist, uint64_t seed,
                                     uint64_t *digest_hist, uint32_t n_bins, double *seconds);
+BNM_API const char *bnm_multi_gpu_transport(void);
 
 /* ---- model binding for group A ------------------------------------------------------------ */
 /* Bind the model that Inference()/BitMnistInference() run.  A `Bitnet_inf.dll` built by

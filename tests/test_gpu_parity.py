@@ -1149,6 +1149,17 @@ def test_c_abi_multi_gpu_entry_point(gpu_ok, bnm, orc):
     cls = util.OracleModel(model, orc).infer(synth.images(0, n, DIST_U))
     assert out[0] == synth.class_digest(cls, 0)
     assert list(out)[1:] == np.bincount(cls, minlength=10).tolist()
+    # the model went through ncclBroadcast (rank 0's BNMBLOB -> every rank's context is built from the received bytes) and the
+    # digests through ncclAllReduce: RCCL is loadable on the box, one rank = one communicator
+    assert bnm.bnm_multi_gpu_transport() == b"rccl"
+    # ... and without RCCL (BNM_NO_RCCL: the library never opens it) the host is the transport: same digest
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); import bitnetmcu_amd as b; L = b.load(); m = b.Model.from_zoo('fc_4bitsym_64');"
+            "out = (C.c_uint64 * 11)(); used = L.bnm_run_synth_multi_gpu(m._h, %d, 0, 0, b.SEED_DIST_U, out, 10, None);"
+            "print(used, L.bnm_multi_gpu_transport().decode(), out[0], sum(list(out)[1:]))" % (util.REPO, n))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, BNM_NO_RCCL="1"))
+    assert r.stdout.split() == [str(used), "host", str(out[0]), str(n)], (r.stdout, r.stderr[-2000:])
     # asking for more GPUs than exist uses what is there; bad arguments are errors, not crashes
     assert bnm.bnm_run_synth_multi_gpu(model._h, 1000, 64, DIST_U, b.SEED_DIST_U, out, 10, None) == used
     assert bnm.bnm_run_synth_multi_gpu(model._h, 1000, 1, 7, b.SEED_DIST_U, out, 10, None) < 0
