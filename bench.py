@@ -377,9 +377,13 @@ def main():
 
     elapsed, launch_ms = timed_steps(torch, lambda: ctx.infer_device(images, cls, logits), a.steps, a.warmup, barrier)
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own time for the K steps, gathered: the line reports the MAX (the contract) and the list, so that a
+        # straggler GPU is visible in the one line
+        mine = torch.tensor([elapsed, float(np.mean(launch_ms))], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        td.all_gather(every, mine)
+        per_rank = [[float(x[0].item()), float(x[1].item())] for x in every]
+        elapsed = max(x[0] for x in per_rank)
 
     # ---- outside the timed region: verification ----------------------------------------------------------
     verified = None
@@ -423,6 +427,8 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
+            "per_rank_ms_per_step": ([x[0] / a.steps * 1e3 for x in per_rank] if distributed else None),
+            "per_rank_kernel_ms": ([x[1] for x in per_rank] if distributed else None),
             "higher_is_better": True,
             "scaling": a.scaling,
             "vs_baseline": None,

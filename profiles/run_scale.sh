@@ -1,0 +1,59 @@
+#!/bin/bash
+# BASELINE configs[4] in one command, ON A MULTI-GPU NODE (never measured so far: every box this repository has seen had one GPU):
+# the headline model on N = 1, 2, 4, 8 GPUs (as many as the node has), one rank per GPU over RCCL,
+#   weak   scaling: 10^8 images PER GPU (each rank's shard is the single-GPU workload)
+#   strong scaling: 10^8 images IN TOTAL, split into contiguous shards
+# and the single-process C entry point (one host thread + one RCCL communicator per GPU, bnm_run_synth_multi_gpu).
+# Output: one bench.py JSON line per run in gpurun_out/scale/{weak,strong}_N.json and a table on stdout; per-rank times are in
+# every line (per_rank_ms_per_step), so a straggler GPU shows.  usage: profiles/run_scale.sh [steps] [warmup]
+set -u
+STEPS=${1:-20}; WARM=${2:-3}
+REPO=$(cd "$(dirname "$0")/.." && pwd); OUT=$REPO/gpurun_out/scale; mkdir -p "$OUT"; cd "$REPO"
+NGPU=$(python - <<'PY'
+import torch
+print(torch.cuda.device_count())
+PY
+)
+echo "GPUs visible: $NGPU"
+PORT=29517
+for N in 1 2 4 8; do
+  [ "$N" -le "$NGPU" ] || continue
+  for MODE in weak strong; do
+    if [ "$N" -eq 1 ]; then
+      python bench.py --gpus 1 --steps "$STEPS" --warmup "$WARM" --scaling $MODE --no-extra --no-cpu > "$OUT/${MODE}_$N.json" 2> "$OUT/${MODE}_$N.err"
+    else
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $PORT bench.py \
+        --gpus "$N" --steps "$STEPS" --warmup "$WARM" --scaling $MODE > "$OUT/${MODE}_$N.json" 2> "$OUT/${MODE}_$N.err"
+      PORT=$((PORT + 1))
+    fi
+  done
+done
+python - "$OUT" <<'PY'
+import glob, json, os, sys
+rows = {}
+for f in sorted(glob.glob(os.path.join(sys.argv[1], "*_*.json"))):
+    lines = [l for l in open(f) if l.startswith("{")]
+    if not lines:
+        print("no JSON line in", f); continue
+    d = json.loads(lines[-1])
+    rows[(d["scaling"], d["n_gpus"])] = d
+print("| scaling | GPUs | inferences/s | ms per step (slowest rank) | per-rank ms | vs 1 GPU | of 8 TB/s per GPU | digest ok |")
+print("|---|---|---|---|---|---|---|---|")
+for (mode, n), d in sorted(rows.items()):
+    one = rows.get((mode, 1))
+    eff = d["value"] / (one["value"] * (n if mode == "weak" else n)) if one else float("nan")
+    pr = d.get("per_rank_ms_per_step") or [d["ms_per_step"]]
+    print(f"| {mode} | {n} | {d['value']:.4g} | {d['ms_per_step']:.3f} | {' '.join('%.3f' % x for x in pr)} | {eff:.3f} | "
+          f"{d['value'] * 260 / n / 8e12:.3f} | {d.get('verified_vs_oracle')} |")
+PY
+# the C host's entry point on all GPUs (RCCL bound at run time)
+python - <<'PY'
+import ctypes as C
+import bitnetmcu_amd as b
+L = b.load()
+m = b.Model.from_zoo("fc_4bitsym_64")
+out = (C.c_uint64 * 11)(); secs = C.c_double()
+used = L.bnm_run_synth_multi_gpu(m._h, 100_000_000, 0, 0, b.SEED_DIST_U, out, 10, C.byref(secs))
+print(f"bnm_run_synth_multi_gpu: {used} GPU(s), transport {L.bnm_multi_gpu_transport().decode()}, 1e8 images in {secs.value * 1e3:.3f} ms "
+      f"= {1e8 / secs.value:.4g} inferences/s, digest {hex(out[0])} (oracle: 0x81b56c9fafee6636)")
+PY

@@ -1115,6 +1115,9 @@ def test_bench_launches_its_own_ranks_two_ranks_share_the_gpu(gpu_ok):
     assert d["config"]["images_per_gpu"] == n // 2 and d["config"]["dist_backend"] == "gloo" and d["config"]["ranks_share_device"] is True
     assert d["config"]["rccl_ranks"] is None and "extra_configs" not in d
     assert d["verified_vs_oracle"] is True and sum(d["class_histogram"]) == n
+    # every rank's own time is in the line; the reported time is the slowest rank's
+    assert len(d["per_rank_ms_per_step"]) == 2 and abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) < 1e-9
+    assert len(d["per_rank_kernel_ms"]) == 2 and all(0 < k <= t * 1.001 for k, t in zip(d["per_rank_kernel_ms"], d["per_rank_ms_per_step"]))
     if n == 100_000_000:
         assert int(d["digest"], 16) == 0x81b56c9fafee6636 == int(d["digest_expected"], 16)
 
