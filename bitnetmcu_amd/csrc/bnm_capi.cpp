@@ -1463,7 +1463,38 @@ namespace {
 
 std::mutex g_mu;
 bnm_ctx *g_default = nullptr;
-DevBuf g_sa, g_sw, g_so, g_sb, g_sarg;   // scratch of the per-function host ABI
+// Scratch of the per-function host ABI.  A call is ONE kernel launch and ONE stream synchronisation: the caller's arrays go
+// through page-locked buffers that the GPU addresses directly (a memcpy on the host, no hipMemcpy), the kernel reads its inputs
+// and writes its results over PCIe, and weight arrays stay on the device between calls (g_weights): a layer-by-layer host calls
+// processfclayer with the same array for every image.  (Round 3's form - three or four synchronous hipMemcpy per call, the weight
+// array among them - cost 45-60 us per call; DESIGN.md 6 has the measured flow of examples/mnist_test.c.)
+PinBuf g_pin_in, g_pin_out, g_pin_arg;
+hipStream_t g_sym_stream = nullptr;
+struct WeightKey {
+    const void *ptr;
+    size_t bytes;
+    uint64_t hash;
+    bool operator<(const WeightKey &o) const { return ptr != o.ptr ? ptr < o.ptr : bytes != o.bytes ? bytes < o.bytes : hash < o.hash; }
+};
+struct WeightEntry {
+    void *dev = nullptr;
+    uint32_t n_act = 0;      // ternary layers: highest activation index a trit can touch + 1
+};
+std::map<WeightKey, WeightEntry> g_weights;
+constexpr size_t kMaxCachedWeightArrays = 1024;      // (a 64-channel CNN host presents 3 x 64 nine-byte kernels + 3 FC arrays)
+
+uint64_t content_hash(const void *p, size_t bytes) {      // FNV-1a over 8-byte words (+ tail bytes): ~2 us for a 12 KB array
+    const uint8_t *b = (const uint8_t *)p;
+    uint64_t h = 0xcbf29ce484222325ull;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0x100000001b3ull;
+    }
+    for (; i < bytes; i++) h = (h ^ b[i]) * 0x100000001b3ull;
+    return h;
+}
 
 // The kernel symbols keep their scratch buffers on ONE device - the calling thread's current device at their first use - and run
 // there whatever the current device is later (a host that switches devices between calls must not mix buffers and launches).
@@ -1510,6 +1541,27 @@ uint32_t ternary_used_inputs(const uint16_t *w, uint32_t n_input, uint32_t n_out
     return used;
 }
 
+// The device-resident copy of a host weight array: keyed by address, length AND content (a host may reuse a buffer for other
+// weights), uploaded once.  compute_n_act: called on a miss only (the ternary scan is O(weights)).
+template <class F>
+const WeightEntry *cached_weights(const void *host, size_t bytes, F compute_n_act) {
+    const WeightKey key{host, bytes, content_hash(host, bytes)};
+    auto it = g_weights.find(key);
+    if (it != g_weights.end()) return &it->second;
+    if (g_weights.size() >= kMaxCachedWeightArrays) {
+        (void)hipStreamSynchronize(g_sym_stream);
+        for (auto &kv : g_weights) (void)hipFree(kv.second.dev);
+        g_weights.clear();
+    }
+    WeightEntry e;
+    if (hipMalloc(&e.dev, bytes + 16) != hipSuccess || hipMemcpy(e.dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    e.n_act = compute_n_act();
+    return &(g_weights[key] = e);
+}
+bool sym_stream_ready() {
+    return g_sym_stream || hipStreamCreateWithFlags(&g_sym_stream, hipStreamNonBlocking) == hipSuccess;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1546,30 +1598,33 @@ void processfclayer(int8_t *activations, const uint32_t *weights, int32_t bpw, u
         std::memset(output, 0, sizeof(int32_t) * n_output);
         return;
     }
-    uint32_t n_act = bpw == 64 ? ternary_used_inputs((const uint16_t *)weights, n_input, n_output) : n_input;
-    size_t wbytes = (size_t)cnt * (bpw == 64 ? 2 : 4);
-    uint32_t stride = n_act ? n_act : 1;
-    if (g_sa.ensure(stride + 16) || g_sw.ensure(wbytes + 16) || g_so.ensure((size_t)n_output * 4)) die("processfclayer");
-    bool ok = hipMemcpy(g_sw.p, weights, wbytes, hipMemcpyHostToDevice) == hipSuccess;
-    if (n_act) ok = ok && hipMemcpy(g_sa.p, activations, n_act, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && bnmk_fc_layer((const int8_t *)g_sa.p, stride, g_sw.p, bpw, n_input, n_output, (int32_t *)g_so.p, 1, nullptr) == hipSuccess;
-    ok = ok && hipMemcpy(output, g_so.p, (size_t)n_output * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    const size_t wbytes = (size_t)cnt * (bpw == 64 ? 2 : 4);
+    if (!sym_stream_ready()) die("processfclayer");
+    const WeightEntry *w = cached_weights(weights, wbytes, [&] {
+        return bpw == 64 ? ternary_used_inputs((const uint16_t *)weights, n_input, n_output) : n_input;
+    });
+    if (!w) { g_err = hipGetErrorString(hipGetLastError()); die("processfclayer"); }
+    const uint32_t n_act = w->n_act, stride = n_act ? n_act : 1;
+    if (g_pin_in.ensure(stride + 16) || g_pin_out.ensure((size_t)n_output * 4)) die("processfclayer");
+    if (n_act) std::memcpy(g_pin_in.host, activations, n_act);
+    bool ok = bnmk_fc_layer((const int8_t *)g_pin_in.dev, stride, w->dev, bpw, n_input, n_output, (int32_t *)g_pin_out.dev, 1, g_sym_stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(g_sym_stream) == hipSuccess;
     if (!ok) { g_err = hipGetErrorString(hipGetLastError()); die("processfclayer"); }
+    std::memcpy(output, g_pin_out.host, (size_t)n_output * 4);
 }
 
 uint32_t ReLUNorm(int32_t *input, int8_t *output, uint32_t n_input) {
     std::lock_guard<std::mutex> g(g_mu);
     DeviceGuard dg(sym_device());
     if (!n_input) return 255;
-    if (g_so.ensure((size_t)n_input * 4) || g_sb.ensure(n_input) || g_sarg.ensure(4)) die("ReLUNorm");
-    uint32_t pos = 255;
-    bool ok = hipMemcpy(g_so.p, input, (size_t)n_input * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && bnmk_relunorm((const int32_t *)g_so.p, n_input, (int8_t *)g_sb.p, n_input, (uint32_t *)g_sarg.p, 1, nullptr) == hipSuccess;
-    ok = ok && hipMemcpy(&pos, g_sarg.p, 4, hipMemcpyDeviceToHost) == hipSuccess;
-    // device -> host last: output may alias input (BitNetMCU_MNIST_dll.c:80)
-    ok = ok && hipMemcpy(output, g_sb.p, n_input, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!sym_stream_ready() || g_pin_in.ensure((size_t)n_input * 4) || g_pin_out.ensure(n_input) || g_pin_arg.ensure(4)) die("ReLUNorm");
+    std::memcpy(g_pin_in.host, input, (size_t)n_input * 4);
+    bool ok = bnmk_relunorm((const int32_t *)g_pin_in.dev, n_input, (int8_t *)g_pin_out.dev, n_input, (uint32_t *)g_pin_arg.dev, 1, g_sym_stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(g_sym_stream) == hipSuccess;
     if (!ok) { g_err = hipGetErrorString(hipGetLastError()); die("ReLUNorm"); }
-    return pos;
+    // (the results leave the staging buffers after the kernel: output may alias input, BitNetMCU_MNIST_dll.c:80)
+    std::memcpy(output, g_pin_out.host, n_input);
+    return *(const uint32_t *)g_pin_arg.host;
 }
 
 int32_t *processconv33ReLU(int32_t *activations, const int8_t *weights, uint32_t xy, uint32_t n_shift, int32_t *output) {
@@ -1577,12 +1632,14 @@ int32_t *processconv33ReLU(int32_t *activations, const int8_t *weights, uint32_t
     DeviceGuard dg(sym_device());
     if (xy < 3) return output;      // no output position exists (the reference's loops do not run either)
     uint32_t o = xy - 2;
-    if (g_so.ensure((size_t)xy * xy * 4) || g_sw.ensure(16) || g_sa.ensure((size_t)o * o * 4)) die("processconv33ReLU");
-    bool ok = hipMemcpy(g_so.p, activations, (size_t)xy * xy * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(g_sw.p, weights, 9, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && bnmk_conv33((const int32_t *)g_so.p, (const int8_t *)g_sw.p, xy, n_shift, (int32_t *)g_sa.p, nullptr) == hipSuccess;
-    ok = ok && hipMemcpy(output, g_sa.p, (size_t)o * o * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!sym_stream_ready() || g_pin_in.ensure((size_t)xy * xy * 4) || g_pin_out.ensure((size_t)o * o * 4)) die("processconv33ReLU");
+    const WeightEntry *w = cached_weights(weights, 9, [] { return 0u; });
+    if (!w) { g_err = hipGetErrorString(hipGetLastError()); die("processconv33ReLU"); }
+    std::memcpy(g_pin_in.host, activations, (size_t)xy * xy * 4);
+    bool ok = bnmk_conv33((const int32_t *)g_pin_in.dev, (const int8_t *)w->dev, xy, n_shift, (int32_t *)g_pin_out.dev, g_sym_stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(g_sym_stream) == hipSuccess;
     if (!ok) { g_err = hipGetErrorString(hipGetLastError()); die("processconv33ReLU"); }
+    std::memcpy(output, g_pin_out.host, (size_t)o * o * 4);      // (output may alias activations: copied out after the kernel)
     return output + (size_t)o * o;
 }
 
@@ -1591,11 +1648,12 @@ int32_t *processmaxpool22(int32_t *activations, uint32_t xy, int32_t *output) {
     DeviceGuard dg(sym_device());
     if (xy < 2) return output;      // no output position exists
     uint32_t o = xy / 2;
-    if (g_so.ensure((size_t)xy * xy * 4) || g_sa.ensure((size_t)o * o * 4)) die("processmaxpool22");
-    bool ok = hipMemcpy(g_so.p, activations, (size_t)xy * xy * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && bnmk_maxpool22((const int32_t *)g_so.p, xy, (int32_t *)g_sa.p, nullptr) == hipSuccess;
-    ok = ok && hipMemcpy(output, g_sa.p, (size_t)o * o * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!sym_stream_ready() || g_pin_in.ensure((size_t)xy * xy * 4) || g_pin_out.ensure((size_t)o * o * 4)) die("processmaxpool22");
+    std::memcpy(g_pin_in.host, activations, (size_t)xy * xy * 4);
+    bool ok = bnmk_maxpool22((const int32_t *)g_pin_in.dev, xy, (int32_t *)g_pin_out.dev, g_sym_stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(g_sym_stream) == hipSuccess;
     if (!ok) { g_err = hipGetErrorString(hipGetLastError()); die("processmaxpool22"); }
+    std::memcpy(output, g_pin_out.host, (size_t)o * o * 4);
     return output + (size_t)o * o;
 }
 

@@ -9,10 +9,15 @@
  * BitNetMCU_MNIST_test_data.h: `int8_t input_data_<k>[256]` / `uint8_t label_<k>` for k = 0..9 (the reference's layout).
  * Output: one line per image, "label: <l> predicted: <p>" - what BitNetMCU_MNIST_test.c:17-40 prints.
  * Every call is a round trip to the GPU: this is symbol-level compatibility, not the fast path (examples/batch_infer.c).
+ * BNM_TIME_REPEATS=<n> in the environment: afterwards the ten images are classified n more times and the mean time per image
+ * goes to stderr (profiles/r04_symbol_flow.py; DESIGN.md 6 has the numbers).
  */
+#define _POSIX_C_SOURCE 199309L
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "BitNetMCU_model.h"
 #include "BitNetMCU_MNIST_test_data.h"
@@ -82,5 +87,17 @@ int main(void) {
     } tests[] = {IMAGE(0), IMAGE(1), IMAGE(2), IMAGE(3), IMAGE(4), IMAGE(5), IMAGE(6), IMAGE(7), IMAGE(8), IMAGE(9)};
     for (size_t t = 0; t < sizeof tests / sizeof tests[0]; t++)
         printf("label: %d predicted: %d\n", (int)*tests[t].label, (int)classify(tests[t].pixels));
+    const char *rep = getenv("BNM_TIME_REPEATS");
+    if (rep && atoi(rep) > 0) {
+        const int n = atoi(rep), images = (int)(sizeof tests / sizeof tests[0]);
+        struct timespec t0, t1;
+        uint32_t sink = 0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int r = 0; r < n; r++)
+            for (int t = 0; t < images; t++) sink += classify(tests[t].pixels);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double us = ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / 1e3 / ((double)n * images);
+        fprintf(stderr, "symbol flow: %.1f us per image over %d images (checksum %u)\n", us, n * images, (unsigned)sink);
+    }
     return 0;
 }
