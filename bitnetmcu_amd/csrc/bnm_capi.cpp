@@ -43,8 +43,14 @@ uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1u) / m * m; }
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    // set when a launch that reads / writes the buffer was CAPTURED into a HIP graph: the graph holds the address for as long as
+    // it may be replayed, so the buffer is neither grown (that frees it) nor released before its context goes
+    bool frozen = false;
     int ensure(size_t need) {
         if (need <= bytes) return BNM_OK;
+        if (frozen)
+            return fail(BNM_EUNSUPPORTED, "this stream's scratch buffer is referenced by a captured graph and cannot grow: run calls "
+                                          "larger than the captured ones on another stream (or capture the largest call first)");
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
@@ -52,10 +58,12 @@ struct DevBuf {
         bytes = need;
         return BNM_OK;
     }
-    void release() {
+    void release(bool even_if_frozen = false) {
+        if (frozen && !even_if_frozen) return;
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
+        frozen = false;
     }
 };
 
@@ -239,8 +247,17 @@ int resolve_path(bnm_ctx *c) {
         // the fastest bit-exact kernel: the fused MFMA kernels for every model they can run - all-ternary ones included (the
         // generic kernel does 1.6e10 inf/s on 256-96-96-96, the ALU kernel 3.0e9; BASELINE configs[2] asks for the ALU kernel
         // by name, and bench.py selects it explicitly with BNM_PATH_TERNARY_ALU)
-        if (c->fused_ok) want = BNM_PATH_FUSED_MFMA;
-        else if (c->model.kind == BNM_KIND_FC && all_tern && c->tern_ok) want = BNM_PATH_TERNARY_ALU;
+        if (c->fused_ok) {
+            want = BNM_PATH_FUSED_MFMA;
+            // fragments that nearly fill the LDS leave room for very few waves beside them: the kernel still runs, far below its
+            // usual rate (a lone wave per SIMD issues VALU at half rate, fewer leave SIMDs idle) - say so once
+            const uint32_t waves = (!c->table_ok && c->generic_ok) ? bnmk_generic_resident_waves(c->gdesc, c->shape.dbl) : 8u;
+            if (waves < 4u && !c->warned_layerwise && !std::getenv("BNM_QUIET")) {
+                std::fprintf(stderr, "bitnetmcu_hip: this model's weight fragments (%u KiB) leave LDS for %u wave%s per compute unit of the fused "
+                                     "kernel; it runs, well below the kernel's usual rate\n", c->gdesc.w_bytes >> 10, waves, waves == 1 ? "" : "s");
+                c->warned_layerwise = true;
+            }
+        } else if (c->model.kind == BNM_KIND_FC && all_tern && c->tern_ok) want = BNM_PATH_TERNARY_ALU;
         else {
             // no silent cliffs: one kernel per layer with int32 sums through HBM - on the matrix cores when every codec decodes
             // to int8 rows (an order of magnitude below the fused kernels), else the bit-serial kernel (~500x below)
@@ -349,7 +366,9 @@ void evict_other_streams(bnm_ctx *c, hipStream_t keep) {
         if (capturing(kv.first)) return;
     if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return; }
     for (auto it = c->scratch.begin(); it != c->scratch.end();) {
-        if (it->first == keep) { ++it; continue; }
+        bool frozen = false;
+        for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat, &it->second.q8}) frozen = frozen || b->frozen;
+        if (it->first == keep || frozen) { ++it; continue; }      // (a captured graph may still replay on a frozen entry's buffers)
         for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat, &it->second.q8}) b->release();
         it = c->scratch.erase(it);
     }
@@ -387,10 +406,15 @@ int work_block(bnm_ctx *c, hipStream_t s_real, uint32_t **out) {
 
 bnm_ctx::StreamScratch &stream_scratch(bnm_ctx *c, hipStream_t s_real) {
     const hipStream_t s = stream_key(s_real);
+    const bool capturing = stream_is_capturing(s_real);
     auto it = c->scratch.find(s);
-    if (it != c->scratch.end()) return it->second;
-    if (c->scratch.size() >= kMaxStreams && !stream_is_capturing(s_real)) evict_other_streams(c, s);
-    return c->scratch[s];
+    if (it == c->scratch.end()) {
+        if (c->scratch.size() >= kMaxStreams && !capturing) evict_other_streams(c, s);
+        it = c->scratch.emplace(s, bnm_ctx::StreamScratch{}).first;
+    }
+    if (capturing)      // what a captured launch touches stays where it is (DevBuf::frozen)
+        for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat, &it->second.q8}) b->frozen = true;
+    return it->second;
 }
 
 int ctx_build(bnm_ctx *c) {
@@ -857,7 +881,7 @@ void bnm_ctx_destroy(bnm_ctx *c) {
     DeviceGuard dg(c->device);
     for (void *p : c->owned) (void)hipFree(p);
     for (auto &kv : c->scratch)
-        for (DevBuf *b : {&kv.second.act_a, &kv.second.act_b, &kv.second.out32, &kv.second.cnn_feat, &kv.second.q8}) b->release();
+        for (DevBuf *b : {&kv.second.act_a, &kv.second.act_b, &kv.second.out32, &kv.second.cnn_feat, &kv.second.q8}) b->release(true);
     for (DevBuf *b : {&c->argmax, &c->stage_img, &c->stage_cls, &c->stage_logits})
         b->release();
     for (PinBuf *b : {&c->lat_in, &c->lat_cls, &c->lat_logits}) b->release();
@@ -958,6 +982,10 @@ int bnm_ctx_release_stream(bnm_ctx *c, void *stream) {
     hipStream_t s = stream_key((hipStream_t)stream);
     auto it = c->scratch.find(s);
     if (it != c->scratch.end()) {
+        bool frozen = false;
+        for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat, &it->second.q8}) frozen = frozen || b->frozen;
+        if (frozen)
+            return fail(BNM_EUNSUPPORTED, "launches captured on this stream reference its scratch buffers: they stay until the context is destroyed");
         for (DevBuf *b : {&it->second.act_a, &it->second.act_b, &it->second.out32, &it->second.cnn_feat, &it->second.q8}) b->release();
         c->scratch.erase(it);
     }

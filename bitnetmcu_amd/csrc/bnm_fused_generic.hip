@@ -83,6 +83,12 @@ int bnmk_generic_tiles(const BnmGenericDesc &d, bool dbl, int tiles, bool logits
     return ok(2) ? 2 : 0;
 }
 
+// waves per CU the default launch of this model would have (0: the model does not fit): the caller warns below one per SIMD
+uint32_t bnmk_generic_resident_waves(const BnmGenericDesc &d, bool dbl) {
+    const int t = bnmk_generic_tiles(d, dbl, 0, false);
+    return t ? generic_waves(d, t, false) : 0u;
+}
+
 bool bnmk_generic_supported(const BnmGenericDesc &d, bool dbl) {
     if (d.M[0] == 0 || d.M[1] == 0 || d.M[2] == 0 || (d.sp != 1 && d.sp != 2) || d.n_classes == 0 || d.n_classes > 256) return false;
     if (d.sp == 2 && dbl) return false;

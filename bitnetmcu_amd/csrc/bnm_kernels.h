@@ -97,6 +97,7 @@ bool bnmk_generic_plan(BnmGenericDesc &d, const uint32_t m_real[4]);   // fills 
 // Returns the tiles per wave a launch would use (1 or 2), or 0 when the model does not fit the kernel in that form.
 int bnmk_generic_tiles(const BnmGenericDesc &d, bool dbl, int tiles, bool logits);
 bool bnmk_generic_supported(const BnmGenericDesc &d, bool dbl);
+uint32_t bnmk_generic_resident_waves(const BnmGenericDesc &d, bool dbl);   // waves per CU of the default launch (0: does not fit)
 // d_counter: a counter block of the caller (BNM_WORK_BLOCK_WORDS words, all zero; the kernel leaves it all zero); batch: units per take (0 = default)
 hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int tiles, int grid_blocks, const int8_t *d_images, uint64_t n,
                               const void *d_frags, uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t batch,

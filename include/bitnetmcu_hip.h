@@ -158,7 +158,9 @@ BNM_API int bnm_ctx_get_variant(const bnm_ctx *c);
  * work only, so after one eager call on the capturing stream it may be captured into a HIP graph and replayed on any stream,
  * next to eager launches: a captured launch gets counters of its own (up to 256 captured launches per context).  On the CNN and
  * layer-wise paths a captured launch uses the CAPTURING stream's scratch (nothing can be allocated under capture): do not run
- * eager launches of the context on the capturing stream while its graph replays on another stream.
+ * eager launches of the context on the capturing stream while its graph replays on another stream.  Scratch that a captured
+ * launch touched stays at its address until the context is destroyed: it is not evicted, bnm_ctx_release_stream refuses the
+ * stream, and an eager call that would need it larger fails with BNM_EUNSUPPORTED (capture the largest call, or use another stream).
  * Every class-id word is written exactly once per call (never a placeholder first): a host that maps d_cls in
  * page-locked memory may poll a pre-set sentinel, as bnm_infer_host does for n <= 64. */
 BNM_API int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls,
