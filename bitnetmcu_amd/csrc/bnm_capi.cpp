@@ -276,8 +276,8 @@ int resolve_path(bnm_ctx *c) {
     if (want == BNM_PATH_FUSED_MFMA && !c->fused_ok)
         return fail(BNM_EUNSUPPORTED, "model shape/codec is outside the fused MFMA kernel table");
     if (want == BNM_PATH_TERNARY_ALU && !(c->tern_ok && c->model.kind == BNM_KIND_FC))
-        return fail(BNM_EUNSUPPORTED, "the ternary ALU kernels serve ternary FC models 256-H1-H2-H3-N with (H1, H2, H3) one of "
-                                      "96-96-96, 128-128-112, 64-64-64, 128-128-128");
+        return fail(BNM_EUNSUPPORTED, "the ternary ALU kernels serve ternary FC models 256-H1-H2-H3-N with H1, H2 in {32, 64, 96, 128}, H3 a "
+                                      "multiple of 16 up to 128 and N <= 64");
     c->path = want;
     return BNM_OK;
 }
@@ -949,7 +949,13 @@ int bnm_ctx_set_ternary_variant(bnm_ctx *c, int variant) {
     if (!c || variant < 0 || (variant > 2 && variant != 11 && variant != 12)) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (variant % 10 == 2 && c->tern_ok && !c->tern_two)
-        return fail(BNM_EUNSUPPORTED, "the two-images-per-lane ternary kernel exists for 96-96-96 only; this model runs variant 1 (one image per lane) or 0");
+        return fail(BNM_EUNSUPPORTED, "the two-images-per-lane ternary kernel exists for 96-96-96 only; this model runs variant 1 (one image per lane)");
+    if (variant % 10 == 0 && c->tern_ok) {
+        uint32_t n_out[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < c->fc.size() && i < 4; i++) n_out[i] = c->fc[i].info.n_output;
+        if (!bnmk_ternary_stream_supported(n_out, 0))
+            return fail(BNM_EUNSUPPORTED, "round 1's plain ternary kernel (variant 0) exists for 96-96-96, 128-128-112, 64-64-64 and 128-128-128 only");
+    }
     c->tern_variant = variant % 10;
     c->tern_dynamic = variant < 10;
     return BNM_OK;

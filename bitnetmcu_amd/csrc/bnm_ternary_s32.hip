@@ -1,0 +1,3 @@
+// ternary_stream_kernel<1, 32, H2, H3, ..>: the family members whose first hidden layer is 32 wide (bnm_ternary_kernel.hpp)
+#include "bnm_ternary_kernel.hpp"
+BNM_TERN_UNIT(32)

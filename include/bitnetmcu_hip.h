@@ -182,11 +182,12 @@ BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
  * variants 4 / 7 / 8; default 4 / 4 / 2) or 64-image pairs (dual-tile kernel, variant 6; default 2) a wave takes at a time;
  * 0 = default. */
 BNM_API int bnm_ctx_set_work_batch(bnm_ctx *c, int tiles);
-/* Ternary ALU kernels (BNM_PATH_TERNARY_ALU; ternary FC models 256-H1-H2-H3-N with (H1, H2, H3) one of 96-96-96, 128-128-112,
- * 64-64-64, 128-128-128).  2: weights streamed through double-buffered scalar registers, two images per lane, image groups handed
+/* Ternary ALU kernels (BNM_PATH_TERNARY_ALU; ternary FC models 256-H1-H2-H3-N with H1, H2 in {32, 64, 96, 128}, H3 a multiple of
+ * 16 up to 128, N <= 64).  2: weights streamed through double-buffered scalar registers, two images per lane, image groups handed
  * out from a device-wide work counter (96-96-96 only, the default there; BNM_EUNSUPPORTED for the other shapes); 1: the same with
- * one image per lane (every shape; the default for the shapes other than 96-96-96); 12 / 11: as 2 / 1 with a fixed stride per
- * wave; 0 the plain ALU kernel (the non-default values are kept for A/B measurements). */
+ * one image per lane (every shape of the family; the default for the shapes other than 96-96-96); 12 / 11: as 2 / 1 with a fixed
+ * stride per wave; 0 round 1's plain ALU kernel (96-96-96, 128-128-112, 64-64-64, 128-128-128 only; the non-default values are
+ * kept for A/B measurements). */
 BNM_API int bnm_ctx_set_ternary_variant(bnm_ctx *c, int variant);
 /* Tuning of the host-pointer path.  mode 0 (default): pipelined page-locked staging; 1: the HIP runtime's own pageable copies,
  * chunk by chunk.  copy_threads: host threads of the staging copy (0 = default).  spin: poll the page-locked result words of the

@@ -647,7 +647,9 @@ def test_ternary_alu_kernels_extreme_sums(signs, gpu_ok, orc):
     ctx.close()
 
 
-@pytest.mark.parametrize("widths", [(128, 128, 112), (64, 64, 64), (128, 128, 128)])
+@pytest.mark.parametrize("widths", [(128, 128, 112), (64, 64, 64), (128, 128, 128),
+                                    # the streamed kernel's family beyond round 3's four-entry table: H1, H2 in {32, 64, 96, 128}, H3 = 16 k
+                                    (32, 32, 16), (64, 96, 48), (128, 32, 80), (96, 128, 112), (32, 128, 128), (128, 64, 16), (96, 64, 32)])
 @pytest.mark.parametrize("signs", ["-+-+", "++++", "dense"])
 def test_ternary_alu_kernel_other_widths(widths, signs, gpu_ok, orc):
     """The no-MFMA path for the other ternary shapes of its table - among them the reference's documented 12 KB ternary model,
@@ -675,8 +677,13 @@ def test_ternary_alu_kernel_other_widths(widths, signs, gpu_ok, orc):
     ctx.set_path(b.PATH_TERNARY_ALU)
     with pytest.raises(b.BnmError):
         ctx.set_ternary_variant(2)                # two images per lane: 96-96-96 only
-    # 1: streamed weights, one image per lane, work counter (the default for these shapes); 11: fixed stride; 0: plain kernel
-    for variant in (None, 1, 11, 0):
+    # 1: streamed weights, one image per lane, work counter (the default for these shapes); 11: fixed stride; 0: round 1's plain
+    # kernel, which exists for the four shapes of its table only
+    plain = widths in ((128, 128, 112), (64, 64, 64), (128, 128, 128))
+    if not plain:
+        with pytest.raises(b.BnmError):
+            ctx.set_ternary_variant(0)
+    for variant in (None, 1, 11) + ((0,) if plain else ()):
         if variant is not None:
             ctx.set_ternary_variant(variant)
         for n in (len(x), 129, 64, 1):
@@ -687,9 +694,13 @@ def test_ternary_alu_kernel_other_widths(widths, signs, gpu_ok, orc):
     ctx.close()
 
 
-def test_ternary_alu_path_refuses_shapes_outside_its_table(gpu_ok):
+@pytest.mark.parametrize("widths,n_classes", [((96, 80, 32), 10),      # H2 is not a multiple of 32
+                                               ((96, 64, 40), 10),      # H3 is not a multiple of 16
+                                               ((160, 64, 32), 10),     # H1 beyond 128
+                                               ((96, 96, 96), 70)])     # more than 64 classes
+def test_ternary_alu_path_refuses_shapes_outside_its_family(widths, n_classes, gpu_ok):
     rng = np.random.default_rng(3)
-    model = b.Model.from_header_text(_random_model_text(rng, (64, 64, 64, 64), (96, 64, 32)))
+    model = b.Model.from_header_text(_random_model_text(rng, (64, 64, 64, 64), widths, n_classes))
     ctx = b.Context(model)
     assert ctx.path == b.PATH_FUSED_MFMA
     with pytest.raises(b.BnmError):
