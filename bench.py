@@ -198,7 +198,7 @@ def kernel_name(b, ctx, model):
     # variant 0 selects the plain ALU kernel
     tern = "ternary_stream_kernel" if getattr(ctx, "ternary_variant", 2) % 10 else "ternary_alu_kernel"
     k = {1: fused, 2: "fc_layer_bitserial_kernel+relunorm_kernel", 3: tern}.get(ctx.path, "?")
-    cnn = "cnn_front_mfma_kernel" if getattr(ctx, "cnn_variant", 1) else "cnn_front_kernel"
+    cnn = {0: "cnn_front_kernel", 3: "cnn_li_kernel"}.get(getattr(ctx, "cnn_variant", 1), "cnn_front_mfma_kernel")
     return k + ("+" + cnn if model.kind == b.KIND_CNN else "")
 
 

@@ -173,8 +173,11 @@ struct bnm_ctx {
     uint32_t channels = 0;
     int8_t *w_conv[3] = {nullptr, nullptr, nullptr};
     int *cnn_wtab = nullptr;       // per-channel weight table of the conv1-on-MFMA front end
+    void *cnn_li_frags = nullptr;  // lane = image front end (cnn_variant 3): per-channel Toeplitz fragments ...
+    int *cnn_li_bias = nullptr;    // ... and plane-offset constants; nullptr when the kernel does not serve the channel count
     int cnn_variant = 1;           // 1: conv1 on the matrix cores (default), 0: the all-VALU kernel of round 1
     uint32_t cnn_grab = 8;         // images a wave of the MFMA front end takes from the work counter at a time (0: fixed shares)
+    uint32_t cnn_li_grab = 2;      // 32-image tiles a wave of the lane = image front end takes at a time
     // Work counters of the persistent kernels that hand their work out dynamically (dual-tile kernel, generic fused kernel, CNN
     // front end, streamed ternary kernel): one counter BLOCK (BNM_WORK_BLOCK_WORDS words, bnm_kernels.h) per STREAM the context
     // is used on.  Launches on one stream are ordered, and every kernel leaves its block all-zero (the last wave to leave puts it
@@ -441,6 +444,20 @@ int ctx_build(bnm_ctx *c) {
             if (int e = dev_alloc(c, &p, tab.size() * sizeof(int))) return e;
             HIP_TRY(hipMemcpy(p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
             c->cnn_wtab = (int *)p;
+        }
+        if (bnmk_cnn_li_waves(c->channels)) {
+            const uint32_t C = c->channels;
+            std::vector<int8_t> fr((size_t)C * 6 * 1024);
+            std::vector<int> bi((size_t)C * 2);
+            bnm_cnn_li_tables((const int8_t *)m.layers[0].weights.data(), (const int8_t *)m.layers[1].weights.data(),
+                              (const int8_t *)m.layers[3].weights.data(), C, fr.data(), bi.data());
+            void *p = nullptr, *q = nullptr;
+            if (int e = dev_alloc(c, &p, fr.size())) return e;
+            if (int e = dev_alloc(c, &q, bi.size() * sizeof(int))) return e;
+            HIP_TRY(hipMemcpy(p, fr.data(), fr.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(q, bi.data(), bi.size() * sizeof(int), hipMemcpyHostToDevice));
+            c->cnn_li_frags = p;
+            c->cnn_li_bias = (int *)q;
         }
         width = c->channels * 4u;
         li = 5;
@@ -769,8 +786,11 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         if (int e = cnn_feat.ensure(feat_bytes + (size_t)cn * AS + 64)) return e;
         int32_t *feat = need_feat ? (int32_t *)cnn_feat.p : nullptr;
         int8_t *acts = (int8_t *)cnn_feat.p + feat_bytes;
-        HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,
-                               c->channels, 4, acts, AS, feat, d_acts_tap != nullptr, block, c->cnn_grab, s));
+        if (c->cnn_variant == 3 && c->cnn_li_frags && !d_acts_tap)
+            HIP_TRY(bnmk_cnn_front_li(d_images + off * 256, cn, c->cnn_li_frags, c->cnn_li_bias, c->channels, acts, AS, block, c->cnn_li_grab, s));
+        else
+            HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,
+                                   c->channels, 4, acts, AS, feat, d_acts_tap != nullptr, block, c->cnn_grab, s));
         uint32_t *cls = d_cls + off;
         int32_t *lg = d_logits ? d_logits + off * ncls : nullptr;
         if (d_acts_tap)
@@ -931,8 +951,14 @@ int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
 }
 
 int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
-    if (!c || variant < 0 || (variant > 2 && variant < 101) || variant > 164) return fail(BNM_EINVAL, "bad argument");
+    if (!c || variant < 0 || (variant > 3 && variant < 101) || (variant > 164 && variant < 301) || variant > 316) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
+    if (variant == 3 || variant > 300) {      // the lane = image kernel (301..316: tiles per take)
+        if (!c->cnn_li_frags) return fail(BNM_EUNSUPPORTED, "the lane = image front end serves CNN models of up to 106 channels");
+        c->cnn_variant = 3;
+        c->cnn_li_grab = variant > 300 ? (uint32_t)(variant - 300) : 2u;
+        return BNM_OK;
+    }
     c->cnn_variant = variant == 0 ? 0 : 1;
     c->cnn_grab = variant == 2 ? 0u : variant > 100 ? (uint32_t)(variant - 100) : 8u;
     return BNM_OK;

@@ -161,10 +161,11 @@ class Context:
         self.ternary_variant = variant
 
     def set_cnn_variant(self, variant):
-        """1: conv1 on the matrix cores, dynamic image batches (default); 2: fixed share per wave; 100 + g: batches of g images;
-        0: the all-VALU front end of round 1"""
+        """1: conv1 on the matrix cores, a lane = a channel, dynamic image batches; 2: fixed share per wave; 100 + g: batches of g
+        images; 0: the all-VALU front end of round 1; 3: the lane = image kernel (all three convolutions on the matrix cores;
+        300 + g: g tiles per take)"""
         L.check(self._lib, self._lib.bnm_ctx_set_cnn_variant(self._h, variant), "bnm_ctx_set_cnn_variant")
-        self.cnn_variant = 0 if variant == 0 else 1
+        self.cnn_variant = 0 if variant == 0 else 3 if (variant == 3 or variant > 300) else 1
 
     def release_stream(self, stream):
         """Drop the scratch buffers and the counter block the context keeps for `stream` (a torch.cuda.Stream); synchronises it."""
