@@ -954,7 +954,7 @@ int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
     if (!c || variant < 0 || (variant > 3 && variant < 101) || (variant > 164 && variant < 301) || variant > 316) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (variant == 3 || variant > 300) {      // the lane = image kernel (301..316: tiles per take)
-        if (!c->cnn_li_frags) return fail(BNM_EUNSUPPORTED, "the lane = image front end serves CNN models of up to 106 channels");
+        if (!c->cnn_li_frags) return fail(BNM_EUNSUPPORTED, "the lane = image front end serves CNN models of up to 142 channels");
         c->cnn_variant = 3;
         c->cnn_li_grab = variant > 300 ? (uint32_t)(variant - 300) : 2u;
         return BNM_OK;

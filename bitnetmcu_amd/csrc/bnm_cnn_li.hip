@@ -18,7 +18,7 @@
 //     (b) a D-register quad is one 2x2 pooling window (the maximum is in-lane) and (c) a lane's pooled values are bytes of ITS
 //     half of conv3's operand: no LDS, no cross-lane traffic between the stages;
 //   * the ReLUNorm over all 4 C features stays fused without holding 2 C int32 per lane: a lane writes, per channel, one LDS word
-//     {f0 >> k, f1 >> k, k} with k = max(bitlength(mx >> 7) - 1, 0) from ITS running maximum mx - at most 8 significant bits are
+//     {f0 >> k, f1 >> k} + a byte k with k = max(bitlength(mx >> 7) - 1, 0) from ITS running maximum mx - at most 8 significant bits are
 //     kept, which is exact for the final shift s >= k + 1 ((f + (1 << s >> 1)) >> s == ((f >> k) + (1 << (s-k) >> 1)) >> (s-k)).
 // Any channel count costs exactly its channels (no idle lanes at 24 or 48 channels).  VALU per channel and tile ~ 580 (conv1
 // epilogue 7 x 46, conv2 6 x 35, conv3 ~ 50) = 1,160 per image at 64 channels against 1,602, next to 88 MFMAs per image.
@@ -33,18 +33,53 @@ constexpr int LI_WAVES = 12;         // up to three waves per SIMD (136 VGPRs); 
 BNM_DEVICE i32x16 mfma0(const i32x4 &a, const i32x4 &b) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0); }
 BNM_DEVICE i32x16 mfma(const i32x4 &a, const i32x4 &b, const i32x16 &c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// relu of two 15-bit values as one packed pair: [max(a, 0) | max(b, 0) << 16]  (v_cvt_pk_i16_i32 + v_pk_max_i16)
+BNM_DEVICE uint32_t relu_pair16(int a, int b) {
+    const s16x2 p = __builtin_amdgcn_cvt_pk_i16(a, b), z = {0, 0};
+    const s16x2 r = __builtin_elementwise_max(p, z);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// Byte planes of pooled values for conv3's operand: byte k of the lane's operand half <- (P[k] >> SH) & 255 (one SDWA shift per
+// byte, the >> 4 of the stage folded into SH).  K-step 0: 12 values -> three dwords (writes to one register are three instructions
+// apart); K-step 1: six values -> bytes 0..3 of one dword and 0..1 of a second (two apart, a nop before the last).  A partial
+// (dst_sel) write needs one wait state before the next access of that register, which hipcc cannot see inside the statement.
+#define LI_SD(DST, SRC, SEL, UNUSED) "v_lshrrev_b32_sdwa " DST ", %[sh], " SRC " dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:DWORD src1_sel:DWORD\n\t"
+BNM_DEVICE void plane_bytes12(int &d0, int &d1, int &d2, const int (&P)[18], int sh) {
+    asm(LI_SD("%0", "%[p0]", "BYTE_0", "UNUSED_PAD") LI_SD("%1", "%[p4]", "BYTE_0", "UNUSED_PAD") LI_SD("%2", "%[p8]", "BYTE_0", "UNUSED_PAD")
+        LI_SD("%0", "%[p1]", "BYTE_1", "UNUSED_PRESERVE") LI_SD("%1", "%[p5]", "BYTE_1", "UNUSED_PRESERVE") LI_SD("%2", "%[p9]", "BYTE_1", "UNUSED_PRESERVE")
+        LI_SD("%0", "%[p2]", "BYTE_2", "UNUSED_PRESERVE") LI_SD("%1", "%[p6]", "BYTE_2", "UNUSED_PRESERVE") LI_SD("%2", "%[p10]", "BYTE_2", "UNUSED_PRESERVE")
+        LI_SD("%0", "%[p3]", "BYTE_3", "UNUSED_PRESERVE") LI_SD("%1", "%[p7]", "BYTE_3", "UNUSED_PRESERVE") LI_SD("%2", "%[p11]", "BYTE_3", "UNUSED_PRESERVE")
+        "s_nop 0"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2)
+        : [sh] "v"(sh), [p0] "v"(P[0]), [p1] "v"(P[1]), [p2] "v"(P[2]), [p3] "v"(P[3]), [p4] "v"(P[4]), [p5] "v"(P[5]), [p6] "v"(P[6]), [p7] "v"(P[7]),
+          [p8] "v"(P[8]), [p9] "v"(P[9]), [p10] "v"(P[10]), [p11] "v"(P[11]));
+}
+BNM_DEVICE void plane_bytes6(int &d0, int &d1, const int (&P)[18], int sh) {
+    asm(LI_SD("%0", "%[p0]", "BYTE_0", "UNUSED_PAD") LI_SD("%1", "%[p4]", "BYTE_0", "UNUSED_PAD")
+        LI_SD("%0", "%[p1]", "BYTE_1", "UNUSED_PRESERVE") LI_SD("%1", "%[p5]", "BYTE_1", "UNUSED_PRESERVE")
+        LI_SD("%0", "%[p2]", "BYTE_2", "UNUSED_PRESERVE") "s_nop 0\n\t"
+        LI_SD("%0", "%[p3]", "BYTE_3", "UNUSED_PRESERVE")
+        "s_nop 0"
+        : "=&v"(d0), "=&v"(d1)
+        : [sh] "v"(sh), [p0] "v"(P[12]), [p1] "v"(P[13]), [p2] "v"(P[14]), [p3] "v"(P[15]), [p4] "v"(P[16]), [p5] "v"(P[17]));
+}
+#undef LI_SD
+
 }  // namespace
 
 // frags: [C][6] fragments of 1 KiB (stage 1 K-steps 0, 1; stage 2; stage 3), lane-linear; bias: [C][2] = {128 sum(w2), 32896 sum(w3)}
-// acts: int8 [n][acts_stride], 4 C bytes written per image.  Dynamic LDS: waves x C x 256 bytes (the ReLUNorm records).
+// acts: int8 [n][acts_stride], 4 C bytes written per image.  Dynamic LDS: waves x C x 192 bytes (the ReLUNorm records).
 __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__restrict__ images, uint32_t n, const i32x4 *__restrict__ frags,
                                                                    const int *__restrict__ bias, uint32_t C, int8_t *__restrict__ acts,
                                                                    uint32_t acts_stride, uint32_t *__restrict__ counter, uint32_t grab) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t li_records[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t li_records[];      // per wave: [C][64] uint16 {f0 >> k, f1 >> k} then [C][64] uint8 k
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = blockDim.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    uint32_t *const rec = li_records + wave * C * 64u + (uint32_t)lane;
+    uint16_t *const rec = (uint16_t *)(li_records + wave * C * 192u) + lane;
+    uint8_t *const rec_k = li_records + wave * C * 192u + C * 128u + lane;
 
     const uint32_t n_tiles = (n + 31u) >> 5;
     const uint32_t total_waves = gridDim.x * nwaves, wave_id = blockIdx.x * nwaves + wave;
@@ -67,25 +102,26 @@ __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__r
             const i32x4 a1a = fc[0], a1b = fc[64], a2a = fc[128], a2b = fc[192], a3a = fc[256], a3b = fc[320];
             const int bias2 = bias[2 * c], bias3 = bias[2 * c + 1];
             i32x4 lo[7], hi[7];                 // conv2's operands: the two planes of conv1's outputs, K-step r = conv1 rows 2r, 2r+1
-            int P[18];                          // pooled conv2 outputs of this lane: P[3 r2 + t] = window 2t + h of pooled row r2
+            int P[18];                          // 16 x the pooled conv2 outputs of this lane: P[3 r2 + t] = window 2t + h of pooled row r2
             static_for<0, 8>([&](auto R_) {
                 constexpr int r = decltype(R_)::value;
                 if constexpr (r < 7) {
                     // ---- stage 1, row pair r: relu(sum) >> 4 of this lane's conv1 row 2r + h, 14 values -> bytes of lo[r] / hi[r]
-                    // (sdwa_shift_pack4<b>: byte b of four dwords from four values, shift 4 = the low plane's byte, 12 = the high one's)
                     const i32x16 d = mfma(a1b, b1[r + 1], mfma0(a1a, b1[r]));
-                    int v[16];
+                    // w = sum >> 4 fits 15 bits: ReLU on packed int16 pairs; a pair's bytes are [lo(2k), hi(2k), lo(2k+1), hi(2k+1)], and
+                    // one v_perm_b32 gathers four values' low (high) bytes into a dword of the low (high) plane: 40 VALU per 14 values
+                    uint32_t x[8];
 #pragma unroll
-                    for (int i = 0; i < 14; i++) v[i] = max(d[i], 0);
-                    v[14] = v[15] = 0;
-                    int l0, l1, l2, l3, g0, g1, g2, g3;
-                    static_for<0, 4>([&](auto B_) {
-                        constexpr int b = decltype(B_)::value;
-                        sdwa_shift_pack4<b>(l0, l1, l2, l3, v[b], v[4 + b], v[8 + b], v[12 + b], 4);
-                        sdwa_shift_pack4<b>(g0, g1, g2, g3, v[b], v[4 + b], v[8 + b], v[12 + b], 12);
-                    });
-                    lo[r] = i32x4{l0, l1, l2, l3} ^ 0x80808080;
-                    hi[r] = i32x4{g0, g1, g2, g3};
+                    for (int k = 0; k < 7; k++) x[k] = relu_pair16(d[2 * k] >> 4, d[2 * k + 1] >> 4);
+                    x[7] = 0;
+                    i32x4 l, g;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        l[q] = (int)__builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x06040200u);
+                        g[q] = (int)__builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x07050301u);
+                    }
+                    lo[r] = l ^ 0x80808080;
+                    hi[r] = g;
                 }
                 if constexpr (r >= 1 && r <= 6) {
                     // ---- stage 2, row pair r2 = r - 1 (needs conv1 row pairs r - 1 and r): pooled, ReLU'd, >> 4
@@ -99,30 +135,25 @@ __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__r
                         for (int e = 0; e < 4; e++) s[e] = dl[4 * t + e] + (dh[4 * t + e] << 8);
                         int m = max(max(s[0], s[1]), s[2]);
                         m = max(max(m, s[3]), -bias2);                       // relu(max + bias) = max(max, -bias) + bias
-                        P[3 * r2 + t] = (m + bias2) >> 4;
+                        P[3 * r2 + t] = m + bias2;                             // (the stage's >> 4 happens in the plane split)
                     }
                 }
             });
             // conv3's operands: three byte planes of the 20-bit pooled values; K-step 0 = pooled rows 0..3 (bytes 0..11 of this lane's
             // half), K-step 1 = rows 4, 5 (bytes 0..5); unused bytes meet zero weights
             i32x4 pl[3][2];
-            static_for<0, 3>([&](auto PL_) {
-                constexpr int p = decltype(PL_)::value;
-                int a0, a1, a2, a3, c0, c1, c2, c3;
-                static_for<0, 4>([&](auto B_) {
-                    constexpr int b = decltype(B_)::value;
-                    sdwa_shift_pack4<b>(a0, a1, a2, a3, P[b], P[4 + b], P[8 + b], 0, 8 * p);
-                    int p16 = 0;
-                    if constexpr (b < 2) p16 = P[16 + b];
-                    sdwa_shift_pack4<b>(c0, c1, c2, c3, P[12 + b], p16, 0, 0, 8 * p);
-                });
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                int a0, a1, a2, c0, c1;
+                plane_bytes12(a0, a1, a2, P, 4 + 8 * p);
+                plane_bytes6(c0, c1, P, 4 + 8 * p);
                 pl[p][0] = i32x4{a0, a1, a2, 0};
                 pl[p][1] = i32x4{c0, c1, 0, 0};
-                if constexpr (p < 2) {
+                if (p < 2) {
                     pl[p][0] ^= 0x80808080;
                     pl[p][1] ^= 0x80808080;
                 }
-            });
+            }
             // ---- stage 3: 4x4 outputs -> 2x2 pooled features; this lane holds windows u = h (quad 0) and u = 2 + h (quad 1)
             int f[2];
             {
@@ -143,7 +174,8 @@ __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__r
             mx = max(max(mx, f[0]), f[1]);
             const int shv = (mx >> 7) == 0 ? 0 : 32 - __builtin_clz((uint32_t)(mx >> 7));      // bitlength(mx >> 7)
             const int k = max(shv - 1, 0);
-            rec[c * 64u] = (uint32_t)(f[0] >> k) | ((uint32_t)(f[1] >> k) << 8) | ((uint32_t)k << 16);
+            rec[c * 64u] = (uint16_t)((uint32_t)(f[0] >> k) | ((uint32_t)(f[1] >> k) << 8));
+            rec_k[c * 64u] = (uint8_t)k;
         }
         // ---- ReLUNorm over the image's 4 C features (BitNetMCU_inference.c:23-72): the maximum of both lane halves, one shift
         const int m_all = max_with_partner32(mx);
@@ -151,7 +183,7 @@ __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__r
         int8_t *row = acts + (uint64_t)img * acts_stride;
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t w = rec[c * 64u];
-            const int d = s_all - (int)(w >> 16), rnd = (1 << d) >> 1;
+            const int d = s_all - (int)rec_k[c * 64u], rnd = (1 << d) >> 1;
             const int o0 = min((int)((w & 255u) + (uint32_t)rnd) >> d, 127), o1 = min((int)(((w >> 8) & 255u) + (uint32_t)rnd) >> d, 127);
             // act bytes of channel c: [window 0, 1, 2, 3] = [o0 of half 0, o0 of half 1, o1 of half 0, o1 of half 1]
             const int x = (o0 | (o1 << 16)) << (8 * h);
@@ -215,10 +247,10 @@ void bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uin
     }
 }
 
-// waves per workgroup (one workgroup per CU): the records take C x 256 bytes of LDS per wave; 0 = the kernel does not serve C
+// waves per workgroup (one workgroup per CU): the records take C x 192 bytes of LDS per wave; 0 = the kernel does not serve C
 uint32_t bnmk_cnn_li_waves(uint32_t C) {
     if (C == 0) return 0;
-    const uint32_t w = (160u * 1024u) / (C * 256u);
+    const uint32_t w = (160u * 1024u) / (C * 192u);
     return w >= (uint32_t)LI_WAVES ? (uint32_t)LI_WAVES : (w >= 6u ? w : 0u);      // fewer than six waves: the channel kernel serves the model
 }
 
@@ -243,7 +275,7 @@ hipError_t bnmk_cnn_front_li(const int8_t *images, uint64_t n, const void *frags
     uint64_t blocks = (tiles + per_block - 1) / per_block;
     const uint64_t cap = (uint64_t)bnm_num_cus();
     if (blocks > cap) blocks = cap;
-    cnn_li_kernel<<<dim3((unsigned)blocks), dim3(64 * waves), waves * C * 256u, s>>>(images, (uint32_t)n, (const i32x4 *)frags, bias, C, acts,
+    cnn_li_kernel<<<dim3((unsigned)blocks), dim3(64 * waves), waves * C * 192u, s>>>(images, (uint32_t)n, (const i32x4 *)frags, bias, C, acts,
                                                                                   acts_stride, counter, grab);
     return hipGetLastError();
 }

@@ -192,18 +192,19 @@ def test_model_vs_oracle_synthetic(name, gpu_ok, orc):
 
 @pytest.mark.parametrize("name", [n for n in MODEL_NAMES if "cnn" in n])
 def test_cnn_front_end_both_kernels(name, gpu_ok, orc):
-    """conv1 on the matrix cores (default) and the all-VALU front end of round 1: ids, logits and the int8 features equal the
-    oracle's on synthetic images of both distributions, odd batch sizes and the extreme images."""
+    """The lane = image kernel (3: all three convolutions on the matrix cores; 302: two tiles per take), conv1 on the matrix cores
+    with a lane per channel (1) and the all-VALU front end of round 1 (0): ids and logits equal the oracle's on synthetic images
+    of both distributions, odd batch sizes, ragged 32-image tiles and the extreme images."""
     model = util.load_golden_model(name)
     om = util.OracleModel(model, orc)
     ctx = b.Context(model)
     x = np.concatenate([synth.images(123, 1501, DIST_U), synth.images(9, 1502, DIST_M), np.zeros((2, 256), np.int8),
                         np.full((2, 256), -128, np.int8), np.full((2, 256), 127, np.int8)])
     want = om.infer(x, logits=True)
-    for variant in (1, 0):
+    for variant in (3, 302, 1, 0):
         ctx.set_cnn_variant(variant)
         # (<= 16 channels: two images per item, the last one or two images through the single-image instantiation)
-        for n in (len(x), 1, 5, 2, 3, 4, 1000):
+        for n in (len(x), 1, 5, 2, 3, 4, 1000, 31, 32, 33, 65):
             got = ctx.infer(x[:n], logits=True)
             assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (name, variant, n)
     ctx.close()
@@ -708,13 +709,13 @@ def test_ternary_alu_path_refuses_shapes_outside_its_family(widths, n_classes, g
     ctx.close()
 
 
-def _random_cnn_text(rng, C, codecs, widths, n_classes=10):
+def _random_cnn_text(rng, C, codecs, widths, n_classes=10, conv_weights=None):
     """Header text of a CNN model in the reference's topology (conv, conv, pool, conv, pool, 3 x FC;
     BitNetMCU_MNIST_dll.c:48-91) with C channels and RANDOM weights."""
     lines = ["#include <stdint.h>", "#define MODEL_CNNMNIST", "#define NUM_LAYERS 8", "#define MAX_N_ACTIVATIONS 256"]
 
     def conv(k, cin, xin):
-        w = rng.integers(-6, 7, size=9 * C)
+        w = conv_weights(k) if conv_weights else rng.integers(-6, 7, size=9 * C)
         lines.extend([f"#define L{k}_active", f"#define L{k}_type BitConv2d", f"#define L{k}_in_channels {cin}", f"#define L{k}_out_channels {C}",
                       f"#define L{k}_incoming_x {xin}", f"#define L{k}_incoming_y {xin}", f"#define L{k}_outgoing_x {xin - 2}",
                       f"#define L{k}_outgoing_y {xin - 2}", f"#define L{k}_kernel_size 3", f"#define L{k}_stride 1", f"#define L{k}_padding 0",
@@ -974,8 +975,12 @@ def test_fuzz_random_cnn_models(seed, gpu_ok, orc):
                         np.full((2, 256), 127, np.int8)])
     want = om.infer(x, logits=True)
     ctx = b.Context(model)
-    for variant in (1, 0):
-        ctx.set_cnn_variant(variant)
+    for variant in (3, 1, 0):
+        try:
+            ctx.set_cnn_variant(variant)
+        except b.BnmError:
+            assert variant == 3 and C > 142      # the lane = image kernel's records must fit the LDS beside six waves
+            continue
         for n in (len(x), 5, 6):
             got = ctx.infer(x[:n], logits=True)
             assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, codecs, widths, n_classes, variant, n)
@@ -1029,6 +1034,35 @@ def test_wide_cnn_tail_runs_layerwise_on_the_matrix_cores(C, codecs, gpu_ok, orc
             assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, cv, n)
         taps[cv] = ctx.activations(x[:100])
     assert np.array_equal(taps[1], taps[0]) and np.array_equal(taps[2], taps[0])
+    ctx.close()
+
+
+@pytest.mark.parametrize("C", [5, 24, 64, 100])
+def test_cnn_kernels_with_full_range_conv_weights(C, gpu_ok, orc):
+    """The zoo's conv kernels use the whole int8 range (-128 .. 127), the random models above only -6 .. 6.  Full-range random
+    kernels plus channels whose nine taps are ALL -128 / ALL 127 / all zero (the extreme sums: conv1 outputs of 14 bits, pooled
+    conv2 outputs of 20, features of 26 - what the lane = image kernel's int8 planes and compressed ReLUNorm records must hold),
+    on extreme and synthetic images; every front end against the oracle."""
+    rng = np.random.default_rng(C)
+
+    def conv_weights(k):
+        w = rng.integers(-128, 128, size=(C, 9))
+        w[0], w[1], w[2] = -128, 127, 0
+        if C > 4:
+            w[3] = {2: 127, 4: -128, 7: 127}[k]                    # all-positive first stage into an all-negative second one
+            w[4] = np.array([127, -128] * 4 + [127])
+        return w.reshape(-1)
+    model = b.Model.from_header_text(_random_cnn_text(rng, C, (16, 4, 4), (64, 32), 10, conv_weights))
+    om = util.OracleModel(model, orc)
+    x = np.concatenate([np.full((3, 256), -128, np.int8), np.full((3, 256), 127, np.int8), np.zeros((2, 256), np.int8),
+                        synth.images(C, 300, DIST_U), synth.images(C, 300, DIST_M)])
+    want = om.infer(x, logits=True)
+    ctx = b.Context(model)
+    for variant in (3, 1, 0):
+        ctx.set_cnn_variant(variant)
+        for n in (len(x), 33, 1):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, variant, n)
     ctx.close()
 
 
