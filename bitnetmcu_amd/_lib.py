@@ -57,6 +57,7 @@ PROTOTYPES = {
     "bnm_ctx_get_variant": (C.c_int, [_vp]),
     "bnm_ctx_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
     "bnm_ctx_set_cnn_variant": (C.c_int, [_vp, C.c_int]),
+    "bnm_ctx_get_cnn_variant": (C.c_int, [_vp]),
     "bnm_ctx_set_ternary_variant": (C.c_int, [_vp, C.c_int]),
     "bnm_ctx_set_work_batch": (C.c_int, [_vp, C.c_int]),
     "bnm_ctx_set_host_tuning": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),

@@ -175,7 +175,7 @@ struct bnm_ctx {
     int *cnn_wtab = nullptr;       // per-channel weight table of the conv1-on-MFMA front end
     void *cnn_li_frags = nullptr;  // lane = image front end (cnn_variant 3): per-channel Toeplitz fragments ...
     int *cnn_li_bias = nullptr;    // ... and plane-offset constants; nullptr when the kernel does not serve the channel count
-    int cnn_variant = 1;           // 1: conv1 on the matrix cores (default), 0: the all-VALU kernel of round 1
+    int cnn_variant = 1;           // 3: lane = image kernel (default up to 112 channels), 1: conv1 on the matrix cores / a lane per channel, 0: round 1's all-VALU kernel
     uint32_t cnn_grab = 8;         // images a wave of the MFMA front end takes from the work counter at a time (0: fixed shares)
     uint32_t cnn_li_grab = 2;      // 32-image tiles a wave of the lane = image front end takes at a time
     // Work counters of the persistent kernels that hand their work out dynamically (dual-tile kernel, generic fused kernel, CNN
@@ -458,6 +458,9 @@ int ctx_build(bnm_ctx *c) {
             HIP_TRY(hipMemcpy(q, bi.data(), bi.size() * sizeof(int), hipMemcpyHostToDevice));
             c->cnn_li_frags = p;
             c->cnn_li_bias = (int *)q;
+            // the default front end: the lane = image kernel while seven waves per CU fit beside its records (<= 112 channels: 1.04 to
+            // 1.9 x the channel kernel, profiles/r04/cnn_channels_r04l.log; at 128 channels - six waves - the channel kernel is ahead)
+            if (bnmk_cnn_li_waves(C) >= 7u) c->cnn_variant = 3;
         }
         width = c->channels * 4u;
         li = 5;
@@ -949,6 +952,8 @@ int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
     c->grid_blocks = grid_blocks > 0 ? grid_blocks : 0;
     return BNM_OK;
 }
+
+int bnm_ctx_get_cnn_variant(const bnm_ctx *c) { return c ? c->cnn_variant : BNM_EINVAL; }
 
 int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
     if (!c || variant < 0 || (variant > 3 && variant < 101) || (variant > 164 && variant < 301) || variant > 316) return fail(BNM_EINVAL, "bad argument");

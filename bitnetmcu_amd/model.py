@@ -116,7 +116,7 @@ class Context:
         h = C.c_void_p()
         L.check(self._lib, self._lib.bnm_ctx_create(model._h, device, C.byref(h)), "bnm_ctx_create")
         self._h = h
-        self.cnn_variant = 1
+        self.cnn_variant = self._lib.bnm_ctx_get_cnn_variant(self._h)      # 3 lane = image kernel, 1 channel kernel (see set_cnn_variant)
         self.ternary_variant = 2
         # diagnostic library only (BNM_LIBRARY=.../libbitnetmcu_hip_diag.so, build.py --diag): cache-resident source for
         # compute-side timing.  The product library does not export the symbol and ignores the variable.

@@ -173,11 +173,15 @@ BNM_API int bnm_ctx_release_stream(bnm_ctx *c, void *stream);
  * host copy threads, H2D / compute / D2H of consecutive chunks overlapped. */
 BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls,
                            int32_t *logits);
-/* CNN front end: 1 (default) conv1 on the matrix cores, waves take batches of 8 images from a device-wide work counter; models
+/* CNN front end.  3 (the default up to 112 channels): the lane = image kernel - a wave owns 32 images and walks the channels, all
+ * three convolutions are Toeplitz products on the matrix cores, the ReLUNorm is fused; serves up to 142 channels
+ * (BNM_EUNSUPPORTED beyond); 300 + g (g = 1..16): g 32-image tiles per take from the work counter.  1 (the default beyond 112
+ * channels): a lane = a channel, conv1 on the matrix cores, waves take batches of 8 images from a device-wide work counter; models
  * whose channel count leaves 1..16 channels beyond a multiple of 32 (16, 48, 80 ... channels) run those channels two images per
  * work item.  2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the
- * all-VALU kernel of round 1 (2, 100 + g and 0 are kept for A/B measurements). */
+ * all-VALU kernel of round 1 (the non-default values are kept for A/B measurements). */
 BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
+BNM_API int bnm_ctx_get_cnn_variant(const bnm_ctx *c);      /* 3, 1 or 0 */
 /* Fused kernels that hand their work out from the device-wide counter: units of one or two 32-image tiles (generic kernel,
  * variants 4 / 7 / 8; default 4 / 4 / 2) or 64-image pairs (dual-tile kernel, variant 6; default 2) a wave takes at a time;
  * 0 = default. */
