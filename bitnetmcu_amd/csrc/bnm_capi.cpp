@@ -177,7 +177,7 @@ struct bnm_ctx {
     int *cnn_li_bias = nullptr;    // ... and plane-offset constants; nullptr when the kernel does not serve the channel count
     int cnn_variant = 1;           // 3: lane = image kernel (default up to 112 channels), 1: conv1 on the matrix cores / a lane per channel, 0: round 1's all-VALU kernel
     uint32_t cnn_grab = 8;         // images a wave of the MFMA front end takes from the work counter at a time (0: fixed shares)
-    uint32_t cnn_li_grab = 2;      // 32-image tiles a wave of the lane = image front end takes at a time
+    uint32_t cnn_li_grab = 1;      // 32-image tiles a wave of the lane = image front end takes at a time
     // Work counters of the persistent kernels that hand their work out dynamically (dual-tile kernel, generic fused kernel, CNN
     // front end, streamed ternary kernel): one counter BLOCK (BNM_WORK_BLOCK_WORDS words, bnm_kernels.h) per STREAM the context
     // is used on.  Launches on one stream are ordered, and every kernel leaves its block all-zero (the last wave to leave puts it
@@ -961,7 +961,7 @@ int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
     if (variant == 3 || variant > 300) {      // the lane = image kernel (301..316: tiles per take)
         if (!c->cnn_li_frags) return fail(BNM_EUNSUPPORTED, "the lane = image front end serves CNN models of up to 142 channels");
         c->cnn_variant = 3;
-        c->cnn_li_grab = variant > 300 ? (uint32_t)(variant - 300) : 2u;
+        c->cnn_li_grab = variant > 300 ? (uint32_t)(variant - 300) : 1u;
         return BNM_OK;
     }
     c->cnn_variant = variant == 0 ? 0 : 1;

@@ -259,7 +259,7 @@ hipError_t bnmk_cnn_front_li(const int8_t *images, uint64_t n, const void *frags
     if (!n) return hipSuccess;
     const uint32_t waves = bnmk_cnn_li_waves(C);
     if (!waves || !counter || acts_stride < 4u * C || (acts_stride & 3u) || n >= (1ull << 31)) return hipErrorInvalidValue;
-    if (!grab) grab = 2;
+    if (!grab) grab = 1;
     static std::mutex mu;
     static bool allowed[64] = {};
     int dev = 0;
