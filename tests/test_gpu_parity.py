@@ -969,7 +969,9 @@ def test_fuzz_random_cnn_models(seed, gpu_ok, orc):
         codecs = (16,) + codecs[1:]          # 4 C act bytes are a multiple of 16: any codec but binary / 2-bit fits every C
     widths = tuple(int(rng.integers(1, 128 // need[codecs[k]] + 1)) * need[codecs[k]] for k in (1, 2))
     n_classes = int(rng.integers(2, 41))
-    model = b.Model.from_header_text(_random_cnn_text(rng, C, codecs, widths, n_classes))
+    # odd seeds: conv kernels over the whole int8 range (the zoo's do: -128 .. 127), even seeds: small ones
+    conv_weights = (lambda k: rng.integers(-128, 128, size=9 * C)) if seed % 2 else None
+    model = b.Model.from_header_text(_random_cnn_text(rng, C, codecs, widths, n_classes, conv_weights))
     om = util.OracleModel(model, orc)
     x = np.concatenate([synth.images(seed, 120, DIST_U), synth.images(seed, 121, DIST_M), np.full((2, 256), -128, np.int8),
                         np.full((2, 256), 127, np.int8)])
