@@ -17,12 +17,14 @@
 //   * the D rows of every stage are ordered so that (a) a lane's 14 conv1 values are the 14 bytes of ITS half of conv2's operand,
 //     (b) a D-register quad is one 2x2 pooling window (the maximum is in-lane) and (c) a lane's pooled values are bytes of ITS
 //     half of conv3's operand: no LDS, no cross-lane traffic between the stages;
-//   * the ReLUNorm over all 4 C features stays fused without holding 2 C int32 per lane: a lane writes, per channel, one LDS word
-//     {f0 >> k, f1 >> k} + a byte k with k = max(bitlength(mx >> 7) - 1, 0) from ITS running maximum mx - at most 8 significant bits are
+//   * the ReLUNorm over all 4 C features stays fused without holding 2 C int32 per lane: a lane writes, per channel, three bytes to
+//     LDS - {f0 >> k, f1 >> k} and k - with k = max(bitlength(mx >> 7) - 1, 0) from ITS running maximum mx - at most 8 significant bits are
 //     kept, which is exact for the final shift s >= k + 1 ((f + (1 << s >> 1)) >> s == ((f >> k) + (1 << (s-k) >> 1)) >> (s-k)).
-// Any channel count costs exactly its channels (no idle lanes at 24 or 48 channels).  VALU per channel and tile ~ 580 (conv1
-// epilogue 7 x 46, conv2 6 x 35, conv3 ~ 50) = 1,160 per image at 64 channels against 1,602, next to 88 MFMAs per image.
-// Work: tiles of 32 images in batches from the launch's counter block (word 0; bnm_device.hpp, work_block_leave_v).
+// Any channel count costs exactly its channels (no idle lanes at 24 or 48 channels).  VALU per channel and tile: 524 in the loop
+// body (conv1 epilogue 7 x 40, conv2 6 x 21 + the plane split 64, conv3 and the record ~ 50) = 1,083 per image at 64 channels by
+// the counters, against the channel kernel's 1,602, next to 88 MFMAs per image: 4.0 .. 4.4e8 inferences/s against 3.4e8
+// (VALU 88 % busy at the edge of the 1400 W cap).
+// Work: tiles of 32 images, one per take, from the launch's counter block (word 0; bnm_device.hpp, work_block_leave_v).
 #include <mutex>
 #include "bnm_fused_math.hpp"
 

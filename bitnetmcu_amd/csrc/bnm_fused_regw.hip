@@ -1,25 +1,25 @@
-// Fused whole-model FC kernel for the 3..5-tile shapes (96-, 112-, 128-, 160-wide hidden layers: the reference's documented
-// 12 KB family, docs/documentation.md:169-183, and the ternary 96-96-96 of BASELINE configs[2] on its MFMA path):
-// weight fragments RESIDENT IN THE REGISTER FILE at ONE wave per SIMD.  gfx950 (CDNA4 / MI355X) only.
+// Fused whole-model FC kernel for the 3- and 4-tile shapes (96-, 112-, 128-wide hidden layers: members of the reference's
+// documented 12 KB family, docs/documentation.md:169-183, and the ternary 96-96-96 of BASELINE configs[2] on its MFMA path):
+// weight fragments RESIDENT IN ACCVGPRS at ONE wave per SIMD.  gfx950 (CDNA4 / MI355X) only.  OPT-IN (fused variant 9): it is
+// bit-exact and measured 0 .. 7 % SLOWER than the generic kernel - DESIGN.md 4.1c says why (a lone wave issues VALU instructions at
+// half the SIMD's rate, profiles/probes/mfma_valu_overlap.hip) - and stays in the library as the measured alternative.
 // Reference semantics: BitNetMCU_inference.c:23-72 (ReLUNorm), :88-208 (processfclayer); schedule BitNetMCU_MNIST_dll.c:95-121.
 //
-// Why: the generic kernel (bnm_fused_generic_kernel.hpp) reads every A fragment from LDS - one 1 KiB ds_read_b128 per MFMA.
-// Four matrix cores per CU at one MFMA per 32 clocks each ask the LDS for exactly its 128 B per clock, so from three tiles per
-// layer on that kernel is LDS-bound (profiles/r03/r03z_pmc_doc12k_binary.md: 1.08 LDS instructions per MFMA, matrix cores 52 %
-// busy), and the two-waves-per-SIMD register budget (256) cannot hold 45 fragments.  A wave that has its SIMD to itself owns
-// all 512 registers of the unified file: 256 architectural VGPRs + 256 AccVGPRs, and an MFMA reads its A / B operands from
-// either half (MI355X_MICROARCH.md, register files).  This translation unit is compiled with -amdgpu-mfma-vgpr-form, so the
-// accumulators (which ReLUNorm's VALU code reads) stay in architectural VGPRs and hipcc's allocator places the loop-invariant
-// weight fragments in AccVGPRs, where the matrix core reads them in place: no LDS traffic for weights at all when all layers
-// fit (RL = number of layers, e.g. 96-96-96-10: 45 fragments = 180 registers), layer 1 in registers and the later layers in
-// LDS when they do not (160-160-160-10: 40 of 95 fragments in registers, the LDS reads of the rest drop from 95 to 55 per tile).
+// The idea: the generic kernel (bnm_fused_generic_kernel.hpp) reads every A fragment from LDS - one 1 KiB
+// ds_read_b128 per MFMA, which at four matrix cores per CU is the LDS's whole 128 B per clock - and two waves per SIMD (256
+// registers each) cannot hold 45 fragments.  A wave that has its SIMD to itself owns all 512 registers of the unified file, 256
+// architectural VGPRs + 256 AccVGPRs, and an MFMA reads its A / B operands from either half (MI355X_MICROARCH.md, register files).
+// So: the fragments are loaded straight into AccVGPRs (RegFrags::load) and named as AccVGPR operands by every MFMA of the loop
+// (mfma_areg); the accumulators, which ReLUNorm's VALU code reads, stay in architectural VGPRs (this translation unit is compiled
+// with -amdgpu-mfma-vgpr-form).  All fragments where they fit (96-96-96-10: 45 = 180 registers; 112-96-96-10: 56), layers 1..RL in
+// registers and the rest in LDS where they do not (128-128-112-10: 64 of 68).
 //
-// Loop structure = fused_fc_dual_kernel's (bnm_fused_fc.hip): a wave carries TWO independent 32-image tiles per iteration in
-// one basic block, so one tile's ReLUNorm VALU work sits between the other tile's MFMAs - with a single wave per SIMD that
-// in-wave overlap is the only overlap there is - and it is arranged by hand, across iterations (see the kernel).
+// Loop: a wave carries TWO 32-image tiles per iteration, as fused_fc_dual_kernel does (bnm_fused_fc.hip) - but with a single wave
+// per SIMD the overlap of one tile's ReLUNorm with the other tile's MFMAs is the only overlap there is, so it is arranged by hand
+// and across iterations (see the kernel).
 #include <mutex>
 #include <set>
-#include <utility>
+#include <utility>      // (std::pair: the per-(kernel, device) set of allow_big_lds)
 #include "bnm_fused_tile.hpp"
 #include "bnm_fused_math.hpp"
 
@@ -40,8 +40,8 @@ struct RegFrags {       // held in AccVGPRs for the whole persistent loop
     // Loaded STRAIGHT INTO AccVGPRs by an asm load ("=a"): a value that starts its life in an architectural VGPR (any load hipcc
     // emits itself) reaches an "a"-constrained asm operand through a COPY per use, and the copies that MachineLICM does not hoist
     // out of the loop keep their VGPR originals alive in it - 22 fragments = 88 VGPRs and as many v_accvgpr_write per iteration
-    // in the first asm-MFMA build.  hipcc does not count these loads (cdna_hip_programming.md 5.7, form iii): the caller retires
-    // them with loaded() before anything reads a fragment.
+    // in the first asm-MFMA build.  hipcc does not count these loads (cdna_hip_programming.md 5.7, form iii): the kernel retires
+    // them with one s_waitcnt vmcnt(0) before anything reads a fragment.
     BNM_DEVICE void load(const i32x4 *base, int lane) {
         const i32x4 *p = base + lane;
 #pragma unroll
@@ -61,12 +61,12 @@ struct LdsFrags {       // read from the workgroup's LDS copy, lane-linear ds_re
 // One MFMA of the pinned loop body, A operand NAMED as an AccVGPR tuple ("a" constraint).  With the builtin hipcc's register
 // allocator is free to give a weight fragment an AccVGPR for one stretch of the loop and architectural VGPRs for another, and it
 // does: ~200 v_accvgpr_read / v_accvgpr_mov per pair of tiles (18 % of the loop's VALU instructions) shuffling loop-invariant
-// weights around (profiles/r04/regw_notes.md).  A value whose every use in the loop asks for an AccVGPR stays in one.
+// weights around (profiles/r04/regw_pmc_r04c_builtin_mfma.md).  A value whose every use in the loop asks for an AccVGPR stays in one.
 // hipcc neither schedules nor pads an asm statement (cdna_hip_programming.md 5.7), so the hazards are handled by construction:
 //   * VALU write -> MFMA operand read (2 wait states): every statement opens with s_nop 1, whatever hipcc put in front of it;
 //   * MFMA result -> VALU read (12 wait states for this 8-pass MFMA): the loop body's order is pinned with sched_barrier and an
 //     accumulator's reader (the sliced ReLUNorm of the NEXT block, or the next iteration) is hundreds of instructions behind its
-//     last MFMA; the one short distance - the classifier's argmax - uses the builtin;
+//     last MFMA; the one short distance - the classifier's sums into the argmax - is padded with 16 wait states (settle());
 //   * MFMA -> MFMA on the same accumulator (SrcC = vDst, the accumulate chain): no wait states, as in hipcc's own code;
 //   * the B operand is never an MFMA result; a fragment's AccVGPRs are written once, ahead of the loop.
 template <bool INIT>
@@ -82,17 +82,6 @@ BNM_DEVICE void mfma_frag(i32x16 &acc, const RegFrags<MT, KS> &A, int m, int s, 
 template <bool INIT, int MT, int KS>
 BNM_DEVICE void mfma_frag(i32x16 &acc, const LdsFrags<MT, KS> &A, int m, int s, const i32x4 &b) {
     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A.get(m, s), b, INIT ? zero16() : acc, 0, 0, 0);
-}
-
-template <int MT, int KT, class F>
-BNM_DEVICE void mma(const F &A, const i32x4 (&b)[KT], i32x16 (&acc)[MT]) {
-#pragma unroll
-    for (int m = 0; m < MT; m++) acc[m] = zero16();
-    // K-step outermost: consecutive MFMAs go to different accumulators
-#pragma unroll
-    for (int s = 0; s < KT; s++)
-#pragma unroll
-        for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A.get(m, s), b[s], acc[m], 0, 0, 0);
 }
 
 // layer L (1-based) of a model with RL register-resident layers: its fragments' home
