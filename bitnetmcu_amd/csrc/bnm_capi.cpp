@@ -175,7 +175,7 @@ struct bnm_ctx {
     int *cnn_wtab = nullptr;       // per-channel weight table of the conv1-on-MFMA front end
     void *cnn_li_frags = nullptr;  // lane = image front end (cnn_variant 3): per-channel Toeplitz fragments ...
     int *cnn_li_bias = nullptr;    // ... and plane-offset constants; nullptr when the kernel does not serve the channel count
-    int cnn_variant = 1;           // 3: lane = image kernel (default up to 112 channels), 1: conv1 on the matrix cores / a lane per channel, 0: round 1's all-VALU kernel
+    int cnn_variant = 1;           // 3: lane = image kernel (the default wherever it runs: up to 170 channels), 1: conv1 on the matrix cores / a lane per channel, 0: round 1's all-VALU kernel
     uint32_t cnn_grab = 8;         // images a wave of the MFMA front end takes from the work counter at a time (0: fixed shares)
     uint32_t cnn_li_grab = 1;      // 32-image tiles a wave of the lane = image front end takes at a time
     // Work counters of the persistent kernels that hand their work out dynamically (dual-tile kernel, generic fused kernel, CNN
@@ -458,9 +458,9 @@ int ctx_build(bnm_ctx *c) {
             HIP_TRY(hipMemcpy(q, bi.data(), bi.size() * sizeof(int), hipMemcpyHostToDevice));
             c->cnn_li_frags = p;
             c->cnn_li_bias = (int *)q;
-            // the default front end: the lane = image kernel while seven waves per CU fit beside its records (<= 112 channels: 1.04 to
-            // 1.9 x the channel kernel, profiles/r04/cnn_channels_r04l.log; at 128 channels - six waves - the channel kernel is ahead)
-            if (bnmk_cnn_li_waves(C) >= 7u) c->cnn_variant = 3;
+            // the default front end: the lane = image kernel wherever it runs (six or more waves per CU beside its records: <= 170
+            // channels; 1.10 to 2.0 x the channel kernel at 8 .. 140 channels, profiles/r04/cnn_channels_r05a.log)
+            c->cnn_variant = 3;
         }
         width = c->channels * 4u;
         li = 5;
@@ -789,7 +789,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         if (int e = cnn_feat.ensure(feat_bytes + (size_t)cn * AS + 64)) return e;
         int32_t *feat = need_feat ? (int32_t *)cnn_feat.p : nullptr;
         int8_t *acts = (int8_t *)cnn_feat.p + feat_bytes;
-        if (c->cnn_variant == 3 && c->cnn_li_frags && !d_acts_tap)
+        if (c->cnn_variant == 3 && c->cnn_li_frags)
             HIP_TRY(bnmk_cnn_front_li(d_images + off * 256, cn, c->cnn_li_frags, c->cnn_li_bias, c->channels, acts, AS, block, c->cnn_li_grab, s));
         else
             HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,
@@ -959,7 +959,7 @@ int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
     if (!c || variant < 0 || (variant > 3 && variant < 101) || (variant > 164 && variant < 301) || variant > 316) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (variant == 3 || variant > 300) {      // the lane = image kernel (301..316: tiles per take)
-        if (!c->cnn_li_frags) return fail(BNM_EUNSUPPORTED, "the lane = image front end serves CNN models of up to 142 channels");
+        if (!c->cnn_li_frags) return fail(BNM_EUNSUPPORTED, "the lane = image front end serves CNN models of up to 170 channels");
         c->cnn_variant = 3;
         c->cnn_li_grab = variant > 300 ? (uint32_t)(variant - 300) : 1u;
         return BNM_OK;

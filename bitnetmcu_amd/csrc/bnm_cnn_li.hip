@@ -17,20 +17,21 @@
 //   * the D rows of every stage are ordered so that (a) a lane's 14 conv1 values are the 14 bytes of ITS half of conv2's operand,
 //     (b) a D-register quad is one 2x2 pooling window (the maximum is in-lane) and (c) a lane's pooled values are bytes of ITS
 //     half of conv3's operand: no LDS, no cross-lane traffic between the stages;
-//   * the ReLUNorm over all 4 C features stays fused without holding 2 C int32 per lane: a lane writes, per channel, three bytes to
-//     LDS - {f0 >> k, f1 >> k} and k - with k = max(bitlength(mx >> 7) - 1, 0) from ITS running maximum mx - at most 8 significant bits are
-//     kept, which is exact for the final shift s >= k + 1 ((f + (1 << s >> 1)) >> s == ((f >> k) + (1 << (s-k) >> 1)) >> (s-k)).
-// Any channel count costs exactly its channels (no idle lanes at 24 or 48 channels).  VALU per channel and tile: 524 in the loop
-// body (conv1 epilogue 7 x 40, conv2 6 x 21 + the plane split 64, conv3 and the record ~ 50) = 1,083 per image at 64 channels by
-// the counters, against the channel kernel's 1,602, next to 88 MFMAs per image: 4.0 .. 4.4e8 inferences/s against 3.4e8
-// (VALU 88 % busy at the edge of the 1400 W cap).
+//   * the ReLUNorm over all 4 C features stays fused without holding 2 C int32 per lane: per channel a lane writes {f0 >> k, f1 >> k}
+//     to LDS and the image one byte k = max(bitlength(mx >> 7) - 1, 0) from the IMAGE's running maximum mx (both lane halves: 160
+//     bytes per channel and wave) - at most 8 significant bits are kept, which is exact for the final shift s >= k + 1
+//     ((f + (1 << s >> 1)) >> s == ((f >> k) + (1 << (s-k) >> 1)) >> (s-k)).
+// Any channel count costs exactly its channels (no idle lanes at 24 or 48 channels).  VALU per channel and tile: 504 in the loop
+// body (conv1 epilogue 7 x 40, conv2 6 x 21 + the plane split 32 + 10, conv3 and the record ~ 55), 44 MFMAs.  124 VGPRs: four waves
+// per SIMD - a lone wave issues VALU at half rate, and the compiler's MFMA -> VALU wait states (190 per channel) need other waves
+// to fill them: 4.4 .. 4.5e8 inferences/s at 64 channels against the channel kernel's 3.4e8.
 // Work: tiles of 32 images, one per take, from the launch's counter block (word 0; bnm_device.hpp, work_block_leave_v).
 #include <mutex>
 #include "bnm_fused_math.hpp"
 
 namespace {
 
-constexpr int LI_WAVES = 12;         // up to three waves per SIMD (136 VGPRs); fewer when the records of a wide model fill the LDS
+constexpr int LI_WAVES = 16;         // up to four waves per SIMD (128 VGPRs); fewer when the records of a wide model fill the LDS
 
 BNM_DEVICE i32x16 mfma0(const i32x4 &a, const i32x4 &b) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0); }
 BNM_DEVICE i32x16 mfma(const i32x4 &a, const i32x4 &b, const i32x16 &c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
@@ -43,68 +44,70 @@ BNM_DEVICE uint32_t relu_pair16(int a, int b) {
     return __builtin_bit_cast(uint32_t, r);
 }
 
-// Byte planes of pooled values for conv3's operand: byte k of the lane's operand half <- (P[k] >> SH) & 255 (one SDWA shift per
-// byte, the >> 4 of the stage folded into SH).  K-step 0: 12 values -> three dwords (writes to one register are three instructions
-// apart); K-step 1: six values -> bytes 0..3 of one dword and 0..1 of a second (two apart, a nop before the last).  A partial
-// (dst_sel) write needs one wait state before the next access of that register, which hipcc cannot see inside the statement.
-#define LI_SD(DST, SRC, SEL, UNUSED) "v_lshrrev_b32_sdwa " DST ", %[sh], " SRC " dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:DWORD src1_sel:DWORD\n\t"
-BNM_DEVICE void plane_bytes12(int &d0, int &d1, int &d2, const int (&P)[18], int sh) {
-    asm(LI_SD("%0", "%[p0]", "BYTE_0", "UNUSED_PAD") LI_SD("%1", "%[p4]", "BYTE_0", "UNUSED_PAD") LI_SD("%2", "%[p8]", "BYTE_0", "UNUSED_PAD")
-        LI_SD("%0", "%[p1]", "BYTE_1", "UNUSED_PRESERVE") LI_SD("%1", "%[p5]", "BYTE_1", "UNUSED_PRESERVE") LI_SD("%2", "%[p9]", "BYTE_1", "UNUSED_PRESERVE")
-        LI_SD("%0", "%[p2]", "BYTE_2", "UNUSED_PRESERVE") LI_SD("%1", "%[p6]", "BYTE_2", "UNUSED_PRESERVE") LI_SD("%2", "%[p10]", "BYTE_2", "UNUSED_PRESERVE")
-        LI_SD("%0", "%[p3]", "BYTE_3", "UNUSED_PRESERVE") LI_SD("%1", "%[p7]", "BYTE_3", "UNUSED_PRESERVE") LI_SD("%2", "%[p11]", "BYTE_3", "UNUSED_PRESERVE")
-        "s_nop 0"
-        : "=&v"(d0), "=&v"(d1), "=&v"(d2)
-        : [sh] "v"(sh), [p0] "v"(P[0]), [p1] "v"(P[1]), [p2] "v"(P[2]), [p3] "v"(P[3]), [p4] "v"(P[4]), [p5] "v"(P[5]), [p6] "v"(P[6]), [p7] "v"(P[7]),
-          [p8] "v"(P[8]), [p9] "v"(P[9]), [p10] "v"(P[10]), [p11] "v"(P[11]));
+// Byte planes of pooled values for conv3's operand.  A pooled value arrives as V = 16 x (its 24-bit ReLU'd sum) = (P << 8) | low
+// bits: plane p of P is byte p + 1 of V, and v_perm_b32 gathers bytes of two registers - 7 instructions for the three planes of
+// four values (two pair gathers per pair, one merge per plane).  Compiler-visible on purpose: an earlier inline-asm version (SDWA
+// byte writes) had its outputs allocated to the DEAD rows of an MFMA result still in flight - the padding quad no one reads - and
+// hipcc places no hazard wait in front of inline asm: the late MFMA write-back then zeroed a plane-2 dword, about one image in
+// 50,000 at full-range weights and only at four waves per SIMD.
+struct PlaneQuad { int p0, p1, p2; };
+BNM_DEVICE PlaneQuad plane_quad(int A, int B, int C, int D) {
+    const uint32_t ab01 = __builtin_amdgcn_perm((uint32_t)B, (uint32_t)A, 0x06020501u);      // [A.1, B.1, A.2, B.2]
+    const uint32_t cd01 = __builtin_amdgcn_perm((uint32_t)D, (uint32_t)C, 0x06020501u);
+    const uint32_t ab2 = __builtin_amdgcn_perm((uint32_t)B, (uint32_t)A, 0x0c0c0703u);       // [A.3, B.3, 0, 0]
+    const uint32_t cd2 = __builtin_amdgcn_perm((uint32_t)D, (uint32_t)C, 0x0c0c0703u);
+    return PlaneQuad{(int)__builtin_amdgcn_perm(cd01, ab01, 0x05040100u), (int)__builtin_amdgcn_perm(cd01, ab01, 0x07060302u),
+                     (int)__builtin_amdgcn_perm(cd2, ab2, 0x05040100u)};
 }
-BNM_DEVICE void plane_bytes6(int &d0, int &d1, const int (&P)[18], int sh) {
-    asm(LI_SD("%0", "%[p0]", "BYTE_0", "UNUSED_PAD") LI_SD("%1", "%[p4]", "BYTE_0", "UNUSED_PAD")
-        LI_SD("%0", "%[p1]", "BYTE_1", "UNUSED_PRESERVE") LI_SD("%1", "%[p5]", "BYTE_1", "UNUSED_PRESERVE")
-        LI_SD("%0", "%[p2]", "BYTE_2", "UNUSED_PRESERVE") "s_nop 0\n\t"
-        LI_SD("%0", "%[p3]", "BYTE_3", "UNUSED_PRESERVE")
-        "s_nop 0"
-        : "=&v"(d0), "=&v"(d1)
-        : [sh] "v"(sh), [p0] "v"(P[12]), [p1] "v"(P[13]), [p2] "v"(P[14]), [p3] "v"(P[15]), [p4] "v"(P[16]), [p5] "v"(P[17]));
+BNM_DEVICE PlaneQuad plane_pair(int A, int B) {      // two values: bytes 0, 1 of the dword, the rest zero
+    const uint32_t ab01 = __builtin_amdgcn_perm((uint32_t)B, (uint32_t)A, 0x06020501u);
+    return PlaneQuad{(int)__builtin_amdgcn_perm(0u, ab01, 0x0c0c0100u), (int)__builtin_amdgcn_perm(0u, ab01, 0x0c0c0302u),
+                     (int)__builtin_amdgcn_perm((uint32_t)B, (uint32_t)A, 0x0c0c0703u)};
 }
-#undef LI_SD
 
 }  // namespace
 
 // frags: [C][6] fragments of 1 KiB (stage 1 K-steps 0, 1; stage 2; stage 3), lane-linear; bias: [C][2] = {128 sum(w2), 32896 sum(w3)}
-// acts: int8 [n][acts_stride], 4 C bytes written per image.  Dynamic LDS: waves x C x 192 bytes (the ReLUNorm records).
+// acts: int8 [n][acts_stride], 4 C bytes written per image.  Dynamic LDS: waves x C x 160 bytes (the ReLUNorm records).
 __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__restrict__ images, uint32_t n, const i32x4 *__restrict__ frags,
                                                                    const int *__restrict__ bias, uint32_t C, int8_t *__restrict__ acts,
                                                                    uint32_t acts_stride, uint32_t *__restrict__ counter, uint32_t grab) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t li_records[];      // per wave: [C][64] uint16 {f0 >> k, f1 >> k} then [C][64] uint8 k
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = blockDim.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    uint16_t *const rec = (uint16_t *)(li_records + wave * C * 192u) + lane;
-    uint8_t *const rec_k = li_records + wave * C * 192u + C * 128u + lane;
+    extern __shared__ __attribute__((aligned(16))) uint8_t li_records[];      // per wave: [C][64] uint16 {f0 >> k, f1 >> k} then [C][32] uint8 k (one per image)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), nwaves = blockDim.x >> 6;
+    // Everything derived from the lane id (the fragment / record / image addresses) is derived AFRESH per tile, twice, from an opaque
+    // copy of tid: hoisted out of the tile loop, as the compiler would, those values are live across the channel loop, and at four
+    // waves per SIMD (128 VGPRs) that is what spilled.
+#define LI_LANE_VALUES                                                                       \
+    uint32_t lane_ = tid;                                                                    \
+    asm volatile("" : "+v"(lane_));                                                          \
+    const int lane = (int)(lane_ & 63u), j = lane & 31, h = lane >> 5;                       \
+    uint16_t *const rec = (uint16_t *)(li_records + wave * C * 160u) + lane;                 \
+    uint8_t *const rec_k = li_records + wave * C * 160u + C * 128u + j;
 
     const uint32_t n_tiles = (n + 31u) >> 5;
     const uint32_t total_waves = gridDim.x * nwaves, wave_id = blockIdx.x * nwaves + wave;
     uint32_t tile = wave_id * grab, left = grab - 1u;      // a wave's first batch is static, later ones come from the counter
 
     while (tile < n_tiles) {
+        int mx = 0;
+        {
+        LI_LANE_VALUES
         // ---- the tile's 32 images: lane (j, h) keeps bytes 32 s + 16 h .. + 15 of image j for s = 0..7 (K-step s = rows 2s, 2s+1)
-        uint32_t img = (tile << 5) + (uint32_t)j;
-        const bool valid = img < n;
-        if (!valid) img = n - 1u;
         i32x4 b1[8];
         {
+            uint32_t img = (tile << 5) + (uint32_t)j;
+            if (img >= n) img = n - 1u;      // ragged last tile: rows past the end re-read the last image (their stores are masked)
             const int8_t *p = images + (uint64_t)img * 256u + 16 * h;
 #pragma unroll
             for (int s = 0; s < 8; s++) b1[s] = __builtin_nontemporal_load((const i32x4 *)(p + 32 * s));
         }
-        int mx = 0;
         for (uint32_t c = 0; c < C; c++) {
             const i32x4 *fc = frags + (uint64_t)c * 6u * 64u + lane;
             const i32x4 a1a = fc[0], a1b = fc[64], a2a = fc[128], a2b = fc[192], a3a = fc[256], a3b = fc[320];
             const int bias2 = bias[2 * c], bias3 = bias[2 * c + 1];
             i32x4 lo[7], hi[7];                 // conv2's operands: the two planes of conv1's outputs, K-step r = conv1 rows 2r, 2r+1
-            int P[18];                          // 16 x the pooled conv2 outputs of this lane: P[3 r2 + t] = window 2t + h of pooled row r2
+            int P[18];                          // 256 x the pooled conv2 outputs of this lane (+ 4 low bits): P[3 r2 + t] = window 2t + h of pooled row r2
             static_for<0, 8>([&](auto R_) {
                 constexpr int r = decltype(R_)::value;
                 if constexpr (r < 7) {
@@ -137,55 +140,63 @@ __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__r
                         for (int e = 0; e < 4; e++) s[e] = dl[4 * t + e] + (dh[4 * t + e] << 8);
                         int m = max(max(s[0], s[1]), s[2]);
                         m = max(max(m, s[3]), -bias2);                       // relu(max + bias) = max(max, -bias) + bias
-                        P[3 * r2 + t] = m + bias2;                             // (the stage's >> 4 happens in the plane split)
+                        P[3 * r2 + t] = (m + bias2) << 4;                      // (v_add_lshl_u32: the stage's >> 4 turns into "bytes 1..3")
                     }
                 }
             });
             // conv3's operands: three byte planes of the 20-bit pooled values; K-step 0 = pooled rows 0..3 (bytes 0..11 of this lane's
             // half), K-step 1 = rows 4, 5 (bytes 0..5); unused bytes meet zero weights
             i32x4 pl[3][2];
-#pragma unroll
-            for (int p = 0; p < 3; p++) {
-                int a0, a1, a2, c0, c1;
-                plane_bytes12(a0, a1, a2, P, 4 + 8 * p);
-                plane_bytes6(c0, c1, P, 4 + 8 * p);
-                pl[p][0] = i32x4{a0, a1, a2, 0};
-                pl[p][1] = i32x4{c0, c1, 0, 0};
-                if (p < 2) {
-                    pl[p][0] ^= 0x80808080;
-                    pl[p][1] ^= 0x80808080;
-                }
+            {
+                const PlaneQuad q0 = plane_quad(P[0], P[1], P[2], P[3]), q1 = plane_quad(P[4], P[5], P[6], P[7]),
+                                q2 = plane_quad(P[8], P[9], P[10], P[11]), q3 = plane_quad(P[12], P[13], P[14], P[15]),
+                                q4 = plane_pair(P[16], P[17]);
+                pl[0][0] = i32x4{q0.p0, q1.p0, q2.p0, 0} ^ 0x80808080;
+                pl[0][1] = i32x4{q3.p0, q4.p0, 0, 0} ^ 0x80808080;
+                pl[1][0] = i32x4{q0.p1, q1.p1, q2.p1, 0} ^ 0x80808080;
+                pl[1][1] = i32x4{q3.p1, q4.p1, 0, 0} ^ 0x80808080;
+                pl[2][0] = i32x4{q0.p2, q1.p2, q2.p2, 0};
+                pl[2][1] = i32x4{q3.p2, q4.p2, 0, 0};
             }
             // ---- stage 3: 4x4 outputs -> 2x2 pooled features; this lane holds windows u = h (quad 0) and u = 2 + h (quad 1)
             int f[2];
             {
+                // (planes one after the other into eight partial sums: three accumulators live at once cost 16 registers more than the
+                // kernel has at four waves per SIMD)
                 const i32x16 d0 = mfma(a3b, pl[0][1], mfma0(a3a, pl[0][0]));
                 const i32x16 d1 = mfma(a3b, pl[1][1], mfma0(a3a, pl[1][0]));
+                int s[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) s[i] = d0[i] + (d1[i] << 8);
                 const i32x16 d2 = mfma(a3b, pl[2][1], mfma0(a3a, pl[2][0]));
 #pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    int s[4];
+                for (int i = 0; i < 8; i++) s[i] += d2[i] << 16;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) s[e] = d0[4 * t + e] + (d1[4 * t + e] << 8) + (d2[4 * t + e] << 16);
-                    int m = max(max(s[0], s[1]), s[2]);
-                    m = max(max(m, s[3]), -bias3);
+                for (int t = 0; t < 2; t++) {
+                    int m = max(max(s[4 * t], s[4 * t + 1]), s[4 * t + 2]);
+                    m = max(max(m, s[4 * t + 3]), -bias3);
                     f[t] = (m + bias3) >> 4;
                 }
             }
             // ---- the ReLUNorm record of (channel, lane): 8 significant bits of each feature under the running maximum
-            mx = max(max(mx, f[0]), f[1]);
+            // (mx: the IMAGE's running maximum - both lane halves - so that the two lanes of an image share one k byte: 160 bytes of
+            // records per channel and wave, which is what lets 16 waves = four per SIMD fit the LDS at 64 channels)
+            mx = max(mx, max_with_partner32(max(f[0], f[1])));
             const int shv = (mx >> 7) == 0 ? 0 : 32 - __builtin_clz((uint32_t)(mx >> 7));      // bitlength(mx >> 7)
             const int k = max(shv - 1, 0);
             rec[c * 64u] = (uint16_t)((uint32_t)(f[0] >> k) | ((uint32_t)(f[1] >> k) << 8));
-            rec_k[c * 64u] = (uint8_t)k;
+            rec_k[c * 32u] = (uint8_t)k;      // (both lanes of the image write the same byte)
         }
-        // ---- ReLUNorm over the image's 4 C features (BitNetMCU_inference.c:23-72): the maximum of both lane halves, one shift
-        const int m_all = max_with_partner32(mx);
-        const int s_all = (m_all >> 7) == 0 ? 0 : 32 - __builtin_clz((uint32_t)(m_all >> 7));
-        int8_t *row = acts + (uint64_t)img * acts_stride;
+        }
+        // ---- ReLUNorm over the image's 4 C features (BitNetMCU_inference.c:23-72): the image's maximum, one shift
+        LI_LANE_VALUES
+        const int s_all = (mx >> 7) == 0 ? 0 : 32 - __builtin_clz((uint32_t)(mx >> 7));
+        const uint32_t img_out = (tile << 5) + (uint32_t)j;
+        const bool valid = img_out < n;
+        int8_t *row = acts + (uint64_t)(valid ? img_out : n - 1u) * acts_stride;
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t w = rec[c * 64u];
-            const int d = s_all - (int)rec_k[c * 64u], rnd = (1 << d) >> 1;
+            const int d = s_all - (int)rec_k[c * 32u], rnd = (1 << d) >> 1;
             const int o0 = min((int)((w & 255u) + (uint32_t)rnd) >> d, 127), o1 = min((int)(((w >> 8) & 255u) + (uint32_t)rnd) >> d, 127);
             // act bytes of channel c: [window 0, 1, 2, 3] = [o0 of half 0, o0 of half 1, o1 of half 0, o1 of half 1]
             const int x = (o0 | (o1 << 16)) << (8 * h);
@@ -204,6 +215,7 @@ __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__r
         }
     }
     work_block_leave_v(counter, total_waves);
+#undef LI_LANE_VALUES
 }
 
 // ---- host side: the per-channel Toeplitz fragments (tests/cnn_li_model.py states the same matrices in numpy) -----------------
@@ -249,10 +261,10 @@ void bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uin
     }
 }
 
-// waves per workgroup (one workgroup per CU): the records take C x 192 bytes of LDS per wave; 0 = the kernel does not serve C
+// waves per workgroup (one workgroup per CU): the records take C x 160 bytes of LDS per wave; 0 = the kernel does not serve C
 uint32_t bnmk_cnn_li_waves(uint32_t C) {
     if (C == 0) return 0;
-    const uint32_t w = (160u * 1024u) / (C * 192u);
+    const uint32_t w = (160u * 1024u) / (C * 160u);
     return w >= (uint32_t)LI_WAVES ? (uint32_t)LI_WAVES : (w >= 6u ? w : 0u);      // fewer than six waves: the channel kernel serves the model
 }
 
@@ -277,7 +289,7 @@ hipError_t bnmk_cnn_front_li(const int8_t *images, uint64_t n, const void *frags
     uint64_t blocks = (tiles + per_block - 1) / per_block;
     const uint64_t cap = (uint64_t)bnm_num_cus();
     if (blocks > cap) blocks = cap;
-    cnn_li_kernel<<<dim3((unsigned)blocks), dim3(64 * waves), waves * C * 192u, s>>>(images, (uint32_t)n, (const i32x4 *)frags, bias, C, acts,
+    cnn_li_kernel<<<dim3((unsigned)blocks), dim3(64 * waves), waves * C * 160u, s>>>(images, (uint32_t)n, (const i32x4 *)frags, bias, C, acts,
                                                                                   acts_stride, counter, grab);
     return hipGetLastError();
 }

@@ -134,7 +134,7 @@ hipError_t bnmk_cnn_front(const int8_t *d_images, uint64_t n, const int8_t *d_w1
                           uint32_t acts_stride, int32_t *d_feat, bool feat_is_output, uint32_t *d_counter, uint32_t grab,
                           hipStream_t s);
 // lane = image formulation (bnm_cnn_li.hip): all three convolutions as Toeplitz products on the matrix cores, ReLUNorm fused, any
-// channel count whose records fit the LDS beside six waves (C <= 142), n_shift 4.  frags / bias: bnm_cnn_li_tables' output on the
+// channel count whose records fit the LDS beside six waves (C <= 170), n_shift 4.  frags / bias: bnm_cnn_li_tables' output on the
 // device (6 KiB + 8 bytes per channel); counter: the launch's counter block.
 void bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int8_t *frag_out, int *bias_out);
 uint32_t bnmk_cnn_li_waves(uint32_t C);      // waves per workgroup; 0: the kernel does not serve this channel count

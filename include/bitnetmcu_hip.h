@@ -173,9 +173,9 @@ BNM_API int bnm_ctx_release_stream(bnm_ctx *c, void *stream);
  * host copy threads, H2D / compute / D2H of consecutive chunks overlapped. */
 BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls,
                            int32_t *logits);
-/* CNN front end.  3 (the default up to 112 channels): the lane = image kernel - a wave owns 32 images and walks the channels, all
- * three convolutions are Toeplitz products on the matrix cores, the ReLUNorm is fused; serves up to 142 channels
- * (BNM_EUNSUPPORTED beyond); 300 + g (g = 1..16): g 32-image tiles per take from the work counter.  1 (the default beyond 112
+/* CNN front end.  3 (the default up to 170 channels): the lane = image kernel - a wave owns 32 images and walks the channels, all
+ * three convolutions are Toeplitz products on the matrix cores, the ReLUNorm is fused; serves up to 170 channels
+ * (BNM_EUNSUPPORTED beyond); 300 + g (g = 1..16): g 32-image tiles per take from the work counter.  1 (the default beyond 170
  * channels): a lane = a channel, conv1 on the matrix cores, waves take batches of 8 images from a device-wide work counter; models
  * whose channel count leaves 1..16 channels beyond a multiple of 32 (16, 48, 80 ... channels) run those channels two images per
  * work item.  2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the

@@ -26,9 +26,10 @@ bitnetmcu_amd/csrc/bnm_cnn_li.hip, written down where it can be checked against 
   stage 3  conv3, 6x6 -> 4x4 -> pool -> 2x2.  One D tile (16 of 32 rows) from K-steps 0, 1, per plane (three accumulators).
            Register quad t of half h (t = 0, 1) is pooling window u = 2t + h = (wr, wc) = (t, h); element e = position (2 wr + (e >> 1),
            2 wc + (e & 1)).  feature(c, u) = relu(max_e(acc0 + 256 acc1 + 65536 acc2) + (128 + 32768) sum(w)) >> 4.
-  ReLUNorm over an image's 4 C features (BitNetMCU_inference.c:23-72) from a COMPRESSED per-(channel, lane) record: a lane keeps
-           the running maximum mx of its own features; with sh = bitlength(mx >> 7) at the time of storing, k = max(sh - 1, 0) and
-           f' = f >> k < 256 is exact for the final shift s >= sh:  (f + (1 << s >> 1)) >> s == (f' + (1 << (s - k) >> 1)) >> (s - k).
+  ReLUNorm over an image's 4 C features (BitNetMCU_inference.c:23-72) from a COMPRESSED per-(channel, image) record: the running
+           maximum mx of the IMAGE's features so far (both lane halves: one k byte per image, 160 bytes of records per channel and
+           wave); with sh = bitlength(mx >> 7) at the time of storing, k = max(sh - 1, 0) and f' = f >> k < 256 is exact for the
+           final shift s >= sh:  (f + (1 << s >> 1)) >> s == (f' + (1 << (s - k) >> 1)) >> (s - k).
 """
 import numpy as np
 
@@ -106,7 +107,7 @@ def front_end_features(images, w1, w2, w3):
     B1 = [np.concatenate([img[:, 2 * s].T, img[:, 2 * s + 1].T]) for s in range(8)]          # each [32][N]
     feats = np.zeros((N, 4 * C), np.int64)
     rec = np.zeros((C, 2, N, 3), np.int64)          # (f'_0, f'_1, k) per channel, lane half, image
-    mx = np.zeros((2, N), np.int64)
+    mx = np.zeros(N, np.int64)
     for c in range(C):
         T1, T2, T3 = toeplitz_conv1(w1[c]), toeplitz_conv2(w2[c]), toeplitz_conv3(w3[c])
         sw2, sw3 = int(w2[c].astype(np.int64).sum()), int(w3[c].astype(np.int64).sum())
@@ -137,6 +138,7 @@ def front_end_features(images, w1, w2, w3):
                     p[2][k >> 5][k & 31] = P >> 16
         # ---- stage 3 -> features ----
         acc = [mfma(T3[:, :32], p[pl][0]) + mfma(T3[:, 32:], p[pl][1]) for pl in range(3)]
+        fh = []
         for h in range(2):
             r0, r1, r2_ = (lane_regs(a, h) for a in acc)
             f = []
@@ -144,18 +146,19 @@ def front_end_features(images, w1, w2, w3):
                 s = r0[4 * t:4 * t + 4] + 256 * r1[4 * t:4 * t + 4] + 65536 * r2_[4 * t:4 * t + 4]
                 f.append(np.maximum(s.max(axis=0) + (128 + 32768) * sw3, 0) >> 4)
                 feats[:, 4 * c + 2 * t + h] = f[-1]
-            mx[h] = np.maximum(mx[h], np.maximum(f[0], f[1]))
-            sh = np.array([int(m >> 7).bit_length() for m in mx[h]])
-            k = np.maximum(sh - 1, 0)
-            rec[c, h, :, 0], rec[c, h, :, 1], rec[c, h, :, 2] = f[0] >> k, f[1] >> k, k
+            fh.append(f)
+        mx = np.maximum(mx, np.maximum(np.maximum(fh[0][0], fh[0][1]), np.maximum(fh[1][0], fh[1][1])))
+        sh = np.array([int(m >> 7).bit_length() for m in mx])
+        k = np.maximum(sh - 1, 0)
+        for h in range(2):
+            rec[c, h, :, 0], rec[c, h, :, 1], rec[c, h, :, 2] = fh[h][0] >> k, fh[h][1] >> k, k
     return feats, (rec, mx)
 
 
 def relunorm_from_records(rec, mx):
     """The fused ReLUNorm from the compressed records: int8 [N][4C] act rows (BitNetMCU_inference.c:23-72 over all 4C features)."""
     C, _, N, _ = rec.shape
-    m = np.maximum(mx[0], mx[1])
-    s = np.array([int(v >> 7).bit_length() for v in m])
+    s = np.array([int(v >> 7).bit_length() for v in mx])
     out = np.zeros((N, 4 * C), np.int64)
     for c in range(C):
         for h in range(2):

@@ -981,7 +981,7 @@ def test_fuzz_random_cnn_models(seed, gpu_ok, orc):
         try:
             ctx.set_cnn_variant(variant)
         except b.BnmError:
-            assert variant == 3 and C > 142      # the lane = image kernel's records must fit the LDS beside six waves
+            assert variant == 3 and C > 170      # the lane = image kernel's records must fit the LDS beside six waves
             continue
         for n in (len(x), 5, 6):
             got = ctx.infer(x[:n], logits=True)
