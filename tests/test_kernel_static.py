@@ -1,5 +1,6 @@
-"""Static checks of the built gfx950 code objects (no GPU): no kernel spills, and the streamed ternary kernels' compiler-invisible
-scalar loads are never touched while in flight (profiles/check_inflight_sgprs.py)."""
+"""Static checks of the built gfx950 code objects (no GPU): no kernel spills, the streamed ternary kernels' compiler-invisible
+scalar loads are never touched while in flight (profiles/check_inflight_sgprs.py), and no vector instruction touches a register of
+an MFMA result in flight (profiles/check_mfma_hazards.py)."""
 import os
 import subprocess
 import sys
@@ -24,6 +25,23 @@ def test_ternary_chunk_loads_untouched_in_flight():
     assert r.returncode == 0, r.stdout[-2000:]
     assert " 0 instructions touch registers of a load in flight" in r.stdout
     assert " 0 instructions touch a result register in flight" in r.stdout and " 0 scalar work-counter takes" not in r.stdout
+
+
+def test_no_instruction_touches_an_mfma_result_in_flight():
+    """Inline-asm outputs allocated to the dead rows of an MFMA result are overwritten by its late write-back (hipcc pads nothing
+    in front of inline asm): round 4's lane = image CNN kernel lost operand bytes that way, one image in 50,000."""
+    sys.path.insert(0, os.path.join(util.REPO, "profiles"))
+    import check_mfma_hazards as H
+    # the checker sees the pattern that was the bug (the asm write 4 wait states behind the MFMA), not the padded one
+    mf = "v_mfma_i32_32x32x32_i8 v[14:29], v[76:79], v[84:87], v[14:29]"
+    wr = "v_lshrrev_b32_sdwa v28, v110, v117 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD"
+    assert len(H.check([mf, "v_mov_b32_e32 v78, v35", "v_mov_b32_e32 v79, v35", wr])) == 1
+    assert H.check([mf, "v_mov_b32_e32 v78, v35", "s_nop 10", wr]) == []
+    assert H.check([mf, "v_mfma_i32_32x32x32_i8 v[14:29], v[0:3], v[4:7], v[14:29]", "s_nop 11", "v_lshlrev_b32_e32 v79, 8, v14"]) == []
+    assert len(H.check([mf, "s_nop 9", "v_lshlrev_b32_e32 v79, 8, v14"])) == 1
+    r = subprocess.run([sys.executable, os.path.join(util.REPO, "profiles", "check_mfma_hazards.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert " 0 instructions touch a result register in flight" in r.stdout
 
 
 def _disassemble(obj):
