@@ -1068,6 +1068,32 @@ def test_cnn_kernels_with_full_range_conv_weights(C, gpu_ok, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("C", [48, 56])
+def test_cnn_lane_image_kernel_on_a_large_sample(C, gpu_ok, orc):
+    """Events of one image in 50,000: round 4's kernel lost a plane-2 operand dword to the late write-back of an MFMA whose dead
+    result rows the allocator had handed to an inline-asm output (tests/test_kernel_static.py has the static check) - only with
+    full-range weights, only where the pooled conv2 values pass 2^16, and not reproducibly.  300,000 images: the front end's act
+    bytes against the channel kernel (an independent implementation), twice (run-to-run identical), ids and logits of the
+    no-tap path against it as well, and the first 3,000 images against the oracle."""
+    rng = np.random.default_rng(C)
+    model = b.Model.from_header_text(_random_cnn_text(rng, C, (16, 4, 4), (96, 64), 10, lambda k: rng.integers(-128, 128, size=9 * C)))
+    n = 300_000
+    x = synth.images(3, n, DIST_U)
+    acts, outs = {}, {}
+    for key, variant in (("channel", 1), ("li", 3), ("li again", 3)):
+        ctx = b.Context(model)
+        ctx.set_cnn_variant(variant)
+        assert ctx.cnn_variant == variant
+        acts[key] = ctx.activations(x)[:, :4 * C]
+        outs[key] = ctx.infer(x, logits=True)
+        ctx.close()
+    for key in ("li", "li again"):
+        assert np.array_equal(acts[key], acts["channel"]), (C, key, int((acts[key] != acts["channel"]).sum()))
+        assert np.array_equal(outs[key][0], outs["channel"][0]) and np.array_equal(outs[key][1], outs["channel"][1]), (C, key)
+    want = util.OracleModel(model, orc).infer(x[:3000], logits=True)
+    assert np.array_equal(outs["li"][0][:3000], want[0]) and np.array_equal(outs["li"][1][:3000], want[1])
+
+
 @pytest.mark.parametrize("C,codecs,widths", [(18, (16, 4, 4), (96, 64)),      # 72 act bytes: not a multiple of 16
                                               (150, (16, 4, 4), (96, 64)),     # 600 act bytes: beyond the fused kernels, C % 4 = 2
                                               (130, (16, 16, 4), (64, 32)),    # 520
