@@ -285,11 +285,15 @@ hipError_t bnmk_cnn_front_li(const int8_t *images, uint64_t n, const void *frags
             allowed[dev] = true;
         }
     }
-    const uint64_t tiles = (n + 31) / 32, per_block = (uint64_t)waves * grab;
+    // a call with fewer tiles than the chip has wave slots spreads them over the CUs first: a wave's walk over the channels takes the
+    // same time alone or beside one other wave on its SIMD (a lone wave issues VALU at half rate), and twice as long beside three
+    const uint64_t tiles = (n + 31) / 32, cap = (uint64_t)bnm_num_cus();
+    uint32_t waves_now = (uint32_t)((tiles + cap - 1) / cap);
+    waves_now = waves_now < 1u ? 1u : waves_now > waves ? waves : waves_now;
+    const uint64_t per_block = (uint64_t)waves_now * grab;
     uint64_t blocks = (tiles + per_block - 1) / per_block;
-    const uint64_t cap = (uint64_t)bnm_num_cus();
     if (blocks > cap) blocks = cap;
-    cnn_li_kernel<<<dim3((unsigned)blocks), dim3(64 * waves), waves * C * 160u, s>>>(images, (uint32_t)n, (const i32x4 *)frags, bias, C, acts,
+    cnn_li_kernel<<<dim3((unsigned)blocks), dim3(64 * waves_now), waves_now * C * 160u, s>>>(images, (uint32_t)n, (const i32x4 *)frags, bias, C, acts,
                                                                                   acts_stride, counter, grab);
     return hipGetLastError();
 }

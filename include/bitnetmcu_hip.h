@@ -122,7 +122,9 @@ BNM_API const void *bnm_model_layer_weights(const bnm_model *m, uint32_t i); /* 
 /* device < 0: current HIP device.  Uploads the packed weights and runs the GPU unpack kernels
  * (packed words -> int8 rows -> MFMA operand fragments).  Every entry point that takes a context works on the context's
  * device and leaves the calling thread's current HIP device as it found it; the group (A) symbols run on the device that was
- * current at their first use.  A context may be shared by host threads (calls are serialised by a mutex inside). */
+ * current at their first use.  A context may be shared by host threads (calls on ONE context are serialised by a mutex inside;
+ * the reference's entry points - Inference(), the four kernel symbols - lease contexts / staging slots from pools and run
+ * concurrently from concurrent host threads, as the reference's stateless functions do). */
 BNM_API int bnm_ctx_create(const bnm_model *m, int device, bnm_ctx **out);
 BNM_API void bnm_ctx_destroy(bnm_ctx *c);
 BNM_API int bnm_ctx_device(const bnm_ctx *c);
@@ -179,7 +181,10 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
  * channels): a lane = a channel, conv1 on the matrix cores, waves take batches of 8 images from a device-wide work counter; models
  * whose channel count leaves 1..16 channels beyond a multiple of 32 (16, 48, 80 ... channels) run those channels two images per
  * work item.  2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the
- * all-VALU kernel of round 1 (the non-default values are kept for A/B measurements). */
+ * all-VALU kernel of round 1 (the non-default values are kept for A/B measurements).
+ * A context nobody has called this function on gives calls of fewer than 2 C^2 images (C = channels; one-image Inference() calls
+ * among them) to kernel 1 although it reports 3: a wave of the lane = image kernel walks all channels of its 32 images, 2 us per
+ * channel, however few images the call has; an explicit choice holds for every call size. */
 BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
 BNM_API int bnm_ctx_get_cnn_variant(const bnm_ctx *c);      /* 3, 1 or 0 */
 /* Fused kernels that hand their work out from the device-wide counter: units of one or two 32-image tiles (generic kernel,

@@ -1068,6 +1068,26 @@ def test_cnn_kernels_with_full_range_conv_weights(C, gpu_ok, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["mcu_cnn_16", "cnn_64"])
+def test_cnn_default_front_end_on_both_sides_of_the_small_call_rule(name, gpu_ok, orc):
+    """A context left to itself gives calls of fewer than 2 C^2 images to the channel kernel and larger ones to the lane = image
+    kernel (bnm_capi.cpp: a wave of the latter walks all channels, 2 us each, however few images there are): ids and logits on
+    both sides of the threshold, and with each kernel chosen explicitly, equal the oracle's."""
+    model = util.load_golden_model(name)
+    C = model.layer(0).out_channels
+    n0 = 2 * C * C
+    x = synth.images(11, n0 + 40, DIST_U)
+    want = util.OracleModel(model, orc).infer(x, logits=True)
+    for variant in (None, 3, 1):
+        ctx = b.Context(model)
+        if variant is not None:
+            ctx.set_cnn_variant(variant)
+        for n in (1, 31, n0 - 1, n0, n0 + 33):
+            got = ctx.infer(x[:n], logits=True)
+            assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (name, variant, n)
+        ctx.close()
+
+
 @pytest.mark.parametrize("C", [48, 56])
 def test_cnn_lane_image_kernel_on_a_large_sample(C, gpu_ok, orc):
     """Events of one image in 50,000: round 4's kernel lost a plane-2 operand dword to the late write-back of an MFMA whose dead
