@@ -596,6 +596,24 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     if n <= 100_000_000:
         r, _ = run("fc_logits", "fc_4bitsym_64", n, 10, 3, want_logits=True)
         hbm_entry("fc_logits", r, BYTES_PER_INFERENCE_LOGITS_10)
+        # what the same bytes cost with no arithmetic on this box: 32-image tiles read, 44 bytes per image written (an id + ten int32
+        # logits, nontemporal 16 B/lane stores of whole tiles) - a stream that mixes 13 % writes into its reads is slower per byte
+        # than the plain read (x 1.07 .. 1.13 of the byte-proportional time, profiles/r04/rw_sweep_r05e.log), and the row's distance
+        # from THAT is what the kernel itself costs.  The fastest of three shapes of the probe (tiles per batch / waves per SIMD).
+        out_probe = torch.empty(((n // 32) * 32 * 44 + 64) // 4, dtype=torch.int32, device=dev)
+        probes = {}
+        for mode, what in ((8 + 32 * 4, "8 tiles per batch, 6 waves per SIMD"), (8 + 32 * 2, "8 tiles per batch, 4 waves per SIMD"),
+                           (4, "4 tiles per batch, 2 waves per SIMD")):
+            _, rw_ms = timed_steps(torch, lambda: b.synth.stream_rw_device(images[:(n // 32) * 32], out_probe, 44, mode), 5, 2)
+            probes[what] = float(np.median(rw_ms))
+        best = min(probes, key=probes.get)
+        rw = probes[best]
+        res["fc_logits"]["roofline"]["stream_read_write"] = {
+            "ms": rw, "bytes": (n // 32) * 32 * 300, "GB/s": (n // 32) * 32 * 300 / (rw * 1e-3) / 1e9, "shape": best, "ms_by_shape": probes,
+            "vs_byte_proportional_read": rw / (stream_read["ms"] * 300 / 256) if n == stream_read["bytes"] // 256 else None,
+            "what": "bnm_stream_rw_device: the row's 256 B read + 44 B written per image, no arithmetic; median of 5 launches after 2"}
+        res["fc_logits"]["roofline"]["time_vs_stream_read_write"] = res["fc_logits"]["median_launch_ms"] / rw
+        del out_probe
     # headline model on Dist-M (MNIST-like value statistics): refill the resident set in place
     if a.dist == 0:
         b.synth.fill_device(images, first=0, dist=1)

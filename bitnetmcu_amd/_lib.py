@@ -79,6 +79,7 @@ PROTOTYPES = {
     "bnm_synth_fill_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "bnm_class_digest_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, _vp]),
     "bnm_stream_read_device": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
+    "bnm_stream_rw_device": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint32, C.c_uint32, _vp]),
     "bnm_run_synth_multi_gpu": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, C.c_uint64, _vp, C.c_uint32, C.POINTER(C.c_double)]),
     "bnm_multi_gpu_transport": (C.c_char_p, []),
     "bnm_bind_default_model": (C.c_int, [_vp]),

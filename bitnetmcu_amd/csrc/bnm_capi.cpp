@@ -1319,6 +1319,14 @@ int bnm_stream_read_device(const void *d_src, uint64_t bytes, uint32_t *d_sink, 
     return BNM_OK;
 }
 
+int bnm_stream_rw_device(const void *d_src, uint64_t n_rows, void *d_dst, uint32_t out_bytes_per_row, uint32_t mode, void *stream) {
+    if (n_rows && (!d_src || !d_dst)) return fail(BNM_EINVAL, "null pointer");
+    if (((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) return fail(BNM_EINVAL, "buffers must be 16-byte aligned");
+    if (!out_bytes_per_row || (out_bytes_per_row & 3u) || out_bytes_per_row > 4096u) return fail(BNM_EINVAL, "out_bytes_per_row: a multiple of 4 up to 4096");
+    HIP_TRY(bnmk_stream_rw(d_src, n_rows, d_dst, out_bytes_per_row, mode, (hipStream_t)stream));
+    return BNM_OK;
+}
+
 #ifdef BNM_DIAG
 // ---- diagnostic library only (bitnetmcu_amd/build.py --diag; declared in csrc/bnm_diag.h, not in the public header) ----
 int bnm_diag_stream_device(const int8_t *d_images, uint64_t n, int mode, int grid_blocks, uint32_t *d_out, void *stream) {

@@ -12,6 +12,8 @@ hipError_t bnmk_class_digest(const uint32_t *d_cls, uint64_t first, uint64_t n, 
 
 // plain 16 B/lane nontemporal read of `bytes` bytes (a multiple of 16 is read); d_sink: one device dword that is practically never written
 hipError_t bnmk_stream_read(const void *d_src, uint64_t bytes, uint32_t *d_sink, hipStream_t s);
+// mixed stream: 32-row tiles of 256-byte rows read, out_bytes_per_row (a multiple of 4... x 32 rows = whole 16-byte units) written per row
+hipError_t bnmk_stream_rw(const void *d_src, uint64_t n_rows, void *d_dst, uint32_t out_bytes_per_row, uint32_t mode, hipStream_t s);
 
 // ---- GPU unpack: packed words -> int8 rows -> MFMA A-operand fragments ------------------------
 // lo/hi: [n_output][row_stride] int8, w = lo + hi (hi != 0 only for FP1.3.0's +-128).

@@ -201,6 +201,66 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const u32x4 *__restric
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// ---- the box's mixed read / write stream rate ----------------------------------------------------------------------
+// What the inference kernels' memory traffic costs with NO arithmetic: a wave reads a tile of 32 rows of 256 bytes (8 nontemporal
+// 16 B/lane loads, as the fused kernels do) and writes the tile's 32 x out_bytes contiguous result bytes (a fold of what it
+// read) as nontemporal 16 B/lane stores - 44 bytes per row for ids + ten int32 logits.  Tiles grid-stride over the waves.
+// bench.py times it next to the logits row: an HBM stream that mixes 13 % writes into its reads is slower per byte than a pure
+// read, and this is by how much on the box at hand.
+template <int BATCH, int STORE>
+__global__ __launch_bounds__(256) void stream_rw_kernel(const u32x4 *__restrict__ src, uint64_t n_tiles, u32x4 *__restrict__ dst,
+                                                        uint32_t out16_per_tile) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    // a wave takes BATCH consecutive tiles at a time: all their reads first, then all their (contiguous) result bytes
+    for (uint64_t t = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * BATCH; t < n_tiles; t += waves * BATCH) {
+        u32x4 a[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const uint64_t tj = t + j < n_tiles ? t + j : n_tiles - 1;
+            const u32x4 *p = src + tj * 512u + lane;
+            a[j] = __builtin_nontemporal_load(p);
+#pragma unroll
+            for (int k = 1; k < 8; k++) a[j] ^= __builtin_nontemporal_load(p + 64 * k);
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            if (t + j >= n_tiles) break;
+            u32x4 *q = dst + (t + j) * out16_per_tile;
+            for (uint32_t i = lane; i < out16_per_tile; i += 64u) {
+                if constexpr (STORE == 0) __builtin_nontemporal_store(a[j], q + i);
+                else q[i] = a[j];
+            }
+        }
+    }
+}
+
+// mode: tiles per batch (1, 2, 4, 8; 0 = 2, what the dual-tile kernel does) + 16 for plain instead of nontemporal stores
+// + 32 x (waves per SIMD - 2) (default two: CUs x 2 blocks of 256 threads... see the launch)
+hipError_t bnmk_stream_rw(const void *d_src, uint64_t n_rows, void *d_dst, uint32_t out_bytes_per_row, uint32_t mode, hipStream_t s) {
+    const uint64_t tiles = n_rows / 32ull;      // (whole tiles only: a rate probe)
+    if (!tiles) return hipSuccess;
+    const uint32_t batch = (mode & 15u) ? (mode & 15u) : 2u, plain = (mode >> 4) & 1u, wps = ((mode >> 5) & 7u) + 2u;
+    const dim3 grid((unsigned)bnm_num_cus() * wps), block(256);
+    const u32x4 *src = (const u32x4 *)d_src;
+    u32x4 *dst = (u32x4 *)d_dst;
+    const uint32_t o16 = out_bytes_per_row * 2u;
+#define BNM_RW(B, S) stream_rw_kernel<B, S><<<grid, block, 0, s>>>(src, tiles, dst, o16)
+    switch (batch * 2u + plain) {
+    case 2: BNM_RW(1, 0); break;
+    case 3: BNM_RW(1, 1); break;
+    case 4: BNM_RW(2, 0); break;
+    case 5: BNM_RW(2, 1); break;
+    case 8: BNM_RW(4, 0); break;
+    case 9: BNM_RW(4, 1); break;
+    case 16: BNM_RW(8, 0); break;
+    case 17: BNM_RW(8, 1); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef BNM_RW
+    return hipGetLastError();
+}
+
 hipError_t bnmk_stream_read(const void *d_src, uint64_t bytes, uint32_t *d_sink, hipStream_t s) {
     if (bytes < 16) return hipSuccess;
     stream_read_kernel<<<dim3((unsigned)bnm_num_cus() * 8u), dim3(256), 0, s>>>((const u32x4 *)d_src, bytes / 16ull, d_sink);

@@ -67,6 +67,19 @@ def digest_device(cls, first=0, n_bins=10, stream=None, lib=None):
     return out
 
 
+def stream_rw_device(images, out, out_bytes_per_row, mode=0, stream=None, lib=None):
+    """The mixed stream probe (bnm_stream_rw_device): 32-row tiles of `images` (int8 [n, 256]) read, out_bytes_per_row bytes per row
+    written into `out` (a cuda tensor of >= n x out_bytes_per_row bytes); asynchronous."""
+    import torch
+    lib = lib or L.load()
+    assert images.is_cuda and images.is_contiguous() and out.is_cuda and out.is_contiguous()
+    n = images.shape[0]
+    assert out.numel() * out.element_size() >= n * out_bytes_per_row
+    s = stream if stream is not None else torch.cuda.current_stream(images.device)
+    L.check(lib, lib.bnm_stream_rw_device(images.data_ptr(), n, out.data_ptr(), out_bytes_per_row, mode, s.cuda_stream), "bnm_stream_rw_device")
+    return out
+
+
 def stream_read_device(tensor, sink=None, stream=None, lib=None):
     """Plain 16 B/lane nontemporal read of a cuda tensor's bytes (bnm_stream_read_device): the box's read rate, asynchronous."""
     import torch

@@ -288,6 +288,12 @@ BNM_API int bnm_class_digest_device(const uint32_t *d_cls, uint64_t first, uint6
  * one device dword the kernel practically never touches).  bench.py times it over the resident image set next to the inference
  * kernels: what an HBM-bound kernel can at best approach on the box it runs on. */
 BNM_API int bnm_stream_read_device(const void *d_src, uint64_t bytes, uint32_t *d_sink, void *stream);
+/* The box's MIXED stream rate, no arithmetic: n_rows / 32 tiles of 32 x 256 bytes read at d_src, every tile's 32 x
+ * out_bytes_per_row bytes (a multiple of 4; 44 = a class id + ten int32 logits) written contiguously at d_dst (>= n_rows x
+ * out_bytes_per_row bytes) with nontemporal 16 B/lane stores.  mode 0: what the dual-tile kernel does (a wave reads two tiles,
+ * then writes their results; two waves per SIMD); otherwise tiles per batch (1, 2, 4, 8) + 16 for plain stores + 32 x (waves per
+ * SIMD - 2).  bench.py times it next to the ids + logits row. */
+BNM_API int bnm_stream_rw_device(const void *d_src, uint64_t n_rows, void *d_dst, uint32_t out_bytes_per_row, uint32_t mode, void *stream);
 
 /* ---- multi-GPU, single process (C hosts; PyTorch hosts use one process per GPU, see bench.py) ------------------
  * Shards the global synthetic image stream [0, n_total) contiguously over the first n_gpus visible devices

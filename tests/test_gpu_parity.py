@@ -484,6 +484,26 @@ def test_input_quantisation_matches_numpy_float32(gpu_ok):
     cctx.close()
 
 
+def test_mixed_stream_probe_writes_the_fold_of_what_it_read(gpu_ok):
+    """bnm_stream_rw_device (bench.py's yardstick for the ids + logits row): every 32-row tile's 32 x 44 output bytes are the XOR
+    fold of the tile's eight 1 KiB slices, 16-byte unit i of the output = unit i mod 64 of the fold; rows beyond the last whole
+    tile are left alone."""
+    import torch
+    n = 32 * 37 + 5
+    x = torch.from_numpy(synth.images(4, n, DIST_U)).cuda()
+    tiles = n // 32
+    src = x.cpu().numpy().view(np.uint32)[:tiles * 32].reshape(tiles, 8, 64, 4)      # [tile][slice][lane][dword]
+    fold = np.bitwise_xor.reduce(src, axis=1)                                           # [tile][lane][dword]
+    units = 32 * 44 // 16
+    want = np.stack([fold[:, i % 64] for i in range(units)], axis=1).reshape(-1)
+    for mode in (0, 1, 4 + 16, 8 + 32 * 4):      # tiles per batch (37 tiles: ragged batches), plain stores, six waves per SIMD
+        out = torch.full((n * 44 // 4 + 16,), -1, dtype=torch.int32, device="cuda")
+        synth.stream_rw_device(x, out, 44, mode)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[:tiles * units * 4], want) and (got[tiles * units * 4:] == 0xFFFFFFFF).all(), mode
+
+
 def test_bench_json_contract(gpu_ok):
     """bench.py on a small N: one JSON line with the contract's keys, verified against the oracle."""
     import json
@@ -515,6 +535,8 @@ def test_bench_json_contract(gpu_ok):
         assert ex[k]["verified_vs_oracle"] is True and ex[k]["value"] > 0 and "roofline" in ex[k], k
         assert 0 < ex[k]["roofline"]["frac"] <= 1, k
     assert ex["ternary_alu"]["roofline"]["bound"] == "valu" and ex["cnn_64"]["roofline"]["bound"] == "valu"
+    # the ids + logits row next to what its bytes cost with no arithmetic on this box (bnm_stream_rw_device)
+    assert ex["fc_logits"]["roofline"]["stream_read_write"]["GB/s"] > 0 and ex["fc_logits"]["roofline"]["time_vs_stream_read_write"] > 0.5
     assert ex["ternary_alu"]["path"] == b.PATH_TERNARY_ALU and ex["ternary_mfma_generic"]["path"] == b.PATH_FUSED_MFMA
     # the VALU-bound configs quote the ALGORITHMIC fraction (MACs at 4 per dot4 lane), which can only be below the pipe's utilisation
     assert ex["ternary_alu"]["roofline"]["macs_per_image"] == 43968 and ex["cnn_64"]["roofline"]["macs_per_image"] == 236416
