@@ -190,7 +190,9 @@ def mfma_roofline(b, ctx, model, rate, kname, counters, model_key=None):
     return r
 
 
-def kernel_name(b, ctx, model):
+def kernel_name(b, ctx, model, count=None, cnn_variant_named=False):
+    """count / cnn_variant_named: a context nobody named a CNN front end on gives calls of fewer than 2 C^2 images to the channel
+    kernel whatever it reports (bnm_capi.cpp)."""
     v = ctx.variant
     fused = {3: "fused_fc_dual_kernel", 5: "fused_fc_dual_kernel", 6: "fused_fc_dual_kernel", 4: "fused_fc_generic_kernel", 7: "fused_fc_generic_kernel",
              8: "fused_fc_generic_kernel", 9: "fused_fc_regw_kernel"}.get(v, "fused_fc_kernel")
@@ -199,6 +201,9 @@ def kernel_name(b, ctx, model):
     tern = "ternary_stream_kernel" if getattr(ctx, "ternary_variant", 2) % 10 else "ternary_alu_kernel"
     k = {1: fused, 2: "fc_layer_bitserial_kernel+relunorm_kernel", 3: tern}.get(ctx.path, "?")
     cnn = {0: "cnn_front_kernel", 3: "cnn_li_kernel"}.get(getattr(ctx, "cnn_variant", 1), "cnn_front_mfma_kernel")
+    if model.kind == b.KIND_CNN and cnn == "cnn_li_kernel" and count is not None and not cnn_variant_named:
+        if count < 2 * model.layers()[0].out_channels ** 2:
+            cnn = "cnn_front_mfma_kernel"
     return k + ("+" + cnn if model.kind == b.KIND_CNN else "")
 
 
@@ -414,7 +419,7 @@ def main():
         bpi = 256 + 4 + (4 * model.num_classes if a.logits else 0)
         avg_ms = float(np.mean(launch_ms))
         achieved = n * bpi / (avg_ms * 1e-3) / 1e9
-        kname = kernel_name(b, ctx, model)
+        kname = kernel_name(b, ctx, model, n, a.cnn_variant >= 0)
         # the box's plain read rate over the same resident images, same process, same stream (bnm_stream_read_device)
         sink = torch.zeros(1, dtype=torch.int32, device=dev)
         _, rd_ms = timed_steps(torch, lambda: b.synth.stream_read_device(images, sink), 5, 2)
@@ -539,7 +544,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         res[name] = {"model": model_name, "model_source": src, "images": count, "dist": "U" if dist == 0 else "M", "steps": steps, "warmup": warmup,
                      "value": rate, "unit": "inferences/s", "avg_launch_ms": float(np.mean(ms)), "median_launch_ms": float(np.median(ms)),
                      "min_launch_ms": float(np.min(ms)),
-                     "kernel": kernel_name(b, ctx, model), "path": ctx.path, "fused_variant": ctx.variant, "verified_vs_oracle": ok,
+                     "kernel": kernel_name(b, ctx, model, count, cnn_variant >= 0), "path": ctx.path, "fused_variant": ctx.variant, "verified_vs_oracle": ok,
                      "mfma_per_image": model_mfmas_per_image(b, model) if ctx.path == b.PATH_FUSED_MFMA else None}
         if note:
             res[name]["note"] = note
