@@ -523,7 +523,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         if c and "valu_per_image" in c:
             r.update({"valu_per_image": c["valu_per_image"],
                       "pipe_utilisation": rate * c["valu_per_image"] / VALU_PEAK_WAVE_INSTR_PER_S,
-                      "valu_per_image_source": f"instruction count replayed from profiles/pmc_counters.json (SQ_INSTS_VALU, pass {c.get('source')})"})
+                      "valu_per_image_source": f"instruction count replayed from profiles/pmc_counters.json (SQ_INSTS_VALU, which counts MFMA instructions too; pass {c.get('source')})"})
         return r
 
     def run(name, model_name, count, steps, warmup, dist=0, want_logits=False, variant=-1, path=0, note=None, cnn_variant=-1):
