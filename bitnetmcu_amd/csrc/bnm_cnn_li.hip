@@ -37,6 +37,7 @@ BNM_DEVICE i32x16 mfma0(const i32x4 &a, const i32x4 &b) { return __builtin_amdgc
 BNM_DEVICE i32x16 mfma(const i32x4 &a, const i32x4 &b, const i32x16 &c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
 // relu of two 15-bit values as one packed pair: [max(a, 0) | max(b, 0) << 16]  (v_cvt_pk_i16_i32 + v_pk_max_i16)
 BNM_DEVICE uint32_t relu_pair16(int a, int b) {
     const s16x2 p = __builtin_amdgcn_cvt_pk_i16(a, b), z = {0, 0};
@@ -167,7 +168,12 @@ __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__r
                 const i32x16 d1 = mfma(a3b, pl[1][1], mfma0(a3a, pl[1][0]));
                 int s[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) s[i] = d0[i] + (d1[i] << 8);
+                for (int i = 0; i < 8; i++) {
+                    s[i] = d0[i] + (d1[i] << 8);
+                    // (an opaque value: left to itself hipcc reassociates the three-plane sum into two shifts + one v_add3 per value;
+                    // two v_lshl_add_u32 do it.  The statement holds no instruction - nothing a late MFMA write-back could meet.)
+                    asm volatile("" : "+v"(s[i]));
+                }
                 const i32x16 d2 = mfma(a3b, pl[2][1], mfma0(a3a, pl[2][0]));
 #pragma unroll
                 for (int i = 0; i < 8; i++) s[i] += d2[i] << 16;
@@ -196,10 +202,14 @@ __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__r
         int8_t *row = acts + (uint64_t)(valid ? img_out : n - 1u) * acts_stride;
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t w = rec[c * 64u];
-            const int d = s_all - (int)rec_k[c * 32u], rnd = (1 << d) >> 1;
-            const int o0 = min((int)((w & 255u) + (uint32_t)rnd) >> d, 127), o1 = min((int)(((w >> 8) & 255u) + (uint32_t)rnd) >> d, 127);
+            // both features of the record at once, as 16-bit halves: (f + (1 << d >> 1)) >> d == (((2 f) >> d) + 1) >> 1 for every
+            // d >= 0 (f < 256); a packed shift takes four bits of its amount, and from d = 10 on the result is 0 anyway
+            const uint32_t d = (uint32_t)min(s_all - (int)rec_k[c * 32u], 15);
+            const u16x2v dd = {(unsigned short)d, (unsigned short)d}, one = {1, 1}, top = {127, 127};
+            u16x2v v = __builtin_bit_cast(u16x2v, __builtin_amdgcn_perm(0u, w, 0x0c010c00u) << 1);      // [2 f0, 2 f1]
+            v = __builtin_elementwise_min((u16x2v)(((v >> dd) + one) >> one), top);
             // act bytes of channel c: [window 0, 1, 2, 3] = [o0 of half 0, o0 of half 1, o1 of half 0, o1 of half 1]
-            const int x = (o0 | (o1 << 16)) << (8 * h);
+            const int x = (int)(__builtin_bit_cast(uint32_t, v) << (8 * h));
             auto both = __builtin_amdgcn_permlane32_swap(x, x, false, false);
             const int word = (int)both[0] | (int)both[1];
             if (valid && h == 0) *(int *)(row + 4u * c) = word;
