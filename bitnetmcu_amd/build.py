@@ -37,28 +37,43 @@ def newer(src_list, out):
 SOURCES = (("bnm_fused_fc.hip", True), ("bnm_fused_regw.hip", True, ("-mllvm", "-amdgpu-mfma-vgpr-form")), ("bnm_fused_generic.hip", True), ("bnm_fused_generic_m2.hip", True),
            ("bnm_fused_generic_m4.hip", True), ("bnm_fused_generic_m6_k8.hip", True), ("bnm_fused_generic_m8_k2.hip", True), ("bnm_fused_generic_m8_k4.hip", True),
            ("bnm_fused_generic_m8_k8.hip", True), ("bnm_fused_generic_m8_k16.hip", True), ("bnm_fused_generic_m2_t2.hip", True), ("bnm_cnn.hip", True, ("-mllvm", "-amdgpu-mfma-vgpr-form")), ("bnm_cnn_li.hip", True), ("bnm_ternary.hip", True), ("bnm_ternary_s32.hip", True), ("bnm_ternary_s64.hip", True), ("bnm_ternary_s96.hip", True), ("bnm_ternary_s128.hip", True),
-           ("bnm_layerwise.hip", True), ("bnm_support.hip", True), ("bnm_qat.hip", True), ("bnm_capi.cpp", False),
+           ("bnm_layerwise.hip", True), ("bnm_support.hip", True), ("bnm_qat.hip", True),
+           ("bnm_fused_f32.hip", True), ("bnm_fused_f32_m2.hip", True), ("bnm_fused_f32_m4.hip", True),
+           ("bnm_capi.cpp", False), ("bnm_capi_ctx.cpp", False), ("bnm_capi_infer.cpp", False), ("bnm_capi_host.cpp", False),
+           ("bnm_capi_float.cpp", False), ("bnm_capi_qat.cpp", False), ("bnm_capi_multigpu.cpp", False), ("bnm_capi_symbols.cpp", False),
            ("bnm_model.cpp", False))
 DIAG_SOURCES = (("bnm_diag.hip", True),)      # diagnostic library only (--diag / --diag-timing)
 
 
+def deps_of(obj):
+    """Prerequisites recorded by the compiler (-MD) beside an object, or None when there is no record."""
+    d = os.path.splitext(obj)[0] + ".d"
+    if not os.path.exists(d):
+        return None
+    text = open(d).read().replace("\\\n", " ")
+    if ":" not in text:
+        return None
+    return [t for t in text.split(":", 1)[1].split() if not t.startswith("/opt/rocm") and not t.startswith("/usr/")]
+
+
 def objects(force=False, extra_flags=(), obj_dir=None, sources=SOURCES):
-    """Compile what is out of date; prints one 'build: compiled|reused <object>' line per translation unit so that a
-    build log shows whether the compiler actually ran (BNM_FORCE_BUILD=1 or --force recompiles everything)."""
+    """Compile what is out of date - a translation unit is rebuilt when one of the files IT includes (the compiler's -MD record)
+    is newer than its object; prints one 'build: compiled|reused <object>' line per translation unit so that a build log
+    shows whether the compiler actually ran (BNM_FORCE_BUILD=1 or --force recompiles everything)."""
     obj_dir = obj_dir or OBJ
     force = force or os.environ.get("BNM_FORCE_BUILD") == "1"
     os.makedirs(obj_dir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".hpp"))] + \
-           [os.path.join(HERE, "..", "include", "bitnetmcu_hip.h")]
     out, jobs = [], []
     for entry in sources:
         src, is_hip, file_flags = entry[0], entry[1], (entry[2] if len(entry) > 2 else ())
         s = os.path.join(CSRC, src)
         o = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
-        if force or newer([s] + hdrs, o):
+        deps = deps_of(o)
+        if force or deps is None or any(not os.path.exists(d) for d in deps) or newer([s] + deps, o):
             if os.path.exists(o):
                 os.remove(o)          # a failed compile must not leave an older object behind for the link step
-            cmd = [HIPCC, f"--offload-arch={ARCH}"] + CXXFLAGS + list(extra_flags) + list(file_flags) + ["-c", s, "-o", o]
+            cmd = [HIPCC, f"--offload-arch={ARCH}"] + CXXFLAGS + list(extra_flags) + list(file_flags) + \
+                  ["-MD", "-MF", os.path.splitext(o)[0] + ".d", "-c", s, "-o", o]
             if not is_hip:
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")

@@ -1,0 +1,39 @@
+// C ABI, float inputs: the reference's Python-side input quantisation on the GPU (test_inference.py:140-141) and float images ->
+// class ids in one call.
+#include "bnm_capi_internal.hpp"
+
+using namespace bnm_internal;
+
+extern "C" {
+
+int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_out, void *stream) {
+    if (n && (!d_x || !d_out)) return fail(BNM_EINVAL, "null pointer");
+    if (((uintptr_t)d_x & 15u) || ((uintptr_t)d_out & 3u)) return fail(BNM_EINVAL, "d_x must be 16-byte aligned");
+    HIP_TRY(bnmk_quantize_input(d_x, n, d_out, (hipStream_t)stream));
+    return BNM_OK;
+}
+
+int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d_cls, int32_t *d_logits, void *stream) {
+    if (!c) return fail(BNM_EINVAL, "null ctx");
+    if (!n) return BNM_OK;
+    if (!d_x || !d_cls) return fail(BNM_EINVAL, "null device pointer");
+    if ((uintptr_t)d_x & 15u) return fail(BNM_EINVAL, "d_x must be 16-byte aligned");
+    std::lock_guard<std::mutex> g(c->mu);
+    DeviceGuard dg(c->device);
+    HIP_TRY(dg.err);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t ncls = c->model.num_classes();
+    // chunks of 2^22 images (1 GiB of int8 scratch per stream): quantise, then the model's kernels, in stream order
+    const uint64_t chunk = 1ull << 22;
+    DevBuf &q8 = stream_scratch(c, s).q8;
+    if (int e = q8.ensure((size_t)(n < chunk ? n : chunk) * 256 + 64)) return e;
+    for (uint64_t off = 0; off < n; off += chunk) {
+        const uint64_t cn = n - off < chunk ? n - off : chunk;
+        HIP_TRY(bnmk_quantize_input(d_x + off * 256, cn, (int8_t *)q8.p, s));
+        if (int e = infer_device_locked(c, (const int8_t *)q8.p, cn, d_cls + off, d_logits ? d_logits + off * ncls : nullptr, nullptr, 0, s))
+            return e;
+    }
+    return BNM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+// C ABI, multi-GPU driver for C hosts: one host thread and one single-process RCCL communicator per GPU.
+#include "bnm_capi_internal.hpp"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+using namespace bnm_internal;
+
+extern "C" {
+
+// ---- RCCL, bound at run time ---------------------------------------------------------------------------------------
+// Only bnm_run_synth_multi_gpu needs it, so the library does not link librccl (a Bitnet_inf.dll must load wherever the HIP
+// runtime does): dlopen at first use.  Types come from <rccl/rccl.h>, the entry points through these pointers.
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok() const { return CommInitAll && CommDestroy && Broadcast && AllReduce && GetErrorString; }
+};
+static const Rccl &rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        if (std::getenv("BNM_NO_RCCL")) return x;      // (tests: exercise the host-transport fallback)
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.lib) break;
+        }
+        if (!x.lib) return x;
+        x.CommInitAll = (decltype(x.CommInitAll))dlsym(x.lib, "ncclCommInitAll");
+        x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.lib, "ncclCommDestroy");
+        x.Broadcast = (decltype(x.Broadcast))dlsym(x.lib, "ncclBroadcast");
+        x.AllReduce = (decltype(x.AllReduce))dlsym(x.lib, "ncclAllReduce");
+        x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.lib, "ncclGetErrorString");
+        return x;
+    }();
+    return r;
+}
+static thread_local const char *g_multi_gpu_transport = "none";
+const char *bnm_multi_gpu_transport(void) { return g_multi_gpu_transport; }
+
+// SURVEY.md 8(e) / north_star: "batch-shard over xGMI with RCCL model bcast".  One HOST THREAD per device (device setup, the
+// launch and the wait of one GPU never sit behind another GPU's), one single-process RCCL communicator per device
+// (ncclCommInitAll):
+//   * the model leaves rank 0 as its BNMBLOB (bnm_model_to_blob, ~13 KB) through ONE ncclBroadcast over xGMI; ranks > 0 rebuild
+//     their model from the bytes they received (bnm_model_from_blob) - the host uploads it to device 0 only;
+//   * every rank generates its own contiguous shard of the synthetic stream on its own GPU (no image byte crosses a link) and
+//     runs the whole-model path on it: an untimed pass, a host barrier, the timed pass;
+//   * the order-independent digest + class histogram of the shards meet in ONE ncclAllReduce (uint64 sum, <= 65 words).
+// Without a loadable librccl (or BNM_NO_RCCL set) the same threads run with the host as transport: it uploads the model to
+// every device and adds the digests itself; bnm_multi_gpu_transport() says which one the last call used ("rccl" / "host").
+int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, int dist, uint64_t seed, uint64_t *digest_hist,
+                            uint32_t n_bins, double *seconds) {
+    if (!m || !digest_hist || n_bins > 64) return fail(BNM_EINVAL, "bad argument");
+    if (dist != BNM_DIST_U && dist != BNM_DIST_M) return fail(BNM_EINVAL, "dist must be 0 or 1");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(BNM_EHIP, "no HIP device visible");
+    int caller_dev = 0;
+    if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = 0;
+    struct Restore {       // RCCL's init and the setup below touch every device: the caller's current device comes back at every exit
+        int dev;
+        ~Restore() { (void)hipSetDevice(dev); }
+    } restore{caller_dev};
+    const int G = (n_gpus <= 0 || n_gpus > ndev) ? ndev : n_gpus;
+    const Rccl &nc = rccl();
+    std::vector<ncclComm_t> comms(G, nullptr);
+    bool use_rccl = nc.ok();
+    if (use_rccl) {
+        std::vector<int> devs(G);
+        for (int g = 0; g < G; g++) devs[g] = g;
+        ncclResult_t r = nc.CommInitAll(comms.data(), G, devs.data());
+        if (r != ncclSuccess) return fail(BNM_EHIP, std::string("ncclCommInitAll: ") + nc.GetErrorString(r));
+    }
+    g_multi_gpu_transport = use_rccl ? "rccl" : "host";
+    const size_t blob_bytes = bnm_model_blob_size(m);
+    std::vector<uint8_t> blob0(blob_bytes);
+    if (bnm_model_to_blob(m, blob0.data(), blob_bytes) != BNM_OK) return fail(BNM_EINVAL, "model does not serialise");
+
+    // a reusable host barrier for the rank threads; `failed` is examined behind it, so that either every rank enters the next
+    // collective or none does
+    struct Barrier {
+        std::mutex mu;
+        std::condition_variable cv;
+        int n, waiting = 0;
+        uint64_t gen = 0;
+        explicit Barrier(int n_) : n(n_) {}
+        void wait() {
+            std::unique_lock<std::mutex> l(mu);
+            const uint64_t my = gen;
+            if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); }
+            else cv.wait(l, [&] { return gen != my; });
+        }
+    } barrier(G);
+    std::atomic<bool> failed{false};
+    std::vector<std::string> errors(G);
+    std::vector<double> elapsed(G, 0.0);
+    std::vector<std::vector<uint64_t>> host_digest(G, std::vector<uint64_t>(65, 0));
+    const uint64_t base = n_total / G, rem = n_total % G;      // contiguous shards differing by at most one image (dist.shard_range)
+
+    auto rank_main = [&](int g) {
+        auto bad = [&](const std::string &what) { errors[g] = "GPU " + std::to_string(g) + ": " + what; failed = true; };
+        auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess) bad(std::string(what) + ": " + hipGetErrorString(e)); return e == hipSuccess; };
+        auto nccl_ok = [&](ncclResult_t r, const char *what) { if (r != ncclSuccess) bad(std::string(what) + ": " + nc.GetErrorString(r)); return r == ncclSuccess; };
+        const uint64_t first = (uint64_t)g * base + ((uint64_t)g < rem ? (uint64_t)g : rem), count = base + ((uint64_t)g < rem ? 1 : 0);
+        hipStream_t st = nullptr;
+        bnm_model *mine = nullptr;
+        bnm_ctx *ctx = nullptr;
+        ScopedDev d_blob, img, cls, dig;
+        bool up = hip_ok(hipSetDevice(g), "hipSetDevice") && hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate") &&
+                  d_blob.ensure(blob_bytes) == BNM_OK;
+        if (!up && !failed) bad("device setup failed");
+        // ---- the model: rank 0's blob to everybody ----------------------------------------------------------------
+        if (up && (g == 0 || !use_rccl)) hip_ok(hipMemcpyAsync(d_blob.p, blob0.data(), blob_bytes, hipMemcpyHostToDevice, st), "blob upload");
+        barrier.wait();
+        if (!failed && use_rccl)
+            nccl_ok(nc.Broadcast(d_blob.p, d_blob.p, blob_bytes, ncclUint8, 0, comms[g], st), "ncclBroadcast(model blob)");
+        std::vector<uint8_t> got(blob_bytes);
+        if (!failed && hip_ok(hipMemcpyAsync(got.data(), d_blob.p, blob_bytes, hipMemcpyDeviceToHost, st), "blob download") &&
+            hip_ok(hipStreamSynchronize(st), "model broadcast")) {
+            // every rank - the root too - builds its model from the bytes that came out of the collective
+            if (bnm_model_from_blob(got.data(), blob_bytes, &mine) != BNM_OK) bad(std::string("received blob does not parse: ") + bnm_last_error());
+            else if (bnm_ctx_create(mine, g, &ctx) != BNM_OK) bad(std::string("bnm_ctx_create: ") + bnm_last_error());
+        }
+        // ---- the shard: generated where it is consumed -----------------------------------------------------------
+        if (!failed && (img.ensure((size_t)(count ? count : 1) * 256) != BNM_OK || cls.ensure((size_t)(count ? count : 1) * 4) != BNM_OK ||
+                        dig.ensure(65 * 8) != BNM_OK)) bad("shard buffers");
+        if (!failed) {
+            hip_ok(hipMemsetAsync(dig.p, 0, 65 * 8, st), "hipMemsetAsync");
+            hip_ok(bnmk_synth_fill((int8_t *)img.p, first, count, seed, dist, st), "bnmk_synth_fill");
+            // one untimed pass first (clock ramp, code upload, first touch of the counters): `seconds` then is a warm launch
+            if (bnm_infer_device(ctx, (const int8_t *)img.p, count, (uint32_t *)cls.p, nullptr, st) != BNM_OK) bad(bnm_last_error());
+            hip_ok(hipStreamSynchronize(st), "warm-up pass");
+        }
+        barrier.wait();
+        // ---- the timed pass: all ranks start together, each stops its own clock -------------------------------------
+        if (!failed) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (bnm_infer_device(ctx, (const int8_t *)img.p, count, (uint32_t *)cls.p, nullptr, st) != BNM_OK) bad(bnm_last_error());
+            hip_ok(hipStreamSynchronize(st), "kernel execution");
+            elapsed[g] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            hip_ok(bnmk_class_digest((const uint32_t *)cls.p, first, count, (uint64_t *)dig.p, n_bins, st), "bnmk_class_digest");
+            hip_ok(hipStreamSynchronize(st), "digest");
+        }
+        barrier.wait();
+        // ---- digest + histogram: one all-reduce ---------------------------------------------------------------------
+        if (!failed && use_rccl)
+            nccl_ok(nc.AllReduce(dig.p, dig.p, 1 + n_bins, ncclUint64, ncclSum, comms[g], st), "ncclAllReduce(digest)");
+        if (!failed && (g == 0 || !use_rccl)) {
+            hip_ok(hipMemcpyAsync(host_digest[g].data(), dig.p, sizeof(uint64_t) * (1 + n_bins), hipMemcpyDeviceToHost, st), "digest download");
+        }
+        if (st) (void)hipStreamSynchronize(st);
+        if (ctx) bnm_ctx_destroy(ctx);
+        if (mine) bnm_model_free(mine);
+        d_blob.release(); img.release(); cls.release(); dig.release();
+        if (st) (void)hipStreamDestroy(st);
+    };
+    std::vector<std::thread> threads;
+    for (int g = 1; g < G; g++) threads.emplace_back(rank_main, g);
+    rank_main(0);
+    for (auto &t : threads) t.join();
+    if (use_rccl)
+        for (int g = 0; g < G; g++) if (comms[g]) (void)nc.CommDestroy(comms[g]);
+    if (failed) {
+        std::string all;
+        for (auto &e : errors) if (!e.empty()) all += (all.empty() ? "" : "; ") + e;
+        return fail(BNM_EHIP, all.empty() ? "multi-GPU run failed" : all);
+    }
+    std::memset(digest_hist, 0, sizeof(uint64_t) * (1 + n_bins));
+    for (int g = 0; g < (use_rccl ? 1 : G); g++)      // host transport: the sum of the shards' digests, here
+        for (uint32_t k = 0; k <= n_bins; k++) digest_hist[k] += host_digest[g][k];
+    if (seconds) {
+        *seconds = 0.0;
+        for (double e : elapsed) *seconds = e > *seconds ? e : *seconds;      // the slowest rank
+    }
+    return G;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// C ABI, QAT forward ops: argument checks in front of bnm_qat.hip.
+#include "bnm_capi_internal.hpp"
+
+using namespace bnm_internal;
+
+extern "C" {
+
+uint64_t bnm_qat_workspace_bytes(uint32_t d, uint32_t k) { return bnmk_qat_workspace_bytes(d, k); }
+
+int bnm_qat_bitlinear_forward_device(const float *d_x, uint64_t n, uint32_t d, const float *d_w, uint32_t k, const float *d_s,
+                                     uint32_t s_count, int quant_type, int norm_type, float *d_y, void *d_workspace,
+                                     uint64_t workspace_bytes, float *d_x_int_out, float *d_x_scale_out, float *d_w_deq_out,
+                                     void *stream) {
+    if (!d_w || !d_s || !d_workspace || (n && (!d_x || !d_y))) return fail(BNM_EINVAL, "null pointer");
+    if (d == 0 || k == 0 || d > 1024u) return fail(BNM_EINVAL, "need 1 <= d <= 1024 and k >= 1");
+    if (s_count != 1u && s_count != k) return fail(BNM_EINVAL, "s_count must be 1 (PerTensor) or k (PerOutput)");
+    if (quant_type < BNM_QAT_NONE || quant_type > BNM_QAT_8BIT) return fail(BNM_EINVAL, "unknown quant_type");
+    if (norm_type < BNM_QAT_NORM_RMS || norm_type > BNM_QAT_NORM_NONE) return fail(BNM_EINVAL, "unknown norm_type");
+    if (workspace_bytes < bnmk_qat_workspace_bytes(d, k)) return fail(BNM_EINVAL, "workspace too small (bnm_qat_workspace_bytes)");
+    if ((uintptr_t)d_workspace & 3u) return fail(BNM_EINVAL, "workspace must be 4-byte aligned");
+    HIP_TRY(bnmk_qat_bitlinear_forward(d_x, n, d, d_w, k, d_s, s_count, quant_type, norm_type, d_y, (float *)d_workspace,
+                                       d_x_int_out, d_x_scale_out, d_w_deq_out, (hipStream_t)stream));
+    return BNM_OK;
+}
+
+int bnm_qat_bitconv2d_forward_device(const float *d_x, uint64_t n, uint32_t cin, uint32_t h, uint32_t w, const float *d_w,
+                                     uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad, uint32_t stride, uint32_t groups,
+                                     const float *d_s, int quant_type, int norm_type, float *d_y, void *d_workspace,
+                                     uint64_t workspace_bytes, void *stream) {
+    if (!d_w || !d_s || !d_workspace || (n && (!d_x || !d_y))) return fail(BNM_EINVAL, "null pointer");
+    if (!cin || !cout || !kh || !kw || !h || !w || !stride || !groups) return fail(BNM_EINVAL, "zero dimension");
+    if (cin % groups || cout % groups) return fail(BNM_EINVAL, "in_channels and out_channels must be multiples of groups");
+    if (h + 2u * pad < kh || w + 2u * pad < kw) return fail(BNM_EINVAL, "kernel larger than the padded plane");
+    if (quant_type < BNM_QAT_NONE || quant_type > BNM_QAT_8BIT) return fail(BNM_EINVAL, "unknown quant_type");
+    if (norm_type != BNM_QAT_NORM_RMS && norm_type != BNM_QAT_NORM_NONE) return fail(BNM_EINVAL, "norm_type must be RMS or NONE");
+    if (n * groups > 0x7fffffffull) return fail(BNM_EINVAL, "n * groups too large for one launch");
+    if (bnmk_qat_bitconv2d_lds_bytes(cin, h, w, cout, kh, kw, pad, groups) > 160u * 1024u)
+        return fail(BNM_EUNSUPPORTED, "a group's input planes + taps exceed 160 KiB of LDS");
+    if (workspace_bytes < bnmk_qat_workspace_bytes((cin / groups) * kh * kw, cout))
+        return fail(BNM_EINVAL, "workspace too small (bnm_qat_workspace_bytes((cin / groups) * kh * kw, cout))");
+    HIP_TRY(bnmk_qat_bitconv2d_forward(d_x, n, cin, h, w, d_w, cout, kh, kw, pad, stride, groups, d_s, quant_type, norm_type, d_y,
+                                       (float *)d_workspace, (hipStream_t)stream));
+    return BNM_OK;
+}
+
+}  // extern "C"

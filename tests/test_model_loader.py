@@ -7,7 +7,7 @@ import pytest
 
 import util
 from util import GOLDEN, MODEL_NAMES, REPO
-from headerwriter import write_header
+from bitnetmcu_amd.headerwriter import write_header
 from bitnetmcu_amd import Model, BnmError, KIND_CNN, KIND_FC
 
 
