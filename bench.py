@@ -33,6 +33,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 BYTES_PER_INFERENCE = 260      # 256 B image read + 4 B class id written (SURVEY.md §8d / DESIGN.md)
 BYTES_PER_INFERENCE_LOGITS_10 = 300
+BYTES_PER_INFERENCE_FLOAT = 1028   # float-input row: 256 float32 read + 4 B class id written (fused)
 # VALU issue roofline: one wave64 VALU instruction occupies its SIMD for 4 cycles (measured: SQ_ACTIVE_INST_VALU =
 # 4.0 cycles per instruction, profiles/r01/rocprof_r01f_ternary_cnn.md); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
 VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.0
@@ -300,10 +301,12 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="fused kernel variant (-1 = default; 4 = generic kernel)")
     ap.add_argument("--grid", type=int, default=0, help="workgroups (0 = default)")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 fused MFMA, 2 layer-wise ALU, 3 ternary ALU")
-    ap.add_argument("--cnn-variant", type=int, default=-1, help="CNN front end: 1 conv1 on MFMA (default), 0 all-VALU kernel of round 1")
+    ap.add_argument("--cnn-variant", type=int, default=-1, help="CNN front end: 3 the lane = image kernel (the default up to 170 channels; calls of fewer than 2 C^2 images then go to 1), "
+                                                                  "300 + g: the same with g tiles per take, 1 a lane = a channel with conv1 on the matrix cores, 0 round 1's all-VALU kernel")
     ap.add_argument("--ternary-variant", type=int, default=-1,
                     help="ternary ALU kernel: 2 streamed weights, two images per lane (default), 1 one image per lane, 0 round 1's kernel")
     ap.add_argument("--work-batch", type=int, default=0, help="fused kernels: tiles / pairs per take from the work counter (0 = default)")
+    ap.add_argument("--float-images", type=int, default=100_000_000, help="images of the float-input rows (102.4 GB of float32 at 1e8; 0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -493,6 +496,13 @@ def main():
                 # configs[2] / configs[3]: the reference's CPU path on the same host cores, a quarter of the headline's sample each
                 for row, name in (("ternary_alu", "tern_96"), ("cnn_64", "cnn_64")):
                     out["extra_configs"][row]["cpu_baseline"] = cpu_baseline(b, name, 0, max(1.0, a.cpu_seconds / 4))
+        if "extra_configs" in out:
+            # every row once more in a few characters: inside "roofline" (an object the driver keeps whole) and as the LAST key of
+            # the line (the driver also keeps the line's tail)
+            rows = {k: [float(f"{v['value']:.4g}"), v["roofline"]["bound"], round(v["roofline"]["frac"], 4), v["verified_vs_oracle"]]
+                    for k, v in out["extra_configs"].items() if "roofline" in v}
+            out["roofline"]["rows"] = {"format": "[inferences/s, binding roofline, fraction of it, verified vs oracle]", **rows}
+            out["summary_rows"] = rows
         print(json.dumps(out), flush=True)
     if distributed:
         td.barrier()
@@ -560,6 +570,51 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
             per = res[name].pop("mfma_per_image")
             res[name]["roofline"]["mfma"] = {"per_image": per, "achieved_per_s": rate * per, "peak_per_s": MFMA_I8_32X32X32_PEAK_PER_S,
                                              "frac": rate * per / MFMA_I8_32X32X32_PEAK_PER_S}
+
+    def float_row(name, model_name, count, steps, warmup, mode, note):
+        """Float images in, class ids out (bnm_infer_float_device).  mode 0: the library's choice - ONE kernel where the fused
+        float-input kernel exists; mode 2: bnm_quantize_input_device + the model's kernels (int8 round trip through HBM)."""
+        model, src = load_model_through_the_text_parser(b, model_name)
+        ctx = b.Context(model, device=dev.index)
+        ctx.set_float_mode(mode)
+        xf = b.synth.float_images_device(images[:count])
+        c = cls[:count]
+        torch.cuda.synchronize()
+        _, ms = timed_steps(torch, lambda: ctx.infer_float_device(xf, c), steps, warmup)
+        rate = count / (float(np.mean(ms)) * 1e-3)
+        ok = None if a.no_verify else ck.verify_float_sample(torch, model, xf, c, None, count)
+        # the box's plain read of the same float bytes, same process
+        sink = torch.zeros(1, dtype=torch.int32, device=dev)
+        _, rd_ms = timed_steps(torch, lambda: b.synth.stream_read_device(xf, sink), 3, 1)
+        rd = float(np.median(rd_ms))
+        fused = ctx.float_fused
+        bpi = BYTES_PER_INFERENCE_FLOAT
+        g = rate * bpi / 1e9
+        res[name] = {"model": model_name, "model_source": src, "images": count, "dist": "U", "steps": steps, "warmup": warmup,
+                     "input": "float32 [n][256] resident in HBM: the synthetic int8 images x 1/127 (bitnetmcu_amd/synth.py float_images)",
+                     "value": rate, "unit": "inferences/s", "avg_launch_ms": float(np.mean(ms)), "median_launch_ms": float(np.median(ms)),
+                     "min_launch_ms": float(np.min(ms)),
+                     "kernel": "fused_fc_f32_kernel" if fused else "quantize_input_kernel+" + kernel_name(b, ctx, model, count),
+                     "launches_per_step": 1 if fused else 2 * ((count + (1 << 22) - 1) >> 22), "path": ctx.path, "verified_vs_oracle": ok,
+                     "note": note,
+                     "roofline": {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_inference": bpi,
+                                  "moved_bytes_per_inference": bpi if fused else bpi + 512,
+                                  "stream_read": {"ms": rd, "bytes": count * 1024, "GB/s": count * 1024 / (rd * 1e-3) / 1e9},
+                                  "time_vs_stream_read": float(np.median(ms)) / rd}}
+        per = model_mfmas_per_image(b, model)
+        res[name]["roofline"]["mfma"] = {"per_image": per, "achieved_per_s": rate * per, "peak_per_s": MFMA_I8_32X32X32_PEAK_PER_S,
+                                         "frac": rate * per / MFMA_I8_32X32X32_PEAK_PER_S}
+        ctx.close()
+        del xf
+        torch.cuda.empty_cache()
+
+    # SURVEY 8(f) row 1: the reference's Python-side input quantisation (test_inference.py:140-141) fused into the FC kernel
+    n_f = min(n, a.float_images)
+    if n_f > 0:
+        float_row("fc_float_input", "fc_4bitsym_64", n_f, 10, 3, 0, "float images -> class ids, ONE kernel (bnm_fused_f32_kernel.hpp): HBM roofline on 1,028 B per inference")
+        float_row("fc_float_input_two_kernels", "fc_4bitsym_64", n_f, 3, 1, 2, "the same call as quantise + infer (1,540 B moved per inference): what the fused kernel replaces")
+        float_row("tern_float_input", "tern_96", n_f, 5, 2, 0, "the 4-tile class of the fused float-input kernel (ternary 96-96-96)")
 
     n_cnn = min(n, 10_000_000)
     # configs[2]: ternary 96-96-96, bit-unpack / sign-accumulate ALU kernel, no MFMA — bound by the VALU issue rate

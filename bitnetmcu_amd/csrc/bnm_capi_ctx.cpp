@@ -374,6 +374,7 @@ int ctx_build(bnm_ctx *c) {
         // the register-resident-weight kernel takes whole 64-image pairs; the generic kernel finishes its calls
         c->regw_ok = c->regw_ok && c->generic_ok;
         c->fused_ok = c->table_ok || c->generic_ok;
+        c->f32_ok = m.kind == BNM_KIND_FC && c->generic_ok && bnmk_fused_f32_supported(c->gdesc, sh.dbl, 0);
     }
     // ---- ternary ALU path ------------------------------------------------------------------------------
     if (m.kind == BNM_KIND_FC && all_tern && nfc == 4) {
@@ -495,6 +496,23 @@ int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
     c->cnn_variant = variant == 0 ? 0 : 1;
     c->cnn_grab = variant == 2 ? 0u : variant > 100 ? (uint32_t)(variant - 100) : 8u;
     return BNM_OK;
+}
+
+int bnm_ctx_set_float_mode(bnm_ctx *c, int mode, int groups) {
+    if (!c || mode < 0 || mode > 2 || (groups != 0 && groups != 2 && groups != 4)) return fail(BNM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (mode == 1 && !c->f32_ok)
+        return fail(BNM_EUNSUPPORTED, "the fused float-input kernel serves FC models whose layers are at most 128 wide");
+    if (groups && c->f32_ok && !bnmk_fused_f32_supported(c->gdesc, c->shape.dbl, groups))
+        return fail(BNM_EUNSUPPORTED, "this many groups in flight are not instantiated for the model's tile class");
+    c->float_mode = mode;
+    c->f32_groups = groups;
+    return BNM_OK;
+}
+
+int bnm_ctx_float_fused(const bnm_ctx *c) {
+    if (!c) return BNM_EINVAL;
+    return (c->f32_ok && c->path == BNM_PATH_FUSED_MFMA && c->float_mode != 2) ? 1 : 0;
 }
 
 int bnm_ctx_set_work_batch(bnm_ctx *c, int tiles) {

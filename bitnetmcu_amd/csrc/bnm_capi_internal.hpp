@@ -200,6 +200,10 @@ struct bnm_ctx {
     void *frags = nullptr, *gfrags = nullptr;
     uint32_t in_width = 256;    // bytes of one input row of the FC stack (256, or 4*C behind the CNN front end)
     int variant = -1, grid_blocks = 0;
+    // float inputs (bnm_infer_float_device): the fused float-input kernel serves this model (FC, 256-value rows, 2- / 4-tile class)
+    bool f32_ok = false;
+    int float_mode = 0;         // 0: the fused kernel where it exists, else quantise + infer; 1: fused or BNM_EUNSUPPORTED; 2: always two kernels
+    int f32_groups = 0;         // 8-image groups in flight per wave of the fused float kernel (0 = default)
     // ternary ALU path
     bool tern_ok = false;
     int *tern_stream = nullptr;   // the trits in the streamed kernel's consumption order (bnmk_ternary_stream_build)

@@ -105,6 +105,13 @@ hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int tiles, int 
                               const void *d_frags, uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t batch,
                               hipStream_t s);
 
+// ---- fused float-input whole-model FC kernel (bnm_fused_f32.hip): float32 [n][256] -> input quantisation -> the FC stack, one
+// kernel, on the generic kernel's descriptor and fragment image.  Serves 256-value rows (KT0 == 8) of the 2- and 4-tile classes
+// whose weights leave LDS for at least one wave per SIMD.  groups: 8-image groups in flight per wave (0 = default; 2 or 4).
+bool bnmk_fused_f32_supported(const BnmGenericDesc &d, bool dbl, int groups);
+hipError_t bnmk_fused_f32(const BnmGenericDesc &d, bool dbl, int groups, int grid_blocks, const float *d_x, uint64_t n, const void *d_frags,
+                          uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t batch, hipStream_t s);
+
 // ---- layer-wise ALU kernels (bit-serial unpack + wave-shuffle reduction) ----------------------
 hipError_t bnmk_fc_layer(const int8_t *d_act, uint32_t act_stride, const void *d_packed, int32_t bpw,
                          uint32_t n_input, uint32_t n_output, int32_t *d_out, uint64_t batch,

@@ -224,6 +224,16 @@ class Context:
                 "bnm_infer_float_device")
         return cls
 
+    def set_float_mode(self, mode=0, groups=0):
+        """How infer_float_device runs: 0 the fused float-input kernel where it exists, 1 fused or an error, 2 always
+        quantise + infer (two kernels); groups: 8-image groups in flight per wave of the fused kernel (0 = default, 2, 4)."""
+        L.check(self._lib, self._lib.bnm_ctx_set_float_mode(self._h, mode, groups), "bnm_ctx_set_float_mode")
+
+    @property
+    def float_fused(self):
+        """True when float calls of this context run the one-kernel path now."""
+        return self._lib.bnm_ctx_float_fused(self._h) == 1
+
     def quantize_device(self, x, out=None, stream=None):
         """float32 cuda tensor [n,256] -> int8 [n,256] on the GPU with the reference's input quantisation
         (test_inference.py:140-141), bit-identical to harness.quantize_input."""

@@ -33,6 +33,29 @@ def images(first, count, dist=L.DIST_U, seed=None):
     return np.ascontiguousarray(v.reshape(count, 256))
 
 
+# The float workload of the float-input path: every synthetic int8 image as float32 pixels v / 127 (the scale MNIST-style data
+# has after ToTensor / Normalize is of this order).  Quantising it back (test_inference.py:140-141) is NOT the identity: an image
+# that holds -128 has max|x| = 128/127, so its values are rescaled by 127/128 and rounded.
+FLOAT_PIXEL = np.float32(1.0 / 127.0)
+
+
+def float_images(first, count, dist=L.DIST_U, seed=None):
+    """float32 [count,256]: images(first, count, dist) * (1/127), multiplied in float32."""
+    return images(first, count, dist, seed).astype(np.float32) * FLOAT_PIXEL
+
+
+def float_images_device(images_i8, out=None, chunk=1 << 22):
+    """The same on the device from a resident torch.int8 [n,256] tensor (workload generation: plain torch, in chunks)."""
+    import torch
+    n = images_i8.shape[0]
+    if out is None:
+        out = torch.empty((n, 256), dtype=torch.float32, device=images_i8.device)
+    for i in range(0, n, chunk):
+        j = min(n, i + chunk)
+        torch.mul(images_i8[i:j].to(torch.float32), float(FLOAT_PIXEL), out=out[i:j])
+    return out
+
+
 def class_digest(cls, first=0):
     """sum_i splitmix64((first+i)*64 + cls[i]) mod 2^64 — the order-independent digest the device
     computes with bnm_class_digest_device."""

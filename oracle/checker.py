@@ -79,6 +79,27 @@ def sample_indices(n):
     return np.unique(idx[(idx >= 0) & (idx < n)])
 
 
+def quantize_input(x):
+    """The reference's Python-side input quantisation, its arithmetic verbatim (test_inference.py:140-141; the same two lines at
+    BitNetMCU.py:435-436) on float32 images [n, 256]: per-image scale 127 / max(max|x|, 1e-5), np.round (half to even), clip."""
+    input_data = np.asarray(x, dtype=np.float32).reshape(-1, 256)
+    scale = 127.0 / np.maximum(np.abs(input_data).max(axis=-1, keepdims=True), 1e-5)
+    scaled_data = np.round(input_data * scale).clip(-128, 127)
+    return scaled_data.astype(np.int8)
+
+
+def verify_float_sample(torch, model, xf, cls, logits, n):
+    """Float images resident on the device: quantise_input + the oracle on sample_indices(n) against the device's class ids (and logits)."""
+    om = OracleModel(model)
+    idx = sample_indices(n)
+    ti = torch.from_numpy(idx).to(xf.device)
+    want, want_lg = om.infer(quantize_input(xf[ti].cpu().numpy()), logits=True)
+    ok = bool(np.array_equal(want, cls[ti].cpu().numpy().astype(np.uint32)))
+    if logits is not None:
+        ok = ok and bool(np.array_equal(want_lg, logits[ti].cpu().numpy()))
+    return ok
+
+
 def verify_sample(torch, model, images, cls, logits, n):
     """The device results of a resident image set against the oracle on sample_indices(n): class ids, and logits when written."""
     om = OracleModel(model)

@@ -213,6 +213,64 @@ def _oracle_parallel(model, first, count, dist, threads=None):
     return out
 
 
+def test_float_input_kernel_on_ten_million_images_equals_quantise_then_oracle(gpu_ok, orc):
+    """the fused float-input kernel (float32 images -> class ids in one kernel) id for id against the
+    reference's Python quantisation (restated in oracle/checker.py from test_inference.py:140-141) + the oracle on 10^7 images -
+    the float workload of bench.py's fc_float_input row (synthetic int8 images x 1/127), edge rows spliced in; both landing depths;
+    and the two-kernel path of the same call."""
+    import concurrent.futures as cf
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(util.REPO, "oracle"))
+    import checker
+    n = 10_000_000
+    model = util.load_golden_model("fc_4bitsym_64")
+    ctx = b.Context(model)
+    assert ctx.float_fused
+    imgs = torch.empty((n, 256), dtype=torch.int8, device="cuda")
+    synth.fill_device(imgs, first=0, dist=DIST_U)
+    xf = synth.float_images_device(imgs)
+    del imgs
+    assert np.array_equal(xf[:3000].cpu().numpy(), synth.float_images(0, 3000, DIST_U)), "device float workload != host statement"
+    # edge rows inside the stream: all-zero images, an image below the 1e-5 floor, exact .5 ties, a lone large value
+    edge = np.zeros((6, 256), np.float32)
+    edge[1] = 3e-6
+    edge[2, :] = 0.5; edge[2, 0] = 127.0
+    edge[3, :] = -2.5; edge[3, 100] = 127.0
+    edge[4] = np.arange(-128, 128, dtype=np.float32) / 2.0
+    edge[5, 255] = -1e30
+    where = [0, 31, 4097, 5_000_001, n - 33, n - 1]
+    for k, i in enumerate(where):
+        xf[i] = torch.from_numpy(edge[k]).cuda()
+    orcl = util.load_oracle()
+
+    def want_of(job):
+        s, c = job
+        x = np.empty((c, 256), np.int8)
+        orcl.orc_synth(b.SEED_DIST_U, DIST_U, s, c, x.ctypes.data)
+        f = x.astype(np.float32) * synth.FLOAT_PIXEL
+        for k, i in enumerate(where):
+            if s <= i < s + c:
+                f[i - s] = edge[k]
+        return s, util.OracleModel(model, orcl).infer(checker.quantize_input(f))
+
+    chunk = 1 << 16
+    want = np.empty(n, np.uint32)
+    with cf.ThreadPoolExecutor(min(32, len(os.sched_getaffinity(0)))) as ex:
+        for s, c in ex.map(want_of, [(s, min(chunk, n - s)) for s in range(0, n, chunk)]):
+            want[s:s + len(c)] = c
+    cls = torch.empty(n, dtype=torch.int32, device="cuda")
+    for mode, groups in ((0, 0), (1, 2), (2, 0)):
+        ctx.set_float_mode(mode, groups)
+        cls.fill_(-1)
+        ctx.infer_float_device(xf, cls)
+        torch.cuda.synchronize()
+        got = cls.cpu().numpy().astype(np.uint32)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (mode, groups, len(bad), bad[:10].tolist())
+    ctx.close()
+
+
 def test_ten_million_images_per_distribution_ids_and_logits(gpu_ok, orc):
     """SURVEY.md 8(d) asks for a full compare on >= 10^6 images per distribution; this compares 10^7 per distribution id for id
     against the oracle on the host threads (about 8 s each on 16 threads), so that less rests on the one-off 10^8 digest."""

@@ -484,6 +484,122 @@ def test_input_quantisation_matches_numpy_float32(gpu_ok):
     cctx.close()
 
 
+def _float_edge_rows(rng, n):
+    """Float images with the quantisation's edge cases in the first rows (test_inference.py:140-141)."""
+    x = rng.normal(size=(n, 256)).astype(np.float32)
+    k = min(n, 12)
+    e = np.array(x[:12])
+    e[0] = 0.0                                    # max|x| below the 1e-5 floor: scale 127 / 1e-5, every value 0
+    e[1] = np.linspace(-1, 1, 256, dtype=np.float32)
+    e[2, :] = 0.5; e[2, 0] = 127.0               # x * scale = 0.5 exactly -> rounds to even (0)
+    e[3, :] = -1.5; e[3, 0] = 127.0              # -1.5 -> -2
+    e[4] = rng.integers(-300, 300, 256).astype(np.float32) / 2.0      # many exact .5 ties
+    e[4, 0] = 150.0
+    e[5] = e[5] * 1e-7                           # tiny values, scale hits the floor
+    e[6] = e[6] * 1e20
+    e[7, :] = 2.5; e[7, 17] = -127.0             # the maximum is a negative value
+    e[8] = rng.integers(-127, 128, 256).astype(np.float32); e[8, 255] = 127.0   # integers: quantise to themselves
+    e[9] = -e[8]
+    e[10] = 1e-5 * np.sign(e[10])                # exactly the floor
+    e[11] = np.float32(3.0e38) * np.sign(e[11])  # near FLT_MAX: the scale is subnormal-free but tiny
+    x[:k] = e[:k]
+    return x
+
+
+FLOAT_MODELS = ["fc_4bitsym_64", "mcu_1k", "mcu_12k", "mcu_12k_fp130", "tern_96", "tern_96_sparse", "doc12k_ternary", "doc12k_2bit",
+                "doc12k_8bit", "doc12k_binary"]
+
+
+@pytest.mark.parametrize("name", FLOAT_MODELS)
+def test_fused_float_input_kernel_equals_quantise_then_oracle(name, gpu_ok, orc):
+    """SURVEY.md 8(f) row 1, fused: float32 images -> class ids (and logits) in ONE kernel (bnm_fused_f32_kernel.hpp) must equal
+    numpy's float32 quantisation (harness.quantize_input = test_inference.py:140-141) followed by the oracle: every FC model of the
+    zoo, both landing depths, ragged sizes (tiles, 8-image groups, one image), a one-workgroup grid (many units and work-counter
+    takes per wave), batches of one unit (a take per unit), a side stream; and the two-kernel path of the same call."""
+    import torch
+    from bitnetmcu_amd import harness
+    model = util.load_golden_model(name)
+    ctx = b.Context(model)
+    om = util.OracleModel(model, orc)
+    rng = np.random.default_rng(1234)
+    x = _float_edge_rows(rng, 70001)
+    q = harness.quantize_input(x)
+    want_cls, want_lg = om.infer(q, logits=True)
+    xd = torch.from_numpy(x).cuda()
+    ncls = model.num_classes
+    expect_fused = name != "doc12k_binary"        # 160-wide layers: the 6-tile class has no float-input instantiation
+    assert ctx.float_fused == expect_fused, name
+    if not expect_fused:
+        with pytest.raises(b.BnmError):
+            ctx.set_float_mode(1)
+    modes = [(0, 0)] + ([(1, 2)] if expect_fused else []) + [(2, 0)]
+    try:
+        ctx.set_float_mode(1, 4)
+        modes.append((1, 4))
+    except b.BnmError:
+        pass                                       # (the 4-tile class holds two groups only)
+    side = torch.cuda.Stream()
+    for mode, groups in modes:
+        ctx.set_float_mode(mode, groups)
+        assert ctx.float_fused == (expect_fused and mode != 2)
+        for n in (70001, 4099, 1000, 255, 33, 32, 31, 9, 8, 7, 1):
+            for grid, batch, logits in ((0, 0, True), (1, 1, False), (1, 3, True)):
+                if n < 4099 and grid:
+                    continue
+                ctx.set_tuning(grid_blocks=grid)
+                ctx.set_work_batch(batch)
+                cls = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+                lg = torch.full((n, ncls), -1, dtype=torch.int32, device="cuda") if logits else None
+                torch.cuda.synchronize()
+                with torch.cuda.stream(side):
+                    ctx.infer_float_device(xd[:n], cls, lg)
+                side.synchronize()
+                assert np.array_equal(cls.cpu().numpy().astype(np.uint32), want_cls[:n]), (name, mode, groups, n, grid, batch)
+                if logits:
+                    assert np.array_equal(lg.cpu().numpy(), want_lg[:n]), (name, mode, groups, n, grid, batch)
+        ctx.set_tuning(grid_blocks=0)
+        ctx.set_work_batch(0)
+    # an input that is not at the start of an allocation (16-byte aligned, not 1 KiB aligned to a tile)
+    ctx.set_float_mode(0)
+    cls = torch.empty(5000, dtype=torch.int32, device="cuda")
+    ctx.infer_float_device(xd[37:5037], cls)
+    torch.cuda.synchronize()
+    assert np.array_equal(cls.cpu().numpy().astype(np.uint32), want_cls[37:5037])
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_fused_float_input_kernel_on_random_models(seed, gpu_ok, orc):
+    """Random FC models (a codec per layer out of all seven - FP1.3.0's +128 second weight plane among them -, widths up to 128,
+    2 to 64 classes) through the float-input kernel vs numpy quantisation + oracle."""
+    import torch
+    from bitnetmcu_amd import harness
+    rng = np.random.default_rng(4400 + seed)
+    n_layers = int(rng.choice([3, 4]))
+    codecs = tuple(int(c) for c in rng.choice([1, 2, 4, 12, 16, 20, 64], size=n_layers))
+    need = {1: 32, 2: 16, 4: 8, 12: 8, 20: 8, 16: 4, 64: 8}
+    widths = []
+    for k in range(1, n_layers):
+        g = need[codecs[k]]
+        hi = int(rng.choice([32, 64, 128]))
+        widths.append(int(rng.integers(1, hi // g + 1)) * g)
+    n_classes = int(rng.integers(2, 65))
+    model = b.Model.from_header_text(_random_model_text(rng, codecs, tuple(widths), n_classes))
+    ctx = b.Context(model)
+    # (a model whose weights - two planes for FP1.3.0's +128 - leave LDS for fewer than four waves runs the two-kernel path)
+    x = _float_edge_rows(rng, 3001) * np.float32(rng.choice([1e-3, 1.0, 37.5]))
+    want_cls, want_lg = util.OracleModel(model, orc).infer(harness.quantize_input(x), logits=True)
+    xd = torch.from_numpy(x).cuda()
+    for n in (3001, 64, 5):
+        cls = torch.empty(n, dtype=torch.int32, device="cuda")
+        lg = torch.empty((n, n_classes), dtype=torch.int32, device="cuda")
+        ctx.infer_float_device(xd[:n], cls, lg)
+        torch.cuda.synchronize()
+        assert np.array_equal(cls.cpu().numpy().astype(np.uint32), want_cls[:n]), (codecs, widths, n_classes, n)
+        assert np.array_equal(lg.cpu().numpy(), want_lg[:n]), (codecs, widths, n_classes, n)
+    ctx.close()
+
+
 def test_mixed_stream_probe_writes_the_fold_of_what_it_read(gpu_ok):
     """bnm_stream_rw_device (bench.py's yardstick for the ids + logits row): every 32-row tile's 32 x 44 output bytes are the XOR
     fold of the tile's eight 1 KiB slices, 16-byte unit i of the output = unit i mod 64 of the fold; rows beyond the last whole
