@@ -225,26 +225,36 @@ def model_macs(b, model):
 
 
 def load_model_through_the_text_parser(b, name, header=None):
-    """The product's model path is exporter TEXT -> run-time parser -> GPU.  The reference's headers do not travel to the GPU
-    box (only their weight data does, as bitnetmcu_amd/zoo/*.bnm), so unless --header names a real exporter-written file the
-    text is RE-EMITTED from the committed blob by the package's own writer (bitnetmcu_amd/headerwriter.py: the exporter's
-    dialect, not the exporter's bytes), parsed by the library like any BitNetMCU_model.h, and must reproduce the blob."""
+    """The product's model path is exporter TEXT -> run-time parser -> GPU.  Sources, in this order: --header; the header the
+    REFERENCE'S OWN EXPORTER wrote in this repository (tests/golden/headers/, committed: the ternary 96-96-96 models and the
+    documented 12 KB family); the REFERENCE'S OWN FILE (BitNetMCU_model_fc.h, BitNetMCU_model_cnn.h, mcu/*.h), a byte-identical
+    copy staged by oracle/build_oracle.py under tests/golden/_ref_headers/ where /root/reference exists and shipped to the GPU box
+    (sha256 in its MANIFEST.json).  Whatever was parsed must equal the committed weight blob (bitnetmcu_amd/zoo/<name>.bnm).  Only
+    a tree that has neither (a fresh clone that never saw the reference) re-emits the blob as text with the package's own writer."""
     if header:
         return b.Model.from_header(header), "exporter-written header file " + header + " through the run-time parser"
     blob_model = b.Model.from_zoo(name)
-    # models whose header the REFERENCE'S OWN EXPORTER wrote in this repository (tests/golden/make_*_headers.py: the ternary
-    # 96-96-96 models and the documented 12 KB family) are parsed from those very bytes on the box; the result must be the blob
     exported = os.path.join(REPO, "tests", "golden", "headers", name + ".h")
-    if os.path.isfile(exported):
-        model = b.Model.from_header(exported)
+    staged = os.path.join(REPO, "tests", "golden", "_ref_headers", name + ".h")
+    for path, what in ((exported, "written by the reference's exportquant.py in this repository"), (staged, None)):
+        if not os.path.isfile(path):
+            continue
+        if what is None:
+            import hashlib
+            man = json.load(open(os.path.join(os.path.dirname(staged), "MANIFEST.json")))[name]
+            sha = hashlib.sha256(open(path, "rb").read()).hexdigest()
+            if sha != man["sha256"]:
+                raise RuntimeError(f"{path}: not the bytes that were staged from {man['origin']}")
+            what = f"the reference's own {man['origin'][len('/root/reference/'):]}, byte-identical staged copy, sha256 {sha[:16]}"
+        model = b.Model.from_header(path)
         if model.to_blob() != blob_model.to_blob():
-            raise RuntimeError(f"{name}: the exporter-written header does not parse to the committed blob")
-        return model, f"tests/golden/headers/{name}.h (written by the reference's exportquant.py) through the run-time parser"
+            raise RuntimeError(f"{name}: {path} does not parse to the committed blob")
+        return model, f"{os.path.relpath(path, REPO)} ({what}) through the run-time parser"
     model = b.Model.from_header_text(blob_model.to_header_text())
     if model.to_blob() != blob_model.to_blob():
         raise RuntimeError(f"{name}: header text -> parser does not reproduce the committed blob")
     return model, (f"bitnetmcu_amd/zoo/{name}.bnm re-emitted as header text by bitnetmcu_amd/headerwriter.py (exporter dialect; "
-                   "not the exporter's own bytes) and parsed by the run-time parser")
+                   "not the exporter's own bytes: no staged reference header in this tree) and parsed by the run-time parser")
 
 
 def timed_steps(torch, step, steps, warmup, barrier=None):
@@ -293,6 +303,7 @@ def main():
     ap.add_argument("--images", type=int, default=100_000_000, help="images per GPU (weak) or in total (strong); configs[1]: 1e8")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL (one rank per GPU); gloo for --ranks-share-device")
+    ap.add_argument("--init-timeout", type=float, default=60.0, help="seconds the process group may take to come up before the run gives up with a reason")
     ap.add_argument("--ranks-share-device", action="store_true",
                     help="all ranks on GPU 0 (needs --dist-backend gloo): the N > 1 code path on a one-GPU box; not a scaling measurement")
     ap.add_argument("--model", default="fc_4bitsym_64")
@@ -350,10 +361,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if a.dist_backend == "nccl":
-            td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            td.init_process_group("gloo", rank=rank, world_size=world)
+        # a group that does not come up within --init-timeout ends the run with one line on stderr (bitnetmcu_amd/dist.py), not a hang
+        b.dist.init_process_group_or_exit(a.dist_backend, rank, world, device=dev if a.dist_backend == "nccl" else None,
+                                          timeout_s=a.init_timeout)
     coll_dev = dev if a.dist_backend == "nccl" else torch.device("cpu")     # where the (tiny) collectives' tensors live
     barrier = td.barrier if distributed else None
 

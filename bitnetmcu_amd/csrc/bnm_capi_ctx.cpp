@@ -76,29 +76,19 @@ namespace bnm_internal {
 
 // Key of a stream in the per-stream tables.  Launches that share a key share a counter block and scratch buffers and must be
 // ordered among themselves - true for a real stream handle, NOT for hipStreamPerThread: that is one constant handle value which
-// names a different stream in every host thread, so its key is the address of a thread-local object (one entry per calling thread).
-// tokens made by stream_key() are addresses of thread-local bytes, real handles come from the runtime: the context remembers
-// which keys are tokens
-std::mutex g_token_mu;
-std::vector<const void *> g_tokens;
-bool c_is_stream_handle(hipStream_t key) {
-    std::lock_guard<std::mutex> g(g_token_mu);
-    for (const void *t : g_tokens)
-        if (t == (const void *)key) return false;
-    return true;
-}
+// names a different stream in every host thread.  Its key is a per-thread TOKEN: an odd number >= 3 from a process-wide counter,
+// never reused.  A stream handle is a pointer to an object, hence even, and the runtime's other constants are 0, 1 and 2: a token
+// can never equal a handle - unlike the address of a thread-local byte (round 4's token), which a later heap object may take
+// over once its thread has gone.  What a context keeps for the token of a thread that has exited goes with the next eviction
+// (evict_other_streams: at 32 entries).
+std::atomic<uintptr_t> g_next_token{3};
+bool c_is_stream_handle(hipStream_t key) { return ((uintptr_t)key & 1u) == 0; }
 hipStream_t stream_key(hipStream_t s) {
-    static thread_local char per_thread_key;
-    static thread_local bool registered = false;
+    static thread_local uintptr_t token = 0;
     if (s != hipStreamPerThread) return s;
-    if (!registered) {
-        std::lock_guard<std::mutex> g(g_token_mu);
-        g_tokens.push_back(&per_thread_key);
-        registered = true;
-    }
-    return (hipStream_t)(void *)&per_thread_key;
+    if (!token) token = g_next_token.fetch_add(2);
+    return (hipStream_t)token;
 }
-
 }  // namespace bnm_internal
 
 namespace {
@@ -482,6 +472,14 @@ int bnm_ctx_set_tuning(bnm_ctx *c, int variant, int grid_blocks) {
 }
 
 int bnm_ctx_get_cnn_variant(const bnm_ctx *c) { return c ? c->cnn_variant : BNM_EINVAL; }
+
+const char *bnm_ctx_last_kernel(bnm_ctx *c) {
+    static thread_local std::string copy;      // (the context may run another call on another thread meanwhile)
+    if (!c) return "";
+    std::lock_guard<std::mutex> g(c->mu);
+    copy = c->last_kernel;
+    return copy.c_str();
+}
 
 int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
     if (!c || variant < 0 || (variant > 3 && variant < 101) || (variant > 164 && variant < 301) || variant > 316) return fail(BNM_EINVAL, "bad argument");

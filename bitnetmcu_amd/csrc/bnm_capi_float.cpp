@@ -29,6 +29,7 @@ int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d
         if (int e = work_block(c, s, &block)) return e;
         HIP_TRY(bnmk_fused_f32(c->gdesc, c->shape.dbl, c->f32_groups, c->grid_blocks, d_x, n, c->gfrags, d_cls, d_logits, block,
                                c->work_batch, s));
+        c->last_kernel = "fused_fc_f32_kernel";
         return BNM_OK;
     }
     if (c->float_mode == 1) return fail(BNM_EUNSUPPORTED, "the fused float-input kernel does not serve the context's current path");
@@ -42,6 +43,7 @@ int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d
         if (int e = infer_device_locked(c, (const int8_t *)q8.p, cn, d_cls + off, d_logits ? d_logits + off * ncls : nullptr, nullptr, 0, s))
             return e;
     }
+    c->last_kernel = "quantize_input_kernel+" + c->last_kernel;
     return BNM_OK;
 }
 

@@ -12,6 +12,27 @@ constexpr uint64_t kCnnChunk = 1ull << 22;   // images per launch of the CNN fro
 // ---- whole-model launches on device data -----------------------------------------------------------
 bool is_generic(int variant) { return variant == BNM_FUSED_GENERIC || variant == BNM_FUSED_GENERIC_T1 || variant == BNM_FUSED_GENERIC_T2; }
 
+// ---- what a call launches, by name (bnm_ctx_last_kernel): the same decisions as the launch code below and the kernels' own
+// dispatchers (bnmk_fused_fc: whole 64-image pairs to the dual-tile kernel, a remainder to the one-tile kernel) ---------------
+std::string fused_names(const bnm_ctx *c, uint64_t n) {
+    if (is_generic(c->variant)) return "fused_fc_generic_kernel";
+    if (c->variant == BNM_FUSED_REGW) {
+        const uint64_t resident_waves = (c->grid_blocks > 0 ? (uint64_t)c->grid_blocks : (uint64_t)bnm_num_cus()) * 4ull;
+        const uint64_t n_main = (n >> 6) < resident_waves ? 0ull : n & ~63ull;
+        return std::string(n_main ? "fused_fc_regw_kernel" : "") + (n_main && n > n_main ? "+" : "") + (n > n_main ? "fused_fc_generic_kernel" : "");
+    }
+    if (c->variant == 3 || c->variant == 5 || c->variant == 6) {
+        const uint64_t n_main = n & ~63ull;
+        return std::string(n_main ? "fused_fc_dual_kernel" : "") + (n_main && n > n_main ? "+" : "") + (n > n_main ? "fused_fc_kernel" : "");
+    }
+    return "fused_fc_kernel";
+}
+std::string tail_names(const bnm_ctx *c, int path, uint64_t n) {
+    if (path == BNM_PATH_FUSED_MFMA) return fused_names(c, n);
+    if (path == BNM_PATH_TERNARY_ALU) return c->tern_variant == 0 ? "ternary_alu_kernel" : "ternary_stream_kernel";
+    return path == BNM_PATH_LAYERWISE_MFMA ? "fc_layer_mfma_kernel+relunorm_kernel" : "fc_layer_bitserial_kernel+relunorm_kernel";
+}
+
 int run_fused(bnm_ctx *c, const int8_t *d_in, uint64_t n, uint32_t *d_cls, int32_t *d_logits, hipStream_t s) {
     uint32_t *block = nullptr;
     if (int e = work_block(c, s, &block)) return e;
@@ -133,6 +154,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
     const uint32_t ncls = c->model.num_classes();
     const int path = d_acts_tap ? BNM_PATH_LAYERWISE_ALU : c->path;
     if (c->model.kind == BNM_KIND_FC) {
+        c->last_kernel = tail_names(c, path, n);
         if (path == BNM_PATH_FUSED_MFMA) return run_fused(c, d_images, n, d_cls, d_logits, s);
         if (path == BNM_PATH_TERNARY_ALU) return run_ternary(c, d_images, n, d_cls, d_logits, s);
         for (uint64_t off = 0; off < n; off += kChunk) {
@@ -172,7 +194,11 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         // image).  Left to itself the context gives calls of fewer than 2 C^2 images - Inference(): one - to the channel kernel
         // (profiles/r04/cnn_small_n_r05c.log: the two cross at 500 / 3,000 / 17,000 images for 16 / 48 / 64 channels).
         const bool small_call = c->cnn_auto && n < 2ull * c->channels * c->channels;
-        if (c->cnn_variant == 3 && c->cnn_li_frags && !small_call)
+        const bool lane_image = c->cnn_variant == 3 && c->cnn_li_frags && !small_call;
+        if (off == 0)
+            c->last_kernel = std::string(lane_image ? "cnn_li_kernel" : c->cnn_variant ? "cnn_front_mfma_kernel" : "cnn_front_kernel") + "+" +
+                             tail_names(c, path, cn);
+        if (lane_image)
             HIP_TRY(bnmk_cnn_front_li(d_images + off * 256, cn, c->cnn_li_frags, c->cnn_li_bias, c->channels, acts, AS, block, c->cnn_li_grab, s));
         else
             HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,

@@ -240,6 +240,8 @@ struct bnm_ctx {
     } slot[2];
     ParallelCopier *copier = nullptr;
     std::vector<void *> owned;
+    // what the context's LAST inference call launched (bnm_ctx_last_kernel): kernel names joined by '+', in launch order
+    std::string last_kernel;
     std::mutex mu;
 };
 

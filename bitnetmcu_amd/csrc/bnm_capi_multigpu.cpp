@@ -1,7 +1,15 @@
 // C ABI, multi-GPU driver for C hosts: one host thread and one single-process RCCL communicator per GPU.
 #include "bnm_capi_internal.hpp"
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+
+// The few RCCL declarations this unit needs, stated here (values and signatures of rccl.h / nccl.h, stable across releases): the
+// library is bound with dlopen at run time, so neither its import library nor its headers are a build requirement.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;      // (any other value is a failure: ncclGetErrorString says which)
+typedef enum { ncclUint8 = 1, ncclUint64 = 5 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
 
 using namespace bnm_internal;
 
@@ -14,6 +22,7 @@ struct Rccl {
     void *lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -22,7 +31,6 @@ struct Rccl {
 static const Rccl &rccl() {
     static Rccl r = [] {
         Rccl x;
-        if (std::getenv("BNM_NO_RCCL")) return x;      // (tests: exercise the host-transport fallback)
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (x.lib) break;
@@ -30,6 +38,7 @@ static const Rccl &rccl() {
         if (!x.lib) return x;
         x.CommInitAll = (decltype(x.CommInitAll))dlsym(x.lib, "ncclCommInitAll");
         x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.lib, "ncclCommDestroy");
+        x.CommAbort = (decltype(x.CommAbort))dlsym(x.lib, "ncclCommAbort");
         x.Broadcast = (decltype(x.Broadcast))dlsym(x.lib, "ncclBroadcast");
         x.AllReduce = (decltype(x.AllReduce))dlsym(x.lib, "ncclAllReduce");
         x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.lib, "ncclGetErrorString");
@@ -64,36 +73,46 @@ int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, in
         ~Restore() { (void)hipSetDevice(dev); }
     } restore{caller_dev};
     const int G = (n_gpus <= 0 || n_gpus > ndev) ? ndev : n_gpus;
+    // (everything that can fail without RCCL first: no exit below leaves communicators behind)
+    const size_t blob_bytes = bnm_model_blob_size(m);
+    std::vector<uint8_t> blob0(blob_bytes);
+    if (bnm_model_to_blob(m, blob0.data(), blob_bytes) != BNM_OK) return fail(BNM_EINVAL, "model does not serialise");
     const Rccl &nc = rccl();
     std::vector<ncclComm_t> comms(G, nullptr);
-    bool use_rccl = nc.ok();
+    // BNM_NO_RCCL (read at every call; tests: the host-transport fallback)
+    const bool use_rccl = nc.ok() && !std::getenv("BNM_NO_RCCL");
     if (use_rccl) {
         std::vector<int> devs(G);
         for (int g = 0; g < G; g++) devs[g] = g;
         ncclResult_t r = nc.CommInitAll(comms.data(), G, devs.data());
-        if (r != ncclSuccess) return fail(BNM_EHIP, std::string("ncclCommInitAll: ") + nc.GetErrorString(r));
+        if (r != ncclSuccess) {
+            for (ncclComm_t cm : comms) if (cm) (void)nc.CommDestroy(cm);      // (whatever a partial init left)
+            return fail(BNM_EHIP, std::string("ncclCommInitAll: ") + nc.GetErrorString(r));
+        }
     }
     g_multi_gpu_transport = use_rccl ? "rccl" : "host";
-    const size_t blob_bytes = bnm_model_blob_size(m);
-    std::vector<uint8_t> blob0(blob_bytes);
-    if (bnm_model_to_blob(m, blob0.data(), blob_bytes) != BNM_OK) return fail(BNM_EINVAL, "model does not serialise");
 
     // a reusable host barrier for the rank threads; `failed` is examined behind it, so that either every rank enters the next
     // collective or none does
+    // wait() returns ONE value of `failed` to all ranks: the last rank to arrive samples it while everybody else is parked, so a
+    // rank that fails right behind the barrier cannot make some ranks skip a collective that the others have entered
+    std::atomic<bool> failed{false};
     struct Barrier {
         std::mutex mu;
         std::condition_variable cv;
         int n, waiting = 0;
         uint64_t gen = 0;
-        explicit Barrier(int n_) : n(n_) {}
-        void wait() {
+        bool verdict = false;
+        std::atomic<bool> &flag;
+        Barrier(int n_, std::atomic<bool> &f) : n(n_), flag(f) {}
+        bool wait() {
             std::unique_lock<std::mutex> l(mu);
             const uint64_t my = gen;
-            if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); }
+            if (++waiting == n) { waiting = 0; verdict = flag.load(); gen++; cv.notify_all(); }
             else cv.wait(l, [&] { return gen != my; });
+            return verdict;
         }
-    } barrier(G);
-    std::atomic<bool> failed{false};
+    } barrier(G, failed);
     std::vector<std::string> errors(G);
     std::vector<double> elapsed(G, 0.0);
     std::vector<std::vector<uint64_t>> host_digest(G, std::vector<uint64_t>(65, 0));
@@ -103,6 +122,13 @@ int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, in
         auto bad = [&](const std::string &what) { errors[g] = "GPU " + std::to_string(g) + ": " + what; failed = true; };
         auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess) bad(std::string(what) + ": " + hipGetErrorString(e)); return e == hipSuccess; };
         auto nccl_ok = [&](ncclResult_t r, const char *what) { if (r != ncclSuccess) bad(std::string(what) + ": " + nc.GetErrorString(r)); return r == ncclSuccess; };
+        // behind a collective's enqueue: did EVERY rank enqueue it?  If one did not, the others' streams would wait for it for ever:
+        // each rank aborts its communicator (which releases the stream) instead of synchronising
+        auto entered_by_all = [&]() {
+            const bool broken = barrier.wait();
+            if (broken && use_rccl && comms[g] && nc.CommAbort) { (void)nc.CommAbort(comms[g]); comms[g] = nullptr; }
+            return !broken;
+        };
         const uint64_t first = (uint64_t)g * base + ((uint64_t)g < rem ? (uint64_t)g : rem), count = base + ((uint64_t)g < rem ? 1 : 0);
         hipStream_t st = nullptr;
         bnm_model *mine = nullptr;
@@ -113,11 +139,11 @@ int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, in
         if (!up && !failed) bad("device setup failed");
         // ---- the model: rank 0's blob to everybody ----------------------------------------------------------------
         if (up && (g == 0 || !use_rccl)) hip_ok(hipMemcpyAsync(d_blob.p, blob0.data(), blob_bytes, hipMemcpyHostToDevice, st), "blob upload");
-        barrier.wait();
-        if (!failed && use_rccl)
+        bool stop = barrier.wait();      // (all ranks agree: the collective is entered by every rank or by none)
+        if (!stop && use_rccl)
             nccl_ok(nc.Broadcast(d_blob.p, d_blob.p, blob_bytes, ncclUint8, 0, comms[g], st), "ncclBroadcast(model blob)");
         std::vector<uint8_t> got(blob_bytes);
-        if (!failed && hip_ok(hipMemcpyAsync(got.data(), d_blob.p, blob_bytes, hipMemcpyDeviceToHost, st), "blob download") &&
+        if (entered_by_all() && hip_ok(hipMemcpyAsync(got.data(), d_blob.p, blob_bytes, hipMemcpyDeviceToHost, st), "blob download") &&
             hip_ok(hipStreamSynchronize(st), "model broadcast")) {
             // every rank - the root too - builds its model from the bytes that came out of the collective
             if (bnm_model_from_blob(got.data(), blob_bytes, &mine) != BNM_OK) bad(std::string("received blob does not parse: ") + bnm_last_error());
@@ -133,9 +159,9 @@ int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, in
             if (bnm_infer_device(ctx, (const int8_t *)img.p, count, (uint32_t *)cls.p, nullptr, st) != BNM_OK) bad(bnm_last_error());
             hip_ok(hipStreamSynchronize(st), "warm-up pass");
         }
-        barrier.wait();
+        stop = barrier.wait();
         // ---- the timed pass: all ranks start together, each stops its own clock -------------------------------------
-        if (!failed) {
+        if (!stop) {
             const auto t0 = std::chrono::steady_clock::now();
             if (bnm_infer_device(ctx, (const int8_t *)img.p, count, (uint32_t *)cls.p, nullptr, st) != BNM_OK) bad(bnm_last_error());
             hip_ok(hipStreamSynchronize(st), "kernel execution");
@@ -143,11 +169,11 @@ int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, in
             hip_ok(bnmk_class_digest((const uint32_t *)cls.p, first, count, (uint64_t *)dig.p, n_bins, st), "bnmk_class_digest");
             hip_ok(hipStreamSynchronize(st), "digest");
         }
-        barrier.wait();
+        stop = barrier.wait();
         // ---- digest + histogram: one all-reduce ---------------------------------------------------------------------
-        if (!failed && use_rccl)
+        if (!stop && use_rccl)
             nccl_ok(nc.AllReduce(dig.p, dig.p, 1 + n_bins, ncclUint64, ncclSum, comms[g], st), "ncclAllReduce(digest)");
-        if (!failed && (g == 0 || !use_rccl)) {
+        if (entered_by_all() && (g == 0 || !use_rccl)) {
             hip_ok(hipMemcpyAsync(host_digest[g].data(), dig.p, sizeof(uint64_t) * (1 + n_bins), hipMemcpyDeviceToHost, st), "digest download");
         }
         if (st) (void)hipStreamSynchronize(st);
@@ -160,8 +186,9 @@ int bnm_run_synth_multi_gpu(const bnm_model *m, uint64_t n_total, int n_gpus, in
     for (int g = 1; g < G; g++) threads.emplace_back(rank_main, g);
     rank_main(0);
     for (auto &t : threads) t.join();
-    if (use_rccl)
-        for (int g = 0; g < G; g++) if (comms[g]) (void)nc.CommDestroy(comms[g]);
+    if (use_rccl)      // a failed run may have left a collective half-entered: abort the communicators rather than drain them
+        for (int g = 0; g < G; g++)
+            if (comms[g]) (void)((failed && nc.CommAbort) ? nc.CommAbort(comms[g]) : nc.CommDestroy(comms[g]));
     if (failed) {
         std::string all;
         for (auto &e : errors) if (!e.empty()) all += (all.empty() ? "" : "; ") + e;

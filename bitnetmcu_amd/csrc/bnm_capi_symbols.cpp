@@ -51,11 +51,22 @@ public:
 private:
     SymSlot *s_;
 };
+// (the layer's geometry is part of the key: what is cached beside the device copy - n_act - depends on it, and two layers can
+// share an array address, a byte count and a content: 64 x 32 and 32 x 64 four-bit weights are both 1024 bytes)
 struct WeightKey {
     const void *ptr;
     size_t bytes;
     uint64_t hash;
-    bool operator<(const WeightKey &o) const { return ptr != o.ptr ? ptr < o.ptr : bytes != o.bytes ? bytes < o.bytes : hash < o.hash; }
+    int32_t bpw;
+    uint32_t n_input, n_output;
+    bool operator<(const WeightKey &o) const {
+        if (ptr != o.ptr) return ptr < o.ptr;
+        if (bytes != o.bytes) return bytes < o.bytes;
+        if (hash != o.hash) return hash < o.hash;
+        if (bpw != o.bpw) return bpw < o.bpw;
+        if (n_input != o.n_input) return n_input < o.n_input;
+        return n_output < o.n_output;
+    }
 };
 struct WeightEntry {
     void *dev = nullptr;
@@ -63,6 +74,8 @@ struct WeightEntry {
 };
 std::map<WeightKey, WeightEntry> g_weights;
 constexpr size_t kMaxCachedWeightArrays = 1024;      // (a 64-channel CNN host presents 3 x 64 nine-byte kernels + 3 FC arrays)
+// device copies taken out of the table while other calls were in flight: freed by the next call that finds itself alone
+std::vector<void *> g_weights_retired;
 
 uint64_t content_hash(const void *p, size_t bytes) {      // FNV-1a over 8-byte words (+ tail bytes): ~2 us for a 12 KB array
     const uint8_t *b = (const uint8_t *)p;
@@ -153,8 +166,8 @@ uint32_t ternary_used_inputs(const uint16_t *w, uint32_t n_input, uint32_t n_out
 // one of them: every call synchronises its stream before it gives its lease back) - otherwise the table grows past its cap
 // until that is the case.
 template <class F>
-bool cached_weights(const void *host, size_t bytes, F compute_n_act, WeightEntry *out) {
-    const WeightKey key{host, bytes, content_hash(host, bytes)};
+bool cached_weights(const void *host, size_t bytes, int32_t bpw, uint32_t n_input, uint32_t n_output, F compute_n_act, WeightEntry *out) {
+    const WeightKey key{host, bytes, content_hash(host, bytes), bpw, n_input, n_output};
     {
         std::lock_guard<std::mutex> g(g_mu);
         auto it = g_weights.find(key);
@@ -171,10 +184,14 @@ bool cached_weights(const void *host, size_t bytes, F compute_n_act, WeightEntry
             dead.push_back(e.dev);
             e = it->second;
         } else {
-            if (g_weights.size() >= kMaxCachedWeightArrays && g_sym_active == 1) {
-                for (auto &kv : g_weights) dead.push_back(kv.second.dev);
+            // a full table is emptied whoever else is running (a host that rewrites its weights in place must not grow it without
+            // bound); the device copies that another call may be launching with right now are only RETIRED - every call
+            // synchronises its stream before it returns its lease, so the first call that holds the only lease frees them
+            if (g_weights.size() >= kMaxCachedWeightArrays) {
+                for (auto &kv : g_weights) g_weights_retired.push_back(kv.second.dev);
                 g_weights.clear();
             }
+            if (g_sym_active == 1) dead.swap(g_weights_retired);
             g_weights[key] = e;
         }
     }
@@ -231,7 +248,7 @@ void processfclayer(int8_t *activations, const uint32_t *weights, int32_t bpw, u
     SymLease sl;
     if (!sl->ready()) die("processfclayer");
     WeightEntry w;
-    if (!cached_weights(weights, wbytes, [&] {
+    if (!cached_weights(weights, wbytes, bpw, n_input, n_output, [&] {
             return bpw == 64 ? ternary_used_inputs((const uint16_t *)weights, n_input, n_output) : n_input;
         }, &w)) { g_err = hipGetErrorString(hipGetLastError()); die("processfclayer"); }
     const uint32_t n_act = w.n_act, stride = n_act ? n_act : 1;
@@ -264,7 +281,7 @@ int32_t *processconv33ReLU(int32_t *activations, const int8_t *weights, uint32_t
     SymLease sl;
     if (!sl->ready() || sl->in.ensure((size_t)xy * xy * 4) || sl->out.ensure((size_t)o * o * 4)) die("processconv33ReLU");
     WeightEntry w;
-    if (!cached_weights(weights, 9, [] { return 0u; }, &w)) { g_err = hipGetErrorString(hipGetLastError()); die("processconv33ReLU"); }
+    if (!cached_weights(weights, 9, 0, 9, 1, [] { return 0u; }, &w)) { g_err = hipGetErrorString(hipGetLastError()); die("processconv33ReLU"); }
     std::memcpy(sl->in.host, activations, (size_t)xy * xy * 4);
     bool ok = bnmk_conv33((const int32_t *)sl->in.dev, (const int8_t *)w.dev, xy, n_shift, (int32_t *)sl->out.dev, sl->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(sl->stream) == hipSuccess;

@@ -9,6 +9,42 @@ at setup (~13 KB blob) and an optional all-reduce of the (digest, histogram) vec
 import numpy as np
 
 
+def init_process_group_or_exit(backend, rank, world, device=None, timeout_s=60.0, exit_code=3):
+    """torch.distributed.init_process_group + one barrier, under a watchdog: when the group is not up within timeout_s - a rank
+    that never started, a rendezvous that cannot be reached, RCCL's communicator setup stuck below Python (the IPC transport of a
+    driver this code has never met: no multi-GPU node has been available to it) - the process prints ONE line saying so to stderr
+    and exits with exit_code, instead of hanging until an outer limit kills it without a reason.  backend "nccl" is RCCL."""
+    import datetime
+    import os
+    import sys
+    import threading
+    import torch.distributed as td
+    stage = ["rendezvous (TCP store at %s:%s)" % (os.environ.get("MASTER_ADDR", "?"), os.environ.get("MASTER_PORT", "?"))]
+
+    def give_up():
+        sys.stderr.write(f"bitnetmcu_amd.dist: rank {rank} of {world}: the '{backend}' process group did not come up within {timeout_s:g} s "
+                         f"(stuck in: {stage[0]}; HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', 'unset')}) - giving up\n")
+        sys.stderr.flush()
+        os._exit(exit_code)
+
+    dog = threading.Timer(timeout_s, give_up)
+    dog.daemon = True
+    dog.start()
+    try:
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        # (the group's own timeout also bounds every later collective: ten minutes; the watchdog above is what bounds the start)
+        td.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(timeout_s, 600.0)), **kw)
+        stage[0] = "first barrier (communicator setup)"
+        td.barrier()
+    except Exception as e:      # the store's own timeout, a refused connection ...: the same one line, then out
+        dog.cancel()
+        sys.stderr.write(f"bitnetmcu_amd.dist: rank {rank} of {world}: the '{backend}' process group did not come up "
+                         f"({stage[0]}): {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}\n")
+        sys.stderr.flush()
+        os._exit(exit_code)
+    dog.cancel()
+
+
 def shard_range(n, rank, world):
     """[first, last) of rank's contiguous shard; shards differ by at most one image."""
     base, rem = divmod(int(n), int(world))

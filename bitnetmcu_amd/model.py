@@ -224,6 +224,11 @@ class Context:
                 "bnm_infer_float_device")
         return cls
 
+    @property
+    def last_kernel(self):
+        """Names of the kernels the context's last inference call launched, joined by '+' (bnm_ctx_last_kernel)."""
+        return self._lib.bnm_ctx_last_kernel(self._h).decode()
+
     def set_float_mode(self, mode=0, groups=0):
         """How infer_float_device runs: 0 the fused float-input kernel where it exists, 1 fused or an error, 2 always
         quantise + infer (two kernels); groups: 8-image groups in flight per wave of the fused kernel (0 = default, 2, 4)."""

@@ -182,11 +182,18 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
  * whose channel count leaves 1..16 channels beyond a multiple of 32 (16, 48, 80 ... channels) run those channels two images per
  * work item.  2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the
  * all-VALU kernel of round 1 (the non-default values are kept for A/B measurements).
- * A context nobody has called this function on gives calls of fewer than 2 C^2 images (C = channels; one-image Inference() calls
- * among them) to kernel 1 although it reports 3: a wave of the lane = image kernel walks all channels of its 32 images, 2 us per
- * channel, however few images the call has; an explicit choice holds for every call size. */
+ * AUTO (a context nobody has called this function on): calls of fewer than 2 C^2 images (C = channels; one-image Inference() calls
+ * among them) go to kernel 1, larger ones to kernel 3 - a wave of the lane = image kernel walks all channels of its 32 images,
+ * 2 us per channel, however few images the call has.  bnm_ctx_get_cnn_variant returns the SETTING (3 for such a context);
+ * bnm_ctx_last_kernel names what the last call really ran.  An explicit choice holds for every call size. */
 BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
-BNM_API int bnm_ctx_get_cnn_variant(const bnm_ctx *c);      /* 3, 1 or 0 */
+BNM_API int bnm_ctx_get_cnn_variant(const bnm_ctx *c);      /* the setting: 3, 1 or 0 */
+/* The kernels the context's LAST inference call launched (bnm_infer_device / _host / _float_device; the first chunk's of a call
+ * that runs in chunks), by name and in launch order, joined by '+': e.g. "fused_fc_dual_kernel", "fused_fc_dual_kernel+fused_fc_kernel"
+ * (a remainder of fewer than 64 images), "cnn_li_kernel+fused_fc_kernel", "cnn_front_mfma_kernel+fused_fc_kernel" (an AUTO context's
+ * small call), "fused_fc_f32_kernel", "quantize_input_kernel+fused_fc_dual_kernel".  Empty before the first call.  The pointer
+ * stays valid until the calling thread's next call of this function. */
+BNM_API const char *bnm_ctx_last_kernel(bnm_ctx *c);
 /* Fused kernels that hand their work out from the device-wide counter: units of one or two 32-image tiles (generic kernel,
  * variants 4 / 7 / 8; default 4 / 4 / 2) or 64-image pairs (dual-tile kernel, variant 6; default 2) a wave takes at a time;
  * 0 = default. */

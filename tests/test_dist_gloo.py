@@ -73,3 +73,24 @@ def test_combine_digests_is_order_independent():
     whole = synth.class_digest(cls, 0)
     parts = [np.array([synth.class_digest(cls[a:b], a)], np.uint64) for a, b in ((0, 300), (300, 301), (301, 1000))]
     assert int(dist.combine_digests(parts[::-1])[0]) == whole
+
+
+def test_a_process_group_that_does_not_come_up_ends_with_a_reason_not_a_hang():
+    """rank 0 of a two-rank group whose second rank never starts.  init_process_group_or_exit must end the
+    process within the timeout with exit code 3 and ONE line on stderr that names the backend and where it was stuck."""
+    import subprocess
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = ("import sys; sys.path.insert(0, %r); from bitnetmcu_amd import dist; "
+            "dist.init_process_group_or_exit('gloo', 0, 2, timeout_s=4.0); print('came up')" % util.REPO)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    assert time.time() - t0 < 60
+    assert "came up" not in r.stdout
+    lines = [l for l in r.stderr.splitlines() if l.startswith("bitnetmcu_amd.dist:")]
+    assert len(lines) == 1 and "'gloo' process group did not come up" in lines[0] and "rank 0 of 2" in lines[0], r.stderr[-800:]

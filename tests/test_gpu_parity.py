@@ -600,6 +600,85 @@ def test_fuzz_fused_float_input_kernel_on_random_models(seed, gpu_ok, orc):
     ctx.close()
 
 
+def test_processfclayer_same_array_two_geometries(gpu_ok, bnm, orc):
+    """the symbols' device-side weight cache is keyed by the layer geometry too.  One host array presented as 64 -> 32
+    and as 32 -> 64 four-bit weights (both 1024 bytes), and one ternary array as 40 -> 8 and 20 -> 16: every call equals the oracle,
+    and the activation buffer of the narrower call is exactly as long as that call says (a stale wider n_act would read past it)."""
+    f, o = util.Funcs(bnm), util.Funcs(orc, "orc_")
+    rng = np.random.default_rng(99)
+    w4 = rng.integers(0, 2**32, size=256, dtype=np.uint64).astype(np.uint32)           # 1024 bytes
+    for n_in, n_out in ((64, 32), (32, 64), (64, 32), (32, 64)):
+        act = rng.integers(-128, 128, n_in).astype(np.int8)
+        assert np.array_equal(f.processfclayer(act, w4, 4, n_in, n_out), o.processfclayer(act, w4, 4, n_in, n_out)), (n_in, n_out)
+    trits = rng.integers(0, 3, size=(32, 10))
+    w16 = np.array([int(np.ceil(int("".join(map(str, t)), 3) * 65536 / 59049)) for t in trits], dtype=np.uint16)   # exportquant.py:139-157
+    for n_in, n_out in ((40, 8), (20, 16), (40, 8)):
+        act = rng.integers(-128, 128, n_in).astype(np.int8)
+        assert np.array_equal(f.processfclayer(act, w16, 64, n_in, n_out), o.processfclayer(act, w16, 64, n_in, n_out)), (n_in, n_out)
+
+
+def test_last_kernel_names_what_the_call_ran(gpu_ok):
+    """bnm_ctx_get_cnn_variant is the SETTING; bnm_ctx_last_kernel names what the last call really launched -
+    on both sides of an AUTO context's 2 C^2 small-call threshold, for a named front end, for the FC remainders and for the float
+    paths - and bench.py's kernel_name() (the key of the replayed counters) agrees with it."""
+    import torch
+    sys.path.insert(0, util.REPO)
+    import bench
+    x = torch.empty((20000, 256), dtype=torch.int8, device="cuda")
+    synth.fill_device(x, first=0, dist=DIST_U)
+    cls = torch.empty(20000, dtype=torch.int32, device="cuda")
+
+    def ran(ctx, n):
+        ctx.infer_device(x[:n], cls[:n])
+        torch.cuda.synchronize()
+        return ctx.last_kernel
+
+    model = util.load_golden_model("cnn_64")
+    ctx = b.Context(model)
+    assert ctx.last_kernel == ""
+    C = model.layer(0).out_channels
+    assert C == 64 and ctx.cnn_variant == 3
+    for n, front in ((2 * C * C - 1, "cnn_front_mfma_kernel"), (2 * C * C, "cnn_li_kernel"), (1, "cnn_front_mfma_kernel")):
+        got = ran(ctx, n)
+        assert got.split("+")[0] == front, (n, got)
+        assert ctx._lib.bnm_ctx_get_cnn_variant(ctx._h) == 3             # the setting does not move
+        assert set(bench.kernel_name(b, ctx, model, n, False).split("+")) == set(got.split("+")), (n, got)
+    ctx.set_cnn_variant(3)                                               # named: holds for every call size
+    assert ran(ctx, 7).split("+")[0] == "cnn_li_kernel"
+    ctx.set_cnn_variant(1)
+    assert ran(ctx, 20000).split("+")[0] == "cnn_front_mfma_kernel"
+    ctx.set_cnn_variant(0)
+    assert ran(ctx, 100).split("+")[0] == "cnn_front_kernel"
+    ctx.close()
+
+    model = util.load_golden_model("fc_4bitsym_64")
+    ctx = b.Context(model)
+    assert ran(ctx, 1000) == "fused_fc_dual_kernel+fused_fc_kernel"       # 15 pairs + 40 images
+    assert ran(ctx, 960) == "fused_fc_dual_kernel"
+    assert ran(ctx, 5) == "fused_fc_kernel"
+    ctx.set_tuning(variant=4)
+    assert ran(ctx, 1000) == "fused_fc_generic_kernel"
+    ctx.set_tuning(variant=6)
+    ctx.set_path(b.PATH_LAYERWISE_MFMA)
+    assert ran(ctx, 100) == "fc_layer_mfma_kernel+relunorm_kernel"
+    ctx.set_path(b.PATH_AUTO)
+    xf = synth.float_images_device(x[:1000])
+    ctx.infer_float_device(xf, cls[:1000])
+    torch.cuda.synchronize()
+    assert ctx.last_kernel == "fused_fc_f32_kernel" and ctx.float_fused
+    ctx.set_float_mode(2)
+    ctx.infer_float_device(xf, cls[:1000])
+    torch.cuda.synchronize()
+    assert ctx.last_kernel == "quantize_input_kernel+fused_fc_dual_kernel+fused_fc_kernel" and not ctx.float_fused
+    ctx.close()
+    ctx = b.Context(util.load_golden_model("tern_96"))
+    ctx.set_path(b.PATH_TERNARY_ALU)
+    assert ran(ctx, 100) == "ternary_stream_kernel"
+    ctx.set_ternary_variant(0)
+    assert ran(ctx, 100) == "ternary_alu_kernel"
+    ctx.close()
+
+
 def test_mixed_stream_probe_writes_the_fold_of_what_it_read(gpu_ok):
     """bnm_stream_rw_device (bench.py's yardstick for the ids + logits row): every 32-row tile's 32 x 44 output bytes are the XOR
     fold of the tile's eight 1 KiB slices, 16-byte unit i of the output = unit i mod 64 of the fold; rows beyond the last whole
