@@ -205,6 +205,8 @@ def kernel_name(b, ctx, model, count=None, cnn_variant_named=False):
     if model.kind == b.KIND_CNN and cnn == "cnn_li_kernel" and count is not None and not cnn_variant_named:
         if count < 2 * model.layers()[0].out_channels ** 2:
             cnn = "cnn_front_mfma_kernel"
+    if model.kind == b.KIND_CNN and cnn == "cnn_li_kernel" and ctx.path == b.PATH_FUSED_MFMA and ctx.cnn_tail_fused:
+        return "cnn_li_fused_kernel"        # front end + FC tail in one kernel: the only launch of the call
     return k + ("+" + cnn if model.kind == b.KIND_CNN else "")
 
 
@@ -482,6 +484,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "kernel": kname,
+                "launched": ctx.last_kernel,      # bnm_ctx_last_kernel: what the library says the last call ran
                 "avg_launch_ms": avg_ms,
                 "median_launch_ms": float(np.median(launch_ms)),
                 "min_launch_ms": float(np.min(launch_ms)),
@@ -564,7 +567,8 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         res[name] = {"model": model_name, "model_source": src, "images": count, "dist": "U" if dist == 0 else "M", "steps": steps, "warmup": warmup,
                      "value": rate, "unit": "inferences/s", "avg_launch_ms": float(np.mean(ms)), "median_launch_ms": float(np.median(ms)),
                      "min_launch_ms": float(np.min(ms)),
-                     "kernel": kernel_name(b, ctx, model, count, cnn_variant >= 0), "path": ctx.path, "fused_variant": ctx.variant, "verified_vs_oracle": ok,
+                     "kernel": kernel_name(b, ctx, model, count, cnn_variant >= 0), "launched": ctx.last_kernel, "path": ctx.path,
+                     "fused_variant": ctx.variant, "verified_vs_oracle": ok,
                      "mfma_per_image": model_mfmas_per_image(b, model) if ctx.path == b.PATH_FUSED_MFMA else None}
         if note:
             res[name]["note"] = note
@@ -633,19 +637,46 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     res["ternary_alu"]["roofline"] = valu(r, "ternary_stream_kernel", BYTES_PER_INFERENCE, m)
     r, _ = run("ternary_mfma_generic", "tern_96", n, 10, 3, note="the same model on the library's default (AUTO) path")
     hbm_entry("ternary_mfma_generic", r, BYTES_PER_INFERENCE)
-    # configs[3]: CNN 64-wide.  Default front end: the lane = image kernel (all three convolutions on the matrix cores, 44 MFMAs per
-    # channel and 32-image tile); the algorithmic VALU fraction keeps its definition (MACs / 256 per image against the VALU issue
-    # peak) so that the rows stay comparable across rounds - the kernel now does most of those MACs on the matrix cores
+    # configs[3]: CNN 64-wide.  Default: ONE kernel per call - the lane = image front end (all three convolutions as Toeplitz products
+    # on the matrix cores, 44 MFMAs per channel and 32-image tile) with the FC tail in the same wave.  What binds it is the VALU
+    # issue rate of the convolutions' epilogues, so the row's `frac` is the kernel's OWN VALU + MFMA instruction count per image
+    # (SQ_INSTS_VALU of the counter pass of this kernel binary, replayed) x the measured rate against the VALU issue peak; beside it
+    # the ALGORITHMIC int8 operations (2 x MACs of the reference's loops) against the dense int8 matrix-core peak, the issued MFMAs
+    # against the same peak, and the HBM fraction of the 260 algorithmic bytes (+ counter traffic where measured)
     def cnn_row(name, model_name, note, cnn_variant=-1):
         r, m = run(name, model_name, n_cnn, 3, 1, note=note, cnn_variant=cnn_variant)
-        li = res[name]["kernel"].endswith("cnn_li_kernel")
-        res[name]["roofline"] = valu(r, "cnn_li_kernel" if li else "cnn_front_mfma_kernel", BYTES_PER_INFERENCE, m, model_name if (li or model_name != "cnn_64") else None)
+        kern = res[name]["kernel"].split("+")[-1]
+        li = kern in ("cnn_li_kernel", "cnn_li_fused_kernel")
+        macs = model_macs(b, m)
+        c = cj.get(f"{kern}@{model_name}") or cj.get(kern)
+        roof = {"bound": "valu", "unit": "wave64 VALU-pipe instructions/s", "peak": VALU_PEAK_WAVE_INSTR_PER_S,
+                "definition": "frac = (VALU + MFMA instructions per image, counted by SQ_INSTS_VALU on this kernel binary) x inferences/s / "
+                              "(1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction): the share of the VALU issue slots the kernel's own "
+                              "instruction stream fills",
+                "macs_per_image": macs}
+        if c and "valu_per_image" in c:
+            roof.update({"valu_per_image": c["valu_per_image"], "achieved": r * c["valu_per_image"],
+                         "frac": r * c["valu_per_image"] / VALU_PEAK_WAVE_INSTR_PER_S,
+                         "valu_per_image_source": f"replayed from profiles/pmc_counters.json (SQ_INSTS_VALU, pass {c.get('source')}, same kernel binary: "
+                                                  f"code_sha1 {c.get('code_sha1', '')[:12]}); not measured by this run"})
+            if "hbm_bytes_per_image" in c:
+                roof["traffic_bytes_per_image"] = c["hbm_bytes_per_image"]
+        else:       # no counter pass of this binary: the algorithmic fraction (MACs at 4 per lane of a v_dot4), labelled as such
+            roof.update({"achieved": r * macs / MACS_PER_WAVE_DOT4, "frac": r * macs / MACS_PER_WAVE_DOT4 / VALU_PEAK_WAVE_INSTR_PER_S,
+                         "frac_is": "ALGORITHMIC (MACs / 256 per image): no counter pass of this kernel binary to replay"})
+        roof["int8_ops_algorithmic"] = {"per_image": 2 * macs, "achieved_per_s": r * 2 * macs, "peak_per_s": MFMA_I8_32X32X32_PEAK_PER_S * 65536.0,
+                                        "frac": r * 2 * macs / (MFMA_I8_32X32X32_PEAK_PER_S * 65536.0),
+                                        "definition": "2 x the reference loops' multiply-accumulates per image x inferences/s / dense int8 peak (5.03e15 op/s)"}
+        roof["hbm_frac"] = r * BYTES_PER_INFERENCE / 1e9 / HBM_PEAK_GBS
         if li:
             per = 44.0 * m.layer(0).out_channels / 32.0 + model_mfmas_per_image(b, m)
-            res[name]["roofline"]["mfma"] = {"per_image": per, "achieved_per_s": r * per, "peak_per_s": MFMA_I8_32X32X32_PEAK_PER_S,
-                                             "frac": r * per / MFMA_I8_32X32X32_PEAK_PER_S,
-                                             "definition": "44 v_mfma_i32_32x32x32_i8 per channel and 32-image tile (conv1 14, conv2 24, conv3 6) + the FC tail's"}
+            roof["mfma"] = {"per_image": per, "achieved_per_s": r * per, "peak_per_s": MFMA_I8_32X32X32_PEAK_PER_S,
+                            "frac": r * per / MFMA_I8_32X32X32_PEAK_PER_S,
+                            "definition": "44 v_mfma_i32_32x32x32_i8 per channel and 32-image tile (conv1 14, conv2 24, conv3 6) + the FC tail's: "
+                                          "the Toeplitz form issues ~12 x the algorithmic int8 operations"}
+        res[name]["roofline"] = roof
     cnn_row("cnn_64", "cnn_64", "BASELINE configs[3]")
+    cnn_row("cnn_64_two_launches", "cnn_64", "the same front end with the FC tail as its own launch over act rows in HBM (round 4's form: 772 B moved per image)", cnn_variant=4)
     cnn_row("cnn_64_channel_kernel", "cnn_64", "the same model on round 3's front end (a lane = a channel, conv1 only on the matrix cores)", cnn_variant=1)
     # the reference's smaller published CNNs (mcu/BitNetMCU_model_cnn_16.h, _48.h)
     for nm in ("mcu_cnn_16", "mcu_cnn_48"):

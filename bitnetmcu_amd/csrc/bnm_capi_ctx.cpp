@@ -289,8 +289,9 @@ int ctx_build(bnm_ctx *c) {
         // count: surplus tiles and K-steps hold zero weights), ktp[i] K-steps; layer i starts at layer_off[i]
         // kmajor: the generic kernel's layout - per layer [plane][K-step][tile] (fragment (p, s, m) at ((p * kt + s) * mt + m) KiB)
         auto build_frags = [&](const uint32_t *mt, const uint32_t *ktp, const uint32_t *layer_off, uint32_t total, bool kmajor, void **out) -> int {
-            if (int e = dev_alloc(c, out, total)) return e;
-            HIP_TRY(hipMemsetAsync(*out, 0, total, s));
+            // (+ 16 KiB: kernels that read the fragments from global memory run their reads a few KiB ahead of the last fragment)
+            if (int e = dev_alloc(c, out, (size_t)total + 16384u)) return e;
+            HIP_TRY(hipMemsetAsync(*out, 0, (size_t)total + 16384u, s));
             for (size_t i = 0; i < nfc; i++) {
                 const FcDev &d = c->fc[i];
                 char *dst = (char *)*out + layer_off[i];
@@ -365,6 +366,7 @@ int ctx_build(bnm_ctx *c) {
         c->regw_ok = c->regw_ok && c->generic_ok;
         c->fused_ok = c->table_ok || c->generic_ok;
         c->f32_ok = m.kind == BNM_KIND_FC && c->generic_ok && bnmk_fused_f32_supported(c->gdesc, sh.dbl, 0);
+        c->cnn_fused_ok = m.kind == BNM_KIND_CNN && c->cnn_li_frags && c->generic_ok && bnmk_cnn_li_fused_supported(c->channels, c->gdesc);
     }
     // ---- ternary ALU path ------------------------------------------------------------------------------
     if (m.kind == BNM_KIND_FC && all_tern && nfc == 4) {
@@ -482,18 +484,25 @@ const char *bnm_ctx_last_kernel(bnm_ctx *c) {
 }
 
 int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
-    if (!c || variant < 0 || (variant > 3 && variant < 101) || (variant > 164 && variant < 301) || variant > 316) return fail(BNM_EINVAL, "bad argument");
+    if (!c || variant < 0 || (variant > 4 && variant < 101) || (variant > 164 && variant < 301) || (variant > 316 && variant < 401) || variant > 416)
+        return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     c->cnn_auto = false;      // (an explicit choice holds for every call size)
-    if (variant == 3 || variant > 300) {      // the lane = image kernel (301..316: tiles per take)
+    if (variant == 3 || variant == 4 || variant > 300) {      // the lane = image kernel (301..316: tiles per take; 4 / 401..416: the FC tail as its own launch)
         if (!c->cnn_li_frags) return fail(BNM_EUNSUPPORTED, "the lane = image front end serves CNN models of up to 170 channels");
         c->cnn_variant = 3;
-        c->cnn_li_grab = variant > 300 ? (uint32_t)(variant - 300) : 1u;
+        c->cnn_fuse_tail = !(variant == 4 || variant > 400);
+        c->cnn_li_grab = variant > 400 ? (uint32_t)(variant - 400) : variant > 300 ? (uint32_t)(variant - 300) : 1u;
         return BNM_OK;
     }
     c->cnn_variant = variant == 0 ? 0 : 1;
     c->cnn_grab = variant == 2 ? 0u : variant > 100 ? (uint32_t)(variant - 100) : 8u;
     return BNM_OK;
+}
+
+int bnm_ctx_cnn_tail_fused(const bnm_ctx *c) {
+    if (!c) return BNM_EINVAL;
+    return (c->cnn_fused_ok && c->cnn_fuse_tail && c->cnn_variant == 3 && c->path == BNM_PATH_FUSED_MFMA) ? 1 : 0;
 }
 
 int bnm_ctx_set_float_mode(bnm_ctx *c, int mode, int groups) {

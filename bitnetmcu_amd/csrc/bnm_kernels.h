@@ -149,6 +149,13 @@ void bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uin
 uint32_t bnmk_cnn_li_waves(uint32_t C);      // waves per workgroup; 0: the kernel does not serve this channel count
 hipError_t bnmk_cnn_front_li(const int8_t *d_images, uint64_t n, const void *d_frags, const int *d_bias, uint32_t C, int8_t *d_acts,
                              uint32_t acts_stride, uint32_t *d_counter, uint32_t grab, hipStream_t s);
+// the lane = image front end with the FC tail fused into the same wave (bnm_cnn_li_fused.hip): images -> class ids (+ logits), one
+// launch, no act rows in HBM.  tail_frags / d: the generic kernel's fragment image and descriptor of the model's FC tail (the
+// image must be followed by 16 KiB of readable padding: fragment reads run a few KiB ahead of the last fragment).
+bool bnmk_cnn_li_fused_supported(uint32_t C, const BnmGenericDesc &d);
+hipError_t bnmk_cnn_li_fused(const int8_t *d_images, uint64_t n, const void *d_frags, const int *d_bias, uint32_t C, const void *d_tail_frags,
+                             const BnmGenericDesc &d, bool dbl, uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t grab,
+                             hipStream_t s);
 constexpr int BNM_CNN_WTAB_DWORDS = 20;      // per (band, channel); 2 bands x C rounded up to 64 channels
 void bnm_cnn_weight_table(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int *out);
 

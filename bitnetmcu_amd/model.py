@@ -163,9 +163,14 @@ class Context:
     def set_cnn_variant(self, variant):
         """1: conv1 on the matrix cores, a lane = a channel, dynamic image batches; 2: fixed share per wave; 100 + g: batches of g
         images; 0: the all-VALU front end of round 1; 3: the lane = image kernel (all three convolutions on the matrix cores;
-        300 + g: g tiles per take)"""
+        300 + g: g tiles per take; the FC tail runs in the same wave where it fits - 4 / 400 + g: the tail as its own launch)"""
         L.check(self._lib, self._lib.bnm_ctx_set_cnn_variant(self._h, variant), "bnm_ctx_set_cnn_variant")
-        self.cnn_variant = 0 if variant == 0 else 3 if (variant == 3 or variant > 300) else 1
+        self.cnn_variant = 0 if variant == 0 else 3 if (variant in (3, 4) or variant > 300) else 1
+
+    @property
+    def cnn_tail_fused(self):
+        """True when calls that take the lane = image front end run ONE kernel (front end + FC tail in the same wave)."""
+        return self._lib.bnm_ctx_cnn_tail_fused(self._h) == 1
 
     def release_stream(self, stream):
         """Drop the scratch buffers and the counter block the context keeps for `stream` (a torch.cuda.Stream); synchronises it."""

@@ -177,7 +177,11 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
                            int32_t *logits);
 /* CNN front end.  3 (the default up to 170 channels): the lane = image kernel - a wave owns 32 images and walks the channels, all
  * three convolutions are Toeplitz products on the matrix cores, the ReLUNorm is fused; serves up to 170 channels
- * (BNM_EUNSUPPORTED beyond); 300 + g (g = 1..16): g 32-image tiles per take from the work counter.  1 (the default beyond 170
+ * (BNM_EUNSUPPORTED beyond); 300 + g (g = 1..16): g 32-image tiles per take from the work counter.  Where the model's FC tail fits
+ * (act row of at most 256 bytes = 64 channels, FC layers at most 96 wide, no FP1.3.0 +128: every CNN of the reference's zoo) the
+ * SAME wave also runs the tail - one kernel from the image bytes to the class id, nothing but 256 + 4 bytes per image through HBM
+ * (bnm_ctx_cnn_tail_fused says so); 4 / 400 + g: the lane = image kernel with the tail as its own launch over act rows in per-stream
+ * scratch (what every other model gets; kept selectable for A/B measurements).  1 (the default beyond 170
  * channels): a lane = a channel, conv1 on the matrix cores, waves take batches of 8 images from a device-wide work counter; models
  * whose channel count leaves 1..16 channels beyond a multiple of 32 (16, 48, 80 ... channels) run those channels two images per
  * work item.  2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the
@@ -188,6 +192,7 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
  * bnm_ctx_last_kernel names what the last call really ran.  An explicit choice holds for every call size. */
 BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
 BNM_API int bnm_ctx_get_cnn_variant(const bnm_ctx *c);      /* the setting: 3, 1 or 0 */
+BNM_API int bnm_ctx_cnn_tail_fused(const bnm_ctx *c);       /* 1: calls that take the lane = image front end run the one-kernel form */
 /* The kernels the context's LAST inference call launched (bnm_infer_device / _host / _float_device; the first chunk's of a call
  * that runs in chunks), by name and in launch order, joined by '+': e.g. "fused_fc_dual_kernel", "fused_fc_dual_kernel+fused_fc_kernel"
  * (a remainder of fewer than 64 images), "cnn_li_kernel+fused_fc_kernel", "cnn_front_mfma_kernel+fused_fc_kernel" (an AUTO context's

@@ -121,7 +121,7 @@ def test_cnn_many_chunks_all_kernels(gpu_ok, orc):
     synth.fill_device(imgs, first=0, dist=DIST_U)
     cls = torch.empty(n, dtype=torch.int32, device="cuda")
     ref = None
-    for variant in (0, 2, 116, 1):
+    for variant in (0, 2, 116, 1, 4, 3):      # (4: lane = image kernel + tail launches over 2^22-image chunks; 3: the one-kernel form)
         ctx.set_cnn_variant(variant)
         cls.fill_(-1)
         ctx.infer_device(imgs, cls)

@@ -201,8 +201,10 @@ def test_cnn_front_end_both_kernels(name, gpu_ok, orc):
     x = np.concatenate([synth.images(123, 1501, DIST_U), synth.images(9, 1502, DIST_M), np.zeros((2, 256), np.int8),
                         np.full((2, 256), -128, np.int8), np.full((2, 256), 127, np.int8)])
     want = om.infer(x, logits=True)
-    for variant in (3, 302, 1, 0):
+    assert ctx.cnn_tail_fused        # every CNN of the zoo: the FC tail runs inside the lane = image kernel's wave (one kernel)
+    for variant in (3, 302, 4, 402, 1, 0):   # 4 / 402: the lane = image kernel with the tail as its own launch
         ctx.set_cnn_variant(variant)
+        assert ctx.cnn_tail_fused == (variant in (3, 302))
         # (<= 16 channels: two images per item, the last one or two images through the single-image instantiation)
         for n in (len(x), 1, 5, 2, 3, 4, 1000, 31, 32, 33, 65):
             got = ctx.infer(x[:n], logits=True)
@@ -638,13 +640,15 @@ def test_last_kernel_names_what_the_call_ran(gpu_ok):
     assert ctx.last_kernel == ""
     C = model.layer(0).out_channels
     assert C == 64 and ctx.cnn_variant == 3
-    for n, front in ((2 * C * C - 1, "cnn_front_mfma_kernel"), (2 * C * C, "cnn_li_kernel"), (1, "cnn_front_mfma_kernel")):
+    for n, front in ((2 * C * C - 1, "cnn_front_mfma_kernel"), (2 * C * C, "cnn_li_fused_kernel"), (1, "cnn_front_mfma_kernel")):
         got = ran(ctx, n)
         assert got.split("+")[0] == front, (n, got)
         assert ctx._lib.bnm_ctx_get_cnn_variant(ctx._h) == 3             # the setting does not move
         assert set(bench.kernel_name(b, ctx, model, n, False).split("+")) == set(got.split("+")), (n, got)
     ctx.set_cnn_variant(3)                                               # named: holds for every call size
-    assert ran(ctx, 7).split("+")[0] == "cnn_li_kernel"
+    assert ran(ctx, 7) == "cnn_li_fused_kernel"                          # (front end + FC tail: the call's only launch)
+    ctx.set_cnn_variant(4)                                               # the tail as its own launch
+    assert ran(ctx, 7) == "cnn_li_kernel+fused_fc_kernel"
     ctx.set_cnn_variant(1)
     assert ran(ctx, 20000).split("+")[0] == "cnn_front_mfma_kernel"
     ctx.set_cnn_variant(0)
@@ -1194,11 +1198,11 @@ def test_fuzz_random_cnn_models(seed, gpu_ok, orc):
                         np.full((2, 256), 127, np.int8)])
     want = om.infer(x, logits=True)
     ctx = b.Context(model)
-    for variant in (3, 1, 0):
+    for variant in (3, 4, 1, 0):     # (3: the one-kernel form where the tail fits it - C <= 64, layers <= 96 wide -, else as 4)
         try:
             ctx.set_cnn_variant(variant)
         except b.BnmError:
-            assert variant == 3 and C > 170      # the lane = image kernel's records must fit the LDS beside six waves
+            assert variant in (3, 4) and C > 170      # the lane = image kernel's records must fit the LDS beside six waves
             continue
         for n in (len(x), 5, 6):
             got = ctx.infer(x[:n], logits=True)
@@ -1277,7 +1281,7 @@ def test_cnn_kernels_with_full_range_conv_weights(C, gpu_ok, orc):
                         synth.images(C, 300, DIST_U), synth.images(C, 300, DIST_M)])
     want = om.infer(x, logits=True)
     ctx = b.Context(model)
-    for variant in (3, 1, 0):
+    for variant in (3, 4, 1, 0):
         ctx.set_cnn_variant(variant)
         for n in (len(x), 33, 1):
             got = ctx.infer(x[:n], logits=True)
@@ -1295,7 +1299,7 @@ def test_cnn_default_front_end_on_both_sides_of_the_small_call_rule(name, gpu_ok
     n0 = 2 * C * C
     x = synth.images(11, n0 + 40, DIST_U)
     want = util.OracleModel(model, orc).infer(x, logits=True)
-    for variant in (None, 3, 1):
+    for variant in (None, 3, 4, 1):
         ctx = b.Context(model)
         if variant is not None:
             ctx.set_cnn_variant(variant)
@@ -1317,14 +1321,16 @@ def test_cnn_lane_image_kernel_on_a_large_sample(C, gpu_ok, orc):
     n = 300_000
     x = synth.images(3, n, DIST_U)
     acts, outs = {}, {}
-    for key, variant in (("channel", 1), ("li", 3), ("li again", 3)):
+    # ("li": ids and logits from the one-kernel form - the FC tail inside the front end's wave -, act bytes from cnn_li_kernel, which
+    # the tap always runs; "li unfused": ids and logits from cnn_li_kernel + the tail's own launch)
+    for key, variant in (("channel", 1), ("li", 3), ("li again", 3), ("li unfused", 4)):
         ctx = b.Context(model)
         ctx.set_cnn_variant(variant)
-        assert ctx.cnn_variant == variant
+        assert ctx.cnn_variant == min(variant, 3) and ctx.cnn_tail_fused == (variant == 3)
         acts[key] = ctx.activations(x)[:, :4 * C]
         outs[key] = ctx.infer(x, logits=True)
         ctx.close()
-    for key in ("li", "li again"):
+    for key in ("li", "li again", "li unfused"):
         assert np.array_equal(acts[key], acts["channel"]), (C, key, int((acts[key] != acts["channel"]).sum()))
         assert np.array_equal(outs[key][0], outs["channel"][0]) and np.array_equal(outs[key][1], outs["channel"][1]), (C, key)
     want = util.OracleModel(model, orc).infer(x[:3000], logits=True)
