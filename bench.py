@@ -319,6 +319,11 @@ def main():
     ap.add_argument("--ternary-variant", type=int, default=-1,
                     help="ternary ALU kernel: 2 streamed weights, two images per lane (default), 1 one image per lane, 0 round 1's kernel")
     ap.add_argument("--work-batch", type=int, default=0, help="fused kernels: tiles / pairs per take from the work counter (0 = default)")
+    ap.add_argument("--input", choices=("int8", "float"), default="int8",
+                    help="float: the timed call is bnm_infer_float_device on float32 images (the synthetic int8 images x 1/127) - the "
+                         "fc_float_input row as the main workload (profiling runs)")
+    ap.add_argument("--float-mode", type=int, default=0, help="--input float: 0 the fused float-input kernel where it exists, 2 quantise + infer")
+    ap.add_argument("--float-groups", type=int, default=0, help="--input float: 8-image groups in flight per wave of the fused kernel (0 default, 2, 4)")
     ap.add_argument("--float-images", type=int, default=100_000_000, help="images of the float-input rows (102.4 GB of float32 at 1e8; 0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -403,7 +408,15 @@ def main():
     b.synth.fill_device(images, first=first, dist=a.dist)
     torch.cuda.synchronize()
 
-    elapsed, launch_ms = timed_steps(torch, lambda: ctx.infer_device(images, cls, logits), a.steps, a.warmup, barrier)
+    xf = None
+    if a.input == "float":
+        ctx.set_float_mode(a.float_mode, a.float_groups)
+        xf = b.synth.float_images_device(images)
+        torch.cuda.synchronize()
+        step = lambda: ctx.infer_float_device(xf, cls, logits)
+    else:
+        step = lambda: ctx.infer_device(images, cls, logits)
+    elapsed, launch_ms = timed_steps(torch, step, a.steps, a.warmup, barrier)
     if distributed:
         # every rank's own time for the K steps, gathered: the line reports the MAX (the contract) and the list, so that a
         # straggler GPU is visible in the one line
@@ -422,24 +435,31 @@ def main():
     dg = digest.cpu().numpy()
     digest_hex = hex(int(dg[0].astype(np.uint64)))
     hist = dg[1:].astype(np.int64)
-    headline = a.model == "fc_4bitsym_64" and a.dist == 0 and n_global == 100_000_000 and not a.header
+    headline = a.model == "fc_4bitsym_64" and a.dist == 0 and n_global == 100_000_000 and not a.header and a.input == "int8"
     if rank == 0 and not a.no_verify:
-        verified = checker().verify_sample(torch, model, images, cls, logits, n) and int(hist.sum()) == n_global
+        if a.input == "float":
+            verified = checker().verify_float_sample(torch, model, xf, cls, logits, n) and int(hist.sum()) == n_global
+        else:
+            verified = checker().verify_sample(torch, model, images, cls, logits, n) and int(hist.sum()) == n_global
         if headline:   # every one of the 1e8 class ids, through the order-independent digest the oracle produced on host cores
             verified = verified and int(dg[0].astype(np.uint64)) == ORACLE_DIGEST_1E8
 
     if rank == 0:
         counters = load_counters(b.LIB_PATH)
         total = n_global * a.steps
-        bpi = 256 + 4 + (4 * model.num_classes if a.logits else 0)
+        bpi = (1024 if a.input == "float" else 256) + 4 + (4 * model.num_classes if a.logits else 0)
         avg_ms = float(np.mean(launch_ms))
         achieved = n * bpi / (avg_ms * 1e-3) / 1e9
         kname = kernel_name(b, ctx, model, n, a.cnn_variant >= 0)
+        if a.input == "float":
+            kname = "fused_fc_f32_kernel" if ctx.float_fused else "quantize_input_kernel+" + kname
         # the box's plain read rate over the same resident images, same process, same stream (bnm_stream_read_device)
         sink = torch.zeros(1, dtype=torch.int32, device=dev)
-        _, rd_ms = timed_steps(torch, lambda: b.synth.stream_read_device(images, sink), 5, 2)
+        src_t = xf if a.input == "float" else images
+        _, rd_ms = timed_steps(torch, lambda: b.synth.stream_read_device(src_t, sink), 5, 2)
         rd = float(np.median(rd_ms))
-        stream_read = {"ms": rd, "bytes": n * 256, "GB/s": n * 256 / (rd * 1e-3) / 1e9,
+        in_bytes = 1024 if a.input == "float" else 256
+        stream_read = {"ms": rd, "bytes": n * in_bytes, "GB/s": n * in_bytes / (rd * 1e-3) / 1e9,
                        "what": "plain nontemporal 16 B/lane loads of this rank's resident images, nothing written; median of 5 launches after 2"}
         traffic, traffic_source = None, None
         tj = counters.get("pmc_traffic.json")
@@ -463,8 +483,10 @@ def main():
             "dtype": "i8",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[{1 if world == 1 else 4}]: {a.model}, {n} synthetic 16x16 int8 images per GPU resident in HBM "
-                            f"(dist {'U' if a.dist == 0 else 'M'}), class ids{' + logits' if a.logits else ''} written",
+                "workload": (f"BASELINE configs[{1 if world == 1 else 4}]: {a.model}, {n} synthetic 16x16 int8 images per GPU resident in HBM "
+                             f"(dist {'U' if a.dist == 0 else 'M'}), class ids{' + logits' if a.logits else ''} written") if a.input == "int8" else
+                            (f"SURVEY 8(f) row 1: {a.model}, {n} synthetic 16x16 FLOAT32 images per GPU resident in HBM (int8 dist "
+                             f"{'U' if a.dist == 0 else 'M'} x 1/127), quantised as test_inference.py:140-141 inside the kernel, class ids written"),
                 "images_per_gpu": n,
                 "global_images": n_global,
                 "path": ctx.path,
@@ -501,7 +523,7 @@ def main():
             "digest_expected": hex(ORACLE_DIGEST_1E8) if headline else None,
             "class_histogram": hist.tolist(),
         }
-        if world == 1 and not a.no_extra:
+        if world == 1 and not a.no_extra and a.input == "int8":
             out["extra_configs"] = extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read)
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(b, a.model, a.dist, a.cpu_seconds)

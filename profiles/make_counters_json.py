@@ -70,6 +70,7 @@ def main():
             fb = d["FETCH_SIZE"] * 1024 * 2
             wb = d.get("WRITE_SIZE", 0.0) * 1024
             e["hbm_bytes_per_launch"] = fb + wb
+            e["hbm_bytes_per_image"] = (fb + wb) / images
             if name.startswith("fused_fc_dual"):
                 json.dump({"hbm_bytes_per_launch": fb + wb, "fetch_bytes": fb, "write_bytes": wb, "source": tag, "kernel": key[0],
                            "mangled": e.get("mangled"), "code_sha1": e.get("code_sha1"),

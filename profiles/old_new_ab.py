@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One arm of an old-library / new-library A/B on ONE box (profiles/r03_old_new_ab.sh alternates processes): loads the library named
+"""One arm of an old-library / new-library A/B on ONE box (profiles/r03/r03_old_new_ab.sh alternates processes): loads the library named
 by BNM_AB_LIBRARY (bound non-strictly: an older build lacks the newest symbols), fills 1e8 images, and times the default kernel
 of the headline model (ids; ids + logits), the generic kernel (variant 4) and the default kernel of every zoo model named in
 BNM_AB_MODELS - 3 warm-ups, 15 launches, median / min."""

@@ -727,8 +727,23 @@ def test_bench_json_contract(gpu_ok):
     assert abs(mf["achieved_per_s"] - d["value"] * 26 / 32) < 1e-6 * mf["achieved_per_s"] and 0 < mf["frac"] < 1
     assert 0 < mf["busy_frac"] < 1 and "code_sha1" in mf["busy_frac_source"]
     assert d["roofline"]["traffic"] is None      # (replayed for the headline workload - 1e8 images - only)
-    assert d["digest"].startswith("0x") and "header text" in d["config"]["model_source"]
+    # the headline row parses the REFERENCE'S OWN header bytes (a staged byte-identical copy of
+    # BitNetMCU_model_fc.h: tests/golden/_ref_headers/, oracle/build_oracle.py), and so does the CNN row
+    assert d["digest"].startswith("0x") and "the reference's own BitNetMCU_model_fc.h" in d["config"]["model_source"], d["config"]["model_source"]
+    assert d["roofline"]["launched"] == "fused_fc_dual_kernel+fused_fc_kernel"      # 300,000 = 4,687 pairs + 32 images
     ex = d["extra_configs"]
+    assert "the reference's own BitNetMCU_model_cnn.h" in ex["cnn_64"]["model_source"]
+    # float images -> class ids in ONE kernel, its own HBM roofline on 1,028 bytes per inference
+    fl = ex["fc_float_input"]
+    assert fl["verified_vs_oracle"] is True and fl["kernel"] == "fused_fc_f32_kernel" and fl["launches_per_step"] == 1
+    assert fl["roofline"]["algorithmic_bytes_per_inference"] == 1028 and 0 < fl["roofline"]["frac"] <= 1
+    assert ex["fc_float_input_two_kernels"]["kernel"].startswith("quantize_input_kernel+") and ex["fc_float_input_two_kernels"]["verified_vs_oracle"] is True
+    # the CNN is one launch per call; its row says what binds it in the kernel's own terms
+    assert ex["cnn_64"]["launched"] in ("cnn_li_fused_kernel", "cnn_front_mfma_kernel+fused_fc_kernel")
+    assert "int8_ops_algorithmic" in ex["cnn_64"]["roofline"] and ex["cnn_64"]["roofline"]["int8_ops_algorithmic"]["per_image"] == 2 * 236416
+    # every row once more, compact, inside roofline (kept whole by the driver) and as the line's last key
+    assert set(d["summary_rows"]) == set(k for k in ex if "roofline" in ex[k]) and list(d)[-1] == "summary_rows"
+    assert d["roofline"]["rows"]["cnn_64"] == d["summary_rows"]["cnn_64"]
     for k in ("ternary_alu", "ternary_mfma_generic", "cnn_64", "fc_generic_kernel", "fc_logits", "fc_dist_m", "doc12k_binary",
               "doc12k_ternary", "doc12k_2bit", "doc12k_8bit"):
         assert ex[k]["verified_vs_oracle"] is True and ex[k]["value"] > 0 and "roofline" in ex[k], k
@@ -739,9 +754,8 @@ def test_bench_json_contract(gpu_ok):
     assert ex["ternary_alu"]["path"] == b.PATH_TERNARY_ALU and ex["ternary_mfma_generic"]["path"] == b.PATH_FUSED_MFMA
     # the VALU-bound configs quote the ALGORITHMIC fraction (MACs at 4 per dot4 lane), which can only be below the pipe's utilisation
     assert ex["ternary_alu"]["roofline"]["macs_per_image"] == 43968 and ex["cnn_64"]["roofline"]["macs_per_image"] == 236416
-    for k in ("ternary_alu", "cnn_64"):
-        if "pipe_utilisation" in ex[k]["roofline"]:
-            assert ex[k]["roofline"]["frac"] <= ex[k]["roofline"]["pipe_utilisation"]
+    if "pipe_utilisation" in ex["ternary_alu"]["roofline"]:
+        assert ex["ternary_alu"]["roofline"]["frac"] <= ex["ternary_alu"]["roofline"]["pipe_utilisation"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"]
     for row in ("ternary_alu", "cnn_64"):          # configs[2] / configs[3] carry the reference's CPU rate as well
