@@ -631,6 +631,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
                      "value": rate, "unit": "inferences/s", "avg_launch_ms": float(np.mean(ms)), "median_launch_ms": float(np.median(ms)),
                      "min_launch_ms": float(np.min(ms)),
                      "kernel": "fused_fc_f32_kernel" if fused else "quantize_input_kernel+" + kernel_name(b, ctx, model, count),
+                     "launched": ctx.last_kernel,
                      "launches_per_step": 1 if fused else 2 * ((count + (1 << 22) - 1) >> 22), "path": ctx.path, "verified_vs_oracle": ok,
                      "note": note,
                      "roofline": {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
