@@ -15,6 +15,7 @@ DECL(bnmk_generic_launch_m8_k4);
 DECL(bnmk_generic_launch_m8_k8);
 DECL(bnmk_generic_launch_m8_k16);
 DECL(bnmk_generic_launch_m2_t2);
+DECL(bnmk_generic_launch_m4_t2);
 #undef DECL
 
 namespace {
@@ -28,7 +29,7 @@ launch_fn launcher_of(uint32_t mmax, int tiles, uint32_t kt0) {
     if (mmax == 6) return (tiles != 2 && kt0 == 8) ? bnmk_generic_launch_m6_k8 : nullptr;
     switch (mmax) {
         case 2: return tiles == 2 ? bnmk_generic_launch_m2_t2 : bnmk_generic_launch_m2;
-        case 4: return tiles == 2 ? nullptr : bnmk_generic_launch_m4;
+        case 4: return tiles == 2 ? (kt0 == 8 ? bnmk_generic_launch_m4_t2 : nullptr) : bnmk_generic_launch_m4;
     }
     return nullptr;
 }

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
     constexpr int ROW = 32 * KT0;
     // layer-1 K-steps whose B operands are held in VGPRs at a time (x T tiles x 4 registers): all of a 256-byte row with one
     // tile per wave, half of it with two (the refill then starts after the first half's MFMAs)
-    constexpr int KC = KT0 * T <= 8 ? KT0 : 8 / T;
+    // (4-tile class with two tiles: two K-steps at a time - its two tiles' 128 accumulator registers leave room for no more)
+    constexpr int KC = KT0 * T <= 8 ? KT0 : (MMAX >= 4 && T == 2) ? 2 : 8 / T;
     constexpr int UNIT = T * G::TILE;              // bytes of the T consecutive tiles a wave handles per iteration
     static_assert(T == 1 || T == 2, "one or two tiles per wave");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -299,7 +300,8 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
     const uint32_t lane16 = 16u * (uint32_t)lane;
     const uint32_t rd_off = tile_off + (uint32_t)(lane & 31) * (uint32_t)ROW + 16u * ((uint32_t)(lane >> 5) ^ G::mask((uint32_t)(lane & 31)));
     // rows of up to 256 bytes: the K-steps' B-operand addresses themselves stay in registers (no XOR per K-step and tile)
-    constexpr bool PRE_RD = KT0 <= 8;
+    // (not in the 4-tile class with two tiles: eight loop-carried registers it does not have)
+    constexpr bool PRE_RD = KT0 <= 8 && !(MMAX >= 4 && T == 2);
     uint32_t rda[PRE_RD ? KT0 : 1];
     if constexpr (PRE_RD) {
 #pragma unroll

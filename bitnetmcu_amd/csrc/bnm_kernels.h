@@ -89,7 +89,7 @@ struct BnmGenericDesc {      // passed to the kernel by value
 // waves per SIMD an instantiation of the generic kernel is compiled for (its launch bound is 256 * this many threads);
 // tiles: image tiles a wave carries per iteration (1 or 2)
 constexpr int bnmk_generic_wps(int mmax, int kt0, int sp, int tiles) {
-    return mmax == 2 ? (tiles == 2 || kt0 == 16 ? 3 : 4) : mmax == 4 ? ((sp == 2 && kt0 == 16) ? 2 : 3) : mmax == 6 ? 2 : 1;
+    return mmax == 2 ? (tiles == 2 || kt0 == 16 ? 3 : 4) : mmax == 4 ? ((tiles == 2 || (sp == 2 && kt0 == 16)) ? 2 : 3) : mmax == 6 ? 2 : 1;
 }
 // variant ids of the generic kernel in bnm_ctx_set_tuning / bnm_ctx_get_variant: 4 = tiles per wave chosen by the library,
 // 7 / 8 = one / two tiles per wave forced (A/B measurements)

@@ -367,6 +367,60 @@ def test_infer_device_under_graph_capture(name, gpu_ok, orc):
     ctx.close()
 
 
+def test_one_kernel_calls_capture_without_a_warm_up(gpu_ok, orc):
+    """The fused float-input call and the one-kernel CNN call are ONE dispatch each and use no scratch (a captured launch takes a
+    preallocated counter block): they can be captured into a HIP graph on a stream the context has never seen - no eager call first -
+    and replayed on new inputs; ids (and the CNN's logits) against numpy quantisation / the oracle."""
+    import torch
+    from bitnetmcu_amd import harness
+    # float images -> class ids
+    model = util.load_golden_model("fc_4bitsym_64")
+    ctx = b.Context(model)
+    n = 5000
+    xf = torch.zeros((n, 256), dtype=torch.float32, device="cuda")
+    cls = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        ctx.infer_float_device(xf, cls)
+    assert ctx.last_kernel == "fused_fc_f32_kernel"
+    rng = np.random.default_rng(3)
+    for k in range(3):
+        x = (rng.normal(size=(n, 256)) * (10.0 ** (k - 1))).astype(np.float32)
+        xf.copy_(torch.from_numpy(x).cuda())
+        cls.fill_(-1)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(cls.cpu().numpy().astype(np.uint32), util.OracleModel(model, orc).infer(harness.quantize_input(x))), k
+    ctx.close()
+    # CNN, one kernel (named, so that the call's size does not send it to the channel kernel)
+    model = util.load_golden_model("mcu_cnn_48")
+    ctx = b.Context(model)
+    ctx.set_cnn_variant(3)
+    n = 777
+    x8 = torch.zeros((n, 256), dtype=torch.int8, device="cuda")
+    cls = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    lg = torch.empty((n, model.num_classes), dtype=torch.int32, device="cuda")
+    side2 = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=side2):
+        ctx.infer_device(x8, cls, lg)
+    assert ctx.last_kernel == "cnn_li_fused_kernel"
+    for k in range(3):
+        xin = synth.images(1000 * k, n, DIST_U)
+        x8.copy_(torch.from_numpy(xin).cuda())
+        cls.fill_(-1)
+        torch.cuda.synchronize()
+        g2.replay()
+        torch.cuda.synchronize()
+        want_cls, want_lg = util.OracleModel(model, orc).infer(xin, logits=True)
+        assert np.array_equal(cls.cpu().numpy().astype(np.uint32), want_cls) and np.array_equal(lg.cpu().numpy(), want_lg), k
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", ["fc_4bitsym_64", "tern_96", "cnn_64"])
 def test_ragged_and_empty_batches(name, gpu_ok, orc):
     model = util.load_golden_model(name)
