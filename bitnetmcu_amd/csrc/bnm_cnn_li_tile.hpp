@@ -22,6 +22,26 @@ BNM_DEVICE uint32_t relu_pair16(int a, int b) {
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// Two pairs of conv1 sums -> two packed int16 pairs, xa = [a0 >> 4 | (a1 >> 4) << 16], xb likewise: ONE SDWA shift per value writes its
+// low 16 bits (the shifted sums fit 15) straight into its half of the pair - no v_cvt_pk_i16_i32.  Inline asm, so three things hipcc
+// would do for its own instructions are done by hand: (1) the statement is ordered BEHIND a compiler-visible reader of the same MFMA
+// result (`after` is that reader's output, an unused input here): hipcc has then placed the MFMA -> VALU wait states, and the MFMA's
+// write-back - its dead rows included - is over before an output register of this statement can be written; (2) the two writes of one
+// register are an instruction apart and (3) an s_nop closes the statement (dst_sel forwarding, as in sdwa_shift_pack16).
+// profiles/check_mfma_hazards.py (a static test) walks the disassembly for the MFMAs issued AFTER the reader.
+BNM_DEVICE void shr4_pack_pairs2(int a0, int a1, int b0, int b1, uint32_t after, uint32_t &xa, uint32_t &xb) {
+    asm("v_ashrrev_i32_sdwa %0, %6, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %1, %6, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %0, %6, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32_sdwa %1, %6, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(xa), "=&v"(xb) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "s"(4), "v"(after));
+}
+BNM_DEVICE uint32_t relu_pk16(uint32_t p) {
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), z));
+}
+
 // Byte planes of pooled values for conv3's operand.  A pooled value arrives as V = 16 x (its 24-bit ReLU'd sum) = (P << 8) | low
 // bits: plane p of P is byte p + 1 of V, and v_perm_b32 gathers bytes of two registers - 7 instructions for the three planes of
 // four values (two pair gathers per pair, one merge per plane).  Compiler-visible on purpose: an earlier inline-asm version (SDWA
