@@ -34,3 +34,23 @@ def test_reference_dll_through_harness(name, orc):
     x = np.concatenate([synth.images(0, n // 2, DIST_U), synth.images(0, n // 2, DIST_M)])
     st = harness.cross_check(lib, om.infer, x)
     assert st["counter"] == n and st["mismatch"] == 0
+
+
+def test_the_two_statements_of_the_input_quantisation_agree():
+    """oracle/checker.quantize_input (the checker's verbatim restatement of test_inference.py:140-141) and
+    bitnetmcu_amd.harness.quantize_input (the product-side host statement) on the edge rows the GPU tests use."""
+    import sys
+    sys.path.insert(0, os.path.join(util.REPO, "oracle"))
+    import checker
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(2000, 256)).astype(np.float32)
+    x[0] = 0.0
+    x[1] = np.linspace(-1, 1, 256, dtype=np.float32)
+    x[2, :] = 0.5; x[2, 0] = 127.0
+    x[3, :] = -1.5; x[3, 0] = 127.0
+    x[4] = rng.integers(-300, 300, 256).astype(np.float32) / 2.0
+    x[5] *= np.float32(1e-7)
+    x[6] *= np.float32(1e20)
+    q = checker.quantize_input(x)
+    assert q.dtype == np.int8 and np.array_equal(q, harness.quantize_input(x))
+    assert q[0].tolist() == [0] * 256 and q[2, 1] == 0 and q[3, 1] == -2 and int(np.abs(q[1:]).max()) == 127

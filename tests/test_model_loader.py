@@ -156,3 +156,23 @@ def test_wrong_element_types_are_rejected():
         with pytest.raises(BnmError):
             Model.from_blob(bytes(b2))
     Model.from_blob(bytes(good))
+
+
+def test_staged_reference_headers_are_the_reference_files_and_parse_to_the_zoo_blobs():
+    """tests/golden/_ref_headers/ (staged by oracle/build_oracle.py where /root/reference exists, shipped to the GPU box): every
+    file has the sha256 its MANIFEST records, is byte-identical to the reference's file where that is present, and parses - through
+    the run-time text parser - to the committed weight blob.  bench.py / smoke() load the headline and CNN models from these bytes."""
+    import hashlib
+    import json
+    from bitnetmcu_amd import Model
+    d = os.path.join(util.GOLDEN, "_ref_headers")
+    if not os.path.isdir(d):
+        pytest.skip("no staged reference headers in this tree (a fresh clone that never saw /root/reference)")
+    man = json.load(open(os.path.join(d, "MANIFEST.json")))
+    assert {"fc_4bitsym_64", "cnn_64"} <= set(man)
+    for name, e in man.items():
+        raw = open(os.path.join(d, name + ".h"), "rb").read()
+        assert hashlib.sha256(raw).hexdigest() == e["sha256"], name
+        if os.path.isfile(e["origin"]):
+            assert raw == open(e["origin"], "rb").read(), name
+        assert Model.from_header(os.path.join(d, name + ".h")).to_blob() == Model.from_zoo(name).to_blob(), name
