@@ -613,6 +613,8 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         model, src = load_model_through_the_text_parser(b, model_name)
         ctx = b.Context(model, device=dev.index)
         ctx.set_float_mode(mode)
+        if model.kind == b.KIND_CNN:
+            ctx.set_cnn_variant(3)
         xf = b.synth.float_images_device(images[:count])
         c = cls[:count]
         torch.cuda.synchronize()
@@ -624,13 +626,14 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         _, rd_ms = timed_steps(torch, lambda: b.synth.stream_read_device(xf, sink), 3, 1)
         rd = float(np.median(rd_ms))
         fused = ctx.float_fused
+        fused_name = "cnn_li_fused_kernel<float>" if model.kind == b.KIND_CNN else "fused_fc_f32_kernel"
         bpi = BYTES_PER_INFERENCE_FLOAT
         g = rate * bpi / 1e9
         res[name] = {"model": model_name, "model_source": src, "images": count, "dist": "U", "steps": steps, "warmup": warmup,
                      "input": "float32 [n][256] resident in HBM: the synthetic int8 images x 1/127 (bitnetmcu_amd/synth.py float_images)",
                      "value": rate, "unit": "inferences/s", "avg_launch_ms": float(np.mean(ms)), "median_launch_ms": float(np.median(ms)),
                      "min_launch_ms": float(np.min(ms)),
-                     "kernel": "fused_fc_f32_kernel" if fused else "quantize_input_kernel+" + kernel_name(b, ctx, model, count),
+                     "kernel": fused_name if fused else "quantize_input_kernel+" + kernel_name(b, ctx, model, count, True),
                      "launched": ctx.last_kernel,
                      "launches_per_step": 1 if fused else 2 * ((count + (1 << 22) - 1) >> 22), "path": ctx.path, "verified_vs_oracle": ok,
                      "note": note,
@@ -642,6 +645,17 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         per = model_mfmas_per_image(b, model)
         res[name]["roofline"]["mfma"] = {"per_image": per, "achieved_per_s": rate * per, "peak_per_s": MFMA_I8_32X32X32_PEAK_PER_S,
                                          "frac": rate * per / MFMA_I8_32X32X32_PEAK_PER_S}
+        if model.kind == b.KIND_CNN:
+            # VALU-bound like the int8 form: the row's frac is the ALGORITHMIC VALU fraction (MACs at 4 per lane of a v_dot4), labelled;
+            # the HBM fraction of the 1,028 B per inference is kept beside it
+            macs = model_macs(b, model)
+            hb = res[name]["roofline"]
+            res[name]["roofline"] = {"bound": "valu", "unit": "wave64 VALU-pipe instructions/s", "peak": VALU_PEAK_WAVE_INSTR_PER_S,
+                                     "achieved": rate * macs / MACS_PER_WAVE_DOT4, "frac": rate * macs / MACS_PER_WAVE_DOT4 / VALU_PEAK_WAVE_INSTR_PER_S,
+                                     "frac_is": "ALGORITHMIC (MACs / 256 per image): no counter pass of this kernel binary is replayed",
+                                     "macs_per_image": macs, "hbm_frac": hb["frac"], "algorithmic_bytes_per_inference": bpi,
+                                     "moved_bytes_per_inference": hb["moved_bytes_per_inference"], "stream_read": hb["stream_read"],
+                                     "time_vs_stream_read": hb["time_vs_stream_read"]}
         ctx.close()
         del xf
         torch.cuda.empty_cache()
@@ -652,6 +666,11 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         float_row("fc_float_input", "fc_4bitsym_64", n_f, 10, 3, 0, "float images -> class ids, ONE kernel (bnm_fused_f32_kernel.hpp): HBM roofline on 1,028 B per inference")
         float_row("fc_float_input_two_kernels", "fc_4bitsym_64", n_f, 3, 1, 2, "the same call as quantise + infer (1,540 B moved per inference): what the fused kernel replaces")
         float_row("tern_float_input", "tern_96", n_f, 5, 2, 0, "the 4-tile class of the fused float-input kernel (ternary 96-96-96)")
+        # ... and the CNN: the one-kernel form with the quantisation in front of its convolution operands (VALU-bound like the int8 form:
+        # the HBM fraction of its 1,028 B per inference is small; `value` is what to compare with the cnn_64 row)
+        n_fc = min(n_f, 10_000_000)
+        float_row("cnn_float_input", "cnn_64", n_fc, 3, 1, 0, "float images -> class ids through the one-kernel CNN (quantisation fused; three waves per SIMD)")
+        float_row("cnn_float_input_two_kernels", "cnn_64", n_fc, 3, 1, 2, "the same call as quantise + the one-kernel CNN on int8")
 
     n_cnn = min(n, 10_000_000)
     # configs[2]: ternary 96-96-96, bit-unpack / sign-accumulate ALU kernel, no MFMA — bound by the VALU issue rate

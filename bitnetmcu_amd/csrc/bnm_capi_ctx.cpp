@@ -508,8 +508,9 @@ int bnm_ctx_cnn_tail_fused(const bnm_ctx *c) {
 int bnm_ctx_set_float_mode(bnm_ctx *c, int mode, int groups) {
     if (!c || mode < 0 || mode > 2 || (groups != 0 && groups != 2 && groups != 4)) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
-    if (mode == 1 && !c->f32_ok)
-        return fail(BNM_EUNSUPPORTED, "the fused float-input kernel serves FC models whose layers are at most 128 wide");
+    if (mode == 1 && !c->f32_ok && !c->cnn_fused_ok)
+        return fail(BNM_EUNSUPPORTED, "the fused float-input kernels serve FC models whose layers are at most 128 wide and CNN models "
+                                      "of up to 64 channels whose FC layers are at most 96 wide");
     if (groups && c->f32_ok && !bnmk_fused_f32_supported(c->gdesc, c->shape.dbl, groups))
         return fail(BNM_EUNSUPPORTED, "this many groups in flight are not instantiated for the model's tile class");
     c->float_mode = mode;
@@ -519,7 +520,9 @@ int bnm_ctx_set_float_mode(bnm_ctx *c, int mode, int groups) {
 
 int bnm_ctx_float_fused(const bnm_ctx *c) {
     if (!c) return BNM_EINVAL;
-    return (c->f32_ok && c->path == BNM_PATH_FUSED_MFMA && c->float_mode != 2) ? 1 : 0;
+    if (c->float_mode == 2 || c->path != BNM_PATH_FUSED_MFMA) return 0;
+    if (c->model.kind == BNM_KIND_CNN) return (c->cnn_fused_ok && c->cnn_fuse_tail && c->cnn_variant == 3) ? 1 : 0;
+    return c->f32_ok ? 1 : 0;
 }
 
 int bnm_ctx_set_work_batch(bnm_ctx *c, int tiles) {

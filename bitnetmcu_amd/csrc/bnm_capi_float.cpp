@@ -24,7 +24,7 @@ int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d
     hipStream_t s = (hipStream_t)stream;
     const uint32_t ncls = c->model.num_classes();
     // ONE kernel where it exists: floats in, class ids out (1,028 bytes per image instead of 1,540; bnm_fused_f32_kernel.hpp)
-    if (bnm_ctx_float_fused(c)) {
+    if (c->model.kind == BNM_KIND_FC && bnm_ctx_float_fused(c)) {
         uint32_t *block = nullptr;
         if (int e = work_block(c, s, &block)) return e;
         HIP_TRY(bnmk_fused_f32(c->gdesc, c->shape.dbl, c->f32_groups, c->grid_blocks, d_x, n, c->gfrags, d_cls, d_logits, block,
@@ -32,7 +32,16 @@ int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d
         c->last_kernel = "fused_fc_f32_kernel";
         return BNM_OK;
     }
-    if (c->float_mode == 1) return fail(BNM_EUNSUPPORTED, "the fused float-input kernel does not serve the context's current path");
+    // CNN models: the one-kernel form quantises in front of its convolution operands (cnn_li_fused_kernel<.., true>)
+    if (c->float_mode != 2 && cnn_one_kernel_call(c, n)) {
+        uint32_t *block = nullptr;
+        if (int e = work_block(c, s, &block)) return e;
+        HIP_TRY(bnmk_cnn_li_fused(d_x, true, n, c->cnn_li_frags, c->cnn_li_bias, c->channels, c->gfrags, c->gdesc, c->shape.dbl, d_cls, d_logits,
+                                  block, c->cnn_li_grab, s));
+        c->last_kernel = "cnn_li_fused_kernel<float>";
+        return BNM_OK;
+    }
+    if (c->float_mode == 1) return fail(BNM_EUNSUPPORTED, "no fused float-input kernel serves this call on the context's current path");
     // chunks of 2^22 images (1 GiB of int8 scratch per stream): quantise, then the model's kernels, in stream order
     const uint64_t chunk = 1ull << 22;
     DevBuf &q8 = stream_scratch(c, s).q8;

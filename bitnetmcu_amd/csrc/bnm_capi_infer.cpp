@@ -167,16 +167,13 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
     }
     // CNN, one kernel: the lane = image front end with the FC tail in the same wave (no act rows in HBM, no scratch, one launch
     // however many images) wherever that kernel serves the model and the lane = image front end would run this call
-    {
-        const bool small_call = c->cnn_auto && n < 2ull * c->channels * c->channels;
-        if (!d_acts_tap && path == BNM_PATH_FUSED_MFMA && c->cnn_fused_ok && c->cnn_fuse_tail && c->cnn_variant == 3 && !small_call && n < (1ull << 31)) {
-            uint32_t *block = nullptr;
-            if (int e = work_block(c, s, &block)) return e;
-            HIP_TRY(bnmk_cnn_li_fused(d_images, n, c->cnn_li_frags, c->cnn_li_bias, c->channels, c->gfrags, c->gdesc, c->shape.dbl, d_cls, d_logits,
-                                      block, c->cnn_li_grab, s));
-            c->last_kernel = "cnn_li_fused_kernel";
-            return BNM_OK;
-        }
+    if (!d_acts_tap && cnn_one_kernel_call(c, n)) {
+        uint32_t *block = nullptr;
+        if (int e = work_block(c, s, &block)) return e;
+        HIP_TRY(bnmk_cnn_li_fused(d_images, false, n, c->cnn_li_frags, c->cnn_li_bias, c->channels, c->gfrags, c->gdesc, c->shape.dbl, d_cls, d_logits,
+                                  block, c->cnn_li_grab, s));
+        c->last_kernel = "cnn_li_fused_kernel";
+        return BNM_OK;
     }
     // CNN: front end (conv/pool/ReLUNorm fused) -> int8 [n][4C] -> FC tail
     const uint32_t W = c->channels * 4u;

@@ -275,6 +275,14 @@ int resolve_path(bnm_ctx *c);
 int work_block(bnm_ctx *c, hipStream_t s_real, uint32_t **out);
 bnm_ctx::StreamScratch &stream_scratch(bnm_ctx *c, hipStream_t s_real);
 hipStream_t stream_key(hipStream_t s);
+// a call of n images on this CNN context runs the one-kernel form (lane = image front end + FC tail in the same wave): the model
+// fits it, nobody chose another front end, and - for a context left to itself - the call is not a small one (fewer than 2 C^2
+// images go to the channel kernel)
+inline bool cnn_one_kernel_call(const bnm_ctx *c, uint64_t n) {
+    const bool small_call = c->cnn_auto && n < 2ull * c->channels * c->channels;
+    return c->model.kind == BNM_KIND_CNN && c->path == BNM_PATH_FUSED_MFMA && c->cnn_fused_ok && c->cnn_fuse_tail && c->cnn_variant == 3 &&
+           !small_call && n < (1ull << 31);
+}
 // ---- bnm_capi_infer.cpp ----------------------------------------------------------------------------------------------
 // whole-model launch on device data (c->mu held, the context's device current); d_acts_tap: the parity tap (layer-wise path)
 int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t *d_cls, int32_t *d_logits,

@@ -19,13 +19,19 @@
 #include <mutex>
 #include "bnm_cnn_li_tile.hpp"
 #include "bnm_fused_generic_kernel.hpp"
+#include "bnm_quantise_f32.hpp"
 
 namespace {
 constexpr int LI_TAIL_MMAX = 3;
+constexpr int LI_WAVES_F32 = 12;
 }
 
-template <bool DBL>
-__global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_fused_kernel(const int8_t *__restrict__ images, uint32_t n, const i32x4 *__restrict__ frags,
+// FLT: `images` is float32 [n][256] and the input quantisation runs in front of the operands (bnm_cnn_li_tile_body.inc) - float
+// images to class ids in one kernel for the CNN models as bnm_fused_f32_kernel.hpp does for the FC ones.
+// (the float form is compiled for three waves per SIMD: the quantisation in front of the channel loop does not fit the 128 registers
+// the int8 form sits at without spilling operands that live across the loop)
+template <bool DBL, bool FLT>
+__global__ __launch_bounds__(64 * (FLT ? LI_WAVES_F32 : LI_WAVES)) void cnn_li_fused_kernel(const int8_t *__restrict__ images, uint32_t n, const i32x4 *__restrict__ frags,
                                                                      const int *__restrict__ bias, uint32_t C, const char *__restrict__ tail_frags,
                                                                      BnmGenericDesc d, uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out,
                                                                      uint32_t *__restrict__ counter, uint32_t grab) {
@@ -41,7 +47,13 @@ __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_fused_kernel(const int8_
         int mx = 0;
         {
         LI_LANE_VALUES
+        if constexpr (FLT) {
+#define LI_FLOAT_IMAGES
 #include "bnm_cnn_li_tile_body.inc"
+#undef LI_FLOAT_IMAGES
+        } else {
+#include "bnm_cnn_li_tile_body.inc"
+        }
         }
         // ---- ReLUNorm over the image's 4 C features (BitNetMCU_inference.c:23-72) straight into the FC tail's layer-1 operands
         LI_LANE_VALUES
@@ -129,22 +141,25 @@ bool bnmk_cnn_li_fused_supported(uint32_t C, const BnmGenericDesc &d) {
     return d.M[0] && d.M[1] && d.M[2] && d.n_classes && d.n_classes <= 256u;
 }
 
-hipError_t bnmk_cnn_li_fused(const int8_t *images, uint64_t n, const void *frags, const int *bias, uint32_t C, const void *tail_frags,
+hipError_t bnmk_cnn_li_fused(const void *images, bool float_images, uint64_t n, const void *frags, const int *bias, uint32_t C, const void *tail_frags,
                              const BnmGenericDesc &d, bool dbl, uint32_t *cls, int32_t *logits, uint32_t *counter, uint32_t grab, hipStream_t s) {
     if (!n) return hipSuccess;
-    const uint32_t waves = bnmk_cnn_li_waves(C);
+    uint32_t waves = bnmk_cnn_li_waves(C);
+    if (float_images && waves > (uint32_t)LI_WAVES_F32) waves = (uint32_t)LI_WAVES_F32;
     if (!bnmk_cnn_li_fused_supported(C, d) || !counter || !cls || n >= (1ull << 31)) return hipErrorInvalidValue;
     if (!grab) grab = 1;
-    auto fn = dbl ? cnn_li_fused_kernel<true> : cnn_li_fused_kernel<false>;
+    auto fn = float_images ? (dbl ? cnn_li_fused_kernel<true, true> : cnn_li_fused_kernel<false, true>)
+                           : (dbl ? cnn_li_fused_kernel<true, false> : cnn_li_fused_kernel<false, false>);
     static std::mutex mu;
-    static bool allowed[2][64] = {};
+    static bool allowed[4][64] = {};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     {
         std::lock_guard<std::mutex> g(mu);
-        if (dev < 64 && !allowed[dbl][dev]) {
+        const int which = (float_images ? 2 : 0) + (dbl ? 1 : 0);
+        if (dev < 64 && !allowed[which][dev]) {
             if (hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
-            allowed[dbl][dev] = true;
+            allowed[which][dev] = true;
         }
     }
     // (launch shape as bnmk_cnn_front_li: a call with fewer tiles than the chip has wave slots spreads them over the CUs first)
@@ -154,7 +169,7 @@ hipError_t bnmk_cnn_li_fused(const int8_t *images, uint64_t n, const void *frags
     const uint64_t per_block = (uint64_t)waves_now * grab;
     uint64_t blocks = (tiles + per_block - 1) / per_block;
     if (blocks > cap) blocks = cap;
-    fn<<<dim3((unsigned)blocks), dim3(64 * waves_now), waves_now * C * 160u, s>>>(images, (uint32_t)n, (const i32x4 *)frags, bias, C, (const char *)tail_frags, d,
+    fn<<<dim3((unsigned)blocks), dim3(64 * waves_now), waves_now * C * 160u, s>>>((const int8_t *)images, (uint32_t)n, (const i32x4 *)frags, bias, C, (const char *)tail_frags, d,
                                                                                  cls, logits, counter, grab);
     return hipGetLastError();
 }

@@ -26,19 +26,9 @@
 // NaNs are not propagated.  Out of contract, as in bnm_quantize_input_device.
 #pragma once
 #include "bnm_fused_generic_kernel.hpp"
+#include "bnm_quantise_f32.hpp"
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// max(|a|, |b|, |c|, |d|) as a bit pattern (a non-negative float): two VALU, no canonicalisation of the inputs
-BNM_DEVICE uint32_t absmax4_bits(const f32x4 &v) {
-    uint32_t m;
-    asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32_e64 %0, %0, |%4|" : "=&v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-    return m;
-}
-
-BNM_DEVICE uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 // lanes < 32: max over {l, l + 32} of a;  lanes >= 32: the same of b
 BNM_DEVICE uint32_t fold32(uint32_t a, uint32_t b) {
@@ -71,24 +61,10 @@ BNM_DEVICE void group_scales(const f32x4 (&v)[8], float (&scale)[8]) {
     const uint32_t e0 = rowmax16(fold16(c0, c1)), e1 = rowmax16(fold16(c2, c3));
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t e = (lane & 8u) ? e1 : e0;
-    // max(m, 1e-5f) on the bit patterns, then the IEEE division numpy performs
-    const float s = __fdiv_rn(127.0f, __uint_as_float(umax(e, 0x3727C5ACu)));
+    const float s = quantise_scale(e);      // max(m, 1e-5f), then the IEEE division numpy performs
     constexpr int kLane[8] = {0, 32, 16, 48, 8, 40, 24, 56};
 #pragma unroll
     for (int r = 0; r < 8; r++) scale[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), kLane[r]));
-}
-
-// four floats -> four int8 in one dword (byte b = value b)
-BNM_DEVICE uint32_t quantise4(const f32x4 &v, float scale) {
-    uint32_t q[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        float p = __fmul_rn(v[b], scale);
-        asm volatile("" : "+v"(p));            // no fma: the product is rounded to float32 first (see the header comment)
-        q[b] = __float_as_uint(__fadd_rn(p, 12582912.0f));
-    }
-    const uint32_t lo = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0400u), hi = __builtin_amdgcn_perm(q[3], q[2], 0x04000c0cu);
-    return lo | hi;
 }
 
 }  // namespace

@@ -153,7 +153,8 @@ hipError_t bnmk_cnn_front_li(const int8_t *d_images, uint64_t n, const void *d_f
 // launch, no act rows in HBM.  tail_frags / d: the generic kernel's fragment image and descriptor of the model's FC tail (the
 // image must be followed by 16 KiB of readable padding: fragment reads run a few KiB ahead of the last fragment).
 bool bnmk_cnn_li_fused_supported(uint32_t C, const BnmGenericDesc &d);
-hipError_t bnmk_cnn_li_fused(const int8_t *d_images, uint64_t n, const void *d_frags, const int *d_bias, uint32_t C, const void *d_tail_frags,
+// float_images: d_images is float32 [n][256], quantised in front of the operands (test_inference.py:140-141) instead of int8 [n][256]
+hipError_t bnmk_cnn_li_fused(const void *d_images, bool float_images, uint64_t n, const void *d_frags, const int *d_bias, uint32_t C, const void *d_tail_frags,
                              const BnmGenericDesc &d, bool dbl, uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t grab,
                              hipStream_t s);
 constexpr int BNM_CNN_WTAB_DWORDS = 20;      // per (band, channel); 2 bands x C rounded up to 64 channels

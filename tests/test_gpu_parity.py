@@ -624,6 +624,44 @@ def test_fused_float_input_kernel_equals_quantise_then_oracle(name, gpu_ok, orc)
     ctx.close()
 
 
+@pytest.mark.parametrize("name", [n for n in MODEL_NAMES if "cnn" in n])
+def test_float_input_cnn_in_one_kernel(name, gpu_ok, orc):
+    """SURVEY 8(f) row 1 for the CNN models: float images -> class ids (+ logits) in ONE kernel - the one-kernel CNN form with the
+    input quantisation in front of its convolution operands (cnn_li_fused_kernel<., true>) - against numpy's float32 quantisation +
+    the oracle: every CNN of the zoo, the front end named (every call size runs it) and left to the context (small calls: two
+    kernels on the channel path), ragged tiles, edge rows, logits, the two-kernel form of the same call."""
+    import torch
+    from bitnetmcu_amd import harness
+    model = util.load_golden_model(name)
+    om = util.OracleModel(model, orc)
+    C = model.layer(0).out_channels
+    rng = np.random.default_rng(77)
+    n_all = max(3000, 2 * C * C + 70)
+    x = _float_edge_rows(rng, n_all)
+    want_cls, want_lg = om.infer(harness.quantize_input(x), logits=True)
+    xd = torch.from_numpy(x).cuda()
+    for named in (True, False):
+        ctx = b.Context(model)
+        assert ctx.float_fused and ctx.cnn_tail_fused, name
+        if named:
+            ctx.set_cnn_variant(3)
+        for mode in (0, 2):
+            ctx.set_float_mode(mode)
+            for n in (n_all, 1000, 33, 32, 31, 1):
+                cls = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+                lg = torch.full((n, model.num_classes), -1, dtype=torch.int32, device="cuda")
+                ctx.infer_float_device(xd[:n], cls, lg)
+                torch.cuda.synchronize()
+                one = mode == 0 and (named or n >= 2 * C * C)
+                if one:
+                    assert ctx.last_kernel == "cnn_li_fused_kernel<float>", (name, named, mode, n, ctx.last_kernel)
+                else:
+                    assert ctx.last_kernel.startswith("quantize_input_kernel+"), (name, named, mode, n, ctx.last_kernel)
+                assert np.array_equal(cls.cpu().numpy().astype(np.uint32), want_cls[:n]), (name, named, mode, n)
+                assert np.array_equal(lg.cpu().numpy(), want_lg[:n]), (name, named, mode, n)
+        ctx.close()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_fuzz_fused_float_input_kernel_on_random_models(seed, gpu_ok, orc):
     """Random FC models (a codec per layer out of all seven - FP1.3.0's +128 second weight plane among them -, widths up to 128,
