@@ -21,8 +21,8 @@
 //     to LDS and the image one byte k = max(bitlength(mx >> 7) - 1, 0) from the IMAGE's running maximum mx (both lane halves: 160
 //     bytes per channel and wave) - at most 8 significant bits are kept, which is exact for the final shift s >= k + 1
 //     ((f + (1 << s >> 1)) >> s == ((f >> k) + (1 << (s-k) >> 1)) >> (s-k)).
-// Any channel count costs exactly its channels (no idle lanes at 24 or 48 channels).  VALU per channel and tile: 454 in the loop
-// body (conv1 epilogue 7 x 34 - one SDWA shift per value writes its half of a packed int16 pair, round 5 -, conv2 6 x 21 + the plane
+// Any channel count costs exactly its channels (no idle lanes at 24 or 48 channels).  VALU per channel and tile: 447 in the loop
+// body (conv1 epilogue 7 x 33 - one SDWA shift per value writes its half of a packed int16 pair, round 5 -, conv2 6 x 21 + the plane
 // split 32 + 10, conv3 and the record ~ 48) + the final pass, 44 MFMAs.
 // 125 VGPRs: four waves per SIMD - a lone wave issues VALU at half rate, and the compiler's MFMA -> VALU wait states (190 per
 // channel) need other waves to fill them.

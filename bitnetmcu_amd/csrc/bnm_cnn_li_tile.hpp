@@ -37,6 +37,15 @@ BNM_DEVICE void shr4_pack_pairs2(int a0, int a1, int b0, int b1, uint32_t after,
         "s_nop 0"
         : "=&v"(xa), "=&v"(xb) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "s"(4), "v"(after));
 }
+// The anchor pair of a row pair: a0 >> 4 is a compiler-visible shift (hipcc places the MFMA -> VALU wait states in front of it), the
+// second value joins it through one SDWA shift into the upper half: two instructions for the pair.
+BNM_DEVICE uint32_t shr4_pack_anchor(int a0, int a1) {
+    int t = a0 >> 4;
+    asm("v_ashrrev_i32_sdwa %0, %2, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "+v"(t) : "v"(a1), "s"(4));
+    return (uint32_t)t;
+}
 BNM_DEVICE uint32_t relu_pk16(uint32_t p) {
     const s16x2 z = {0, 0};
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), z));
