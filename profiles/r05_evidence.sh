@@ -26,6 +26,7 @@ timeout 400 bash profiles/pmc_kernel.sh ${TAG}_f32_tern --input float --model te
 PMC_TRAFFIC=1 timeout 600 bash profiles/pmc_kernel.sh ${TAG}_cnn_fused --model cnn_64 --images 4194304 > "$OUT/pmc_cnn_fused.md" 2>&1
 timeout 400 bash profiles/pmc_kernel.sh ${TAG}_cnn_fused16 --model mcu_cnn_16 --images 4194304 > "$OUT/pmc_cnn_fused16.md" 2>&1
 timeout 400 bash profiles/pmc_kernel.sh ${TAG}_cnn_fused48 --model mcu_cnn_48 --images 4194304 > "$OUT/pmc_cnn_fused48.md" 2>&1
+timeout 400 bash profiles/pmc_kernel.sh ${TAG}_cnn_f32 --model cnn_64 --images 4194304 --input float --cnn-variant 3 > "$OUT/pmc_cnn_f32.md" 2>&1
 PMC_TRAFFIC=1 timeout 600 bash profiles/pmc_kernel.sh ${TAG}_cnn_two --model cnn_64 --images 4194304 --cnn-variant 4 > "$OUT/pmc_cnn_two.md" 2>&1
-for t in dual f32 f32_tern cnn_fused cnn_fused16 cnn_fused48 cnn_two; do cp "gpurun_out/pmc_${TAG}_$t/table.json" "$OUT/table_$t.json" 2>/dev/null; done
+for t in dual f32 f32_tern cnn_fused cnn_fused16 cnn_fused48 cnn_f32 cnn_two; do cp "gpurun_out/pmc_${TAG}_$t/table.json" "$OUT/table_$t.json" 2>/dev/null; done
 tail -c 300 "$OUT/bench.json"; cat "$OUT/rocprof_kernel_trace_headline.md" "$OUT/rocprof_kernel_trace_float.md" "$OUT/rocprof_kernel_trace_cnn.md"
