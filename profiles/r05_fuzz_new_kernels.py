@@ -41,9 +41,23 @@ def main():
             outs[key] = ctx.infer(x, logits=True)
             ctx.close()
         d = [int((outs[k][0] != outs["channel"][0]).sum()) + int((outs[k][1] != outs["channel"][1]).sum()) for k in ("one kernel", "one kernel again", "two launches")]
+        # float images into the one-kernel form (cnn_li_fused_kernel<., true>): 200,000 images x 1/127 against quantise_input + the channel kernel
+        nf = 200_000
+        xf = x[:nf].astype(np.float32) * b.synth.FLOAT_PIXEL
+        ctx = b.Context(model)
+        ctx.set_cnn_variant(3)
+        cls = torch.empty(nf, dtype=torch.int32, device="cuda")
+        lg = torch.empty((nf, ncls), dtype=torch.int32, device="cuda")
+        ctx.infer_float_device(torch.from_numpy(xf).cuda(), cls, lg)
+        torch.cuda.synchronize()
+        assert ctx.last_kernel == "cnn_li_fused_kernel<float>", ctx.last_kernel
+        ctx.set_cnn_variant(1)
+        want = ctx.infer(checker.quantize_input(xf), logits=True)
+        ctx.close()
+        d.append(int((cls.cpu().numpy().astype(np.uint32) != want[0]).sum()) + int((lg.cpu().numpy() != want[1]).sum()))
         bad += sum(d)
         print(f"CNN {C} channels, tail {widths}-{ncls}, codecs {codecs}: {n} images, ids + logits differing from the channel kernel's: "
-              f"one kernel {d[0]}, again {d[1]}, two launches {d[2]}", flush=True)
+              f"one kernel {d[0]}, again {d[1]}, two launches {d[2]}; float one-kernel form on {nf} images {d[3]}", flush=True)
     n_models = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     for seed in range(n_models):
         rng = np.random.default_rng(880000 + seed)
