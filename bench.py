@@ -690,7 +690,8 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         kern = res[name]["kernel"].split("+")[-1]
         li = kern in ("cnn_li_kernel", "cnn_li_fused_kernel")
         macs = model_macs(b, m)
-        c = cj.get(f"{kern}@{model_name}") or cj.get(kern)
+        # (the three-plane A/B form of the one-kernel CNN is another binary than the one the replayed counters describe)
+        c = None if cnn_variant == 5 else (cj.get(f"{kern}@{model_name}") or cj.get(kern))
         roof = {"bound": "valu", "unit": "wave64 VALU-pipe instructions/s", "peak": VALU_PEAK_WAVE_INSTR_PER_S,
                 "definition": "frac = (VALU + MFMA instructions per image, counted by SQ_INSTS_VALU on this kernel binary) x inferences/s / "
                               "(1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction): the share of the VALU issue slots the kernel's own "
@@ -718,6 +719,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
                                           "the Toeplitz form issues ~12 x the algorithmic int8 operations"}
         res[name]["roofline"] = roof
     cnn_row("cnn_64", "cnn_64", "BASELINE configs[3]")
+    cnn_row("cnn_64_three_planes", "cnn_64", "the one-kernel form with conv3's third operand plane kept (the model's weights rule it out: bnm_cnn_li_tables; A/B)", cnn_variant=5)
     cnn_row("cnn_64_two_launches", "cnn_64", "the same front end with the FC tail as its own launch over act rows in HBM (round 4's form: 772 B moved per image)", cnn_variant=4)
     cnn_row("cnn_64_channel_kernel", "cnn_64", "the same model on round 3's front end (a lane = a channel, conv1 only on the matrix cores)", cnn_variant=1)
     # the reference's smaller published CNNs (mcu/BitNetMCU_model_cnn_16.h, _48.h)

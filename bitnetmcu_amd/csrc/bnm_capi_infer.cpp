@@ -170,7 +170,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
     if (!d_acts_tap && cnn_one_kernel_call(c, n)) {
         uint32_t *block = nullptr;
         if (int e = work_block(c, s, &block)) return e;
-        HIP_TRY(bnmk_cnn_li_fused(d_images, false, n, c->cnn_li_frags, c->cnn_li_bias, c->channels, c->gfrags, c->gdesc, c->shape.dbl, d_cls, d_logits,
+        HIP_TRY(bnmk_cnn_li_fused(d_images, false, n, c->cnn_li_frags, c->cnn_li_bias, c->channels, c->cnn_li_plane2, c->gfrags, c->gdesc, c->shape.dbl, d_cls, d_logits,
                                   block, c->cnn_li_grab, s));
         c->last_kernel = "cnn_li_fused_kernel";
         return BNM_OK;
@@ -209,7 +209,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
             c->last_kernel = std::string(lane_image ? "cnn_li_kernel" : c->cnn_variant ? "cnn_front_mfma_kernel" : "cnn_front_kernel") + "+" +
                              tail_names(c, path, cn);
         if (lane_image)
-            HIP_TRY(bnmk_cnn_front_li(d_images + off * 256, cn, c->cnn_li_frags, c->cnn_li_bias, c->channels, acts, AS, block, c->cnn_li_grab, s));
+            HIP_TRY(bnmk_cnn_front_li(d_images + off * 256, cn, c->cnn_li_frags, c->cnn_li_bias, c->channels, c->cnn_li_plane2, acts, AS, block, c->cnn_li_grab, s));
         else
             HIP_TRY(bnmk_cnn_front(d_images + off * 256, cn, c->w_conv[0], c->w_conv[1], c->w_conv[2], c->cnn_variant ? c->cnn_wtab : nullptr,
                                    c->channels, 4, acts, AS, feat, d_acts_tap != nullptr, block, c->cnn_grab, s));

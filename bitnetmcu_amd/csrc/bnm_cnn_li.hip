@@ -9,7 +9,8 @@
 //   * a 3x3 kernel is translation invariant, so with the K axis laid out in ROW PAIRS (two input rows per 32-slot K-step) every
 //     output row pair of a stage uses the SAME two A fragments: 6 fragments = 6 KiB per channel for the three stages (L2-resident
 //     table, tests/cnn_li_model.py builds the same matrices), 14 + 24 + 6 = 44 MFMAs per channel and tile = 88 per image at 64
-//     channels (the channel kernel: 14);
+//     channels (the channel kernel: 14) - 14 + 24 + 4 = 42 for models whose weights bound the pooled conv2 outputs below 2^16
+//     (every CNN of the reference's zoo): conv3's third operand plane is then not in the kernel (template parameter P2);
 //   * operands wider than int8 travel as int8 PLANES with separate accumulators (the plane weight 256 does not fit an int8
 //     weight): conv1's 14-bit outputs as two planes, the pooled 20-bit conv2 outputs as three; the low planes are offset by
 //     -128 (byte ^ 0x80, four bytes per v_xor) and the offset's contribution 128 sum(w) is a per-channel constant added behind
@@ -32,10 +33,13 @@
 
 // frags: [C][6] fragments of 1 KiB (stage 1 K-steps 0, 1; stage 2; stage 3), lane-linear; bias: [C][2] = {128 sum(w2), 32896 sum(w3)}
 // acts: int8 [n][acts_stride], 4 C bytes written per image.  Dynamic LDS: waves x C x 160 bytes (the ReLUNorm records).
+// P2: conv3's third operand plane (pooled conv2 values of 2^16 and more) is in the kernel; false for models whose weights rule such values out
+template <bool P2>
 __global__ __launch_bounds__(64 * LI_WAVES) void cnn_li_kernel(const int8_t *__restrict__ images, uint32_t n, const i32x4 *__restrict__ frags,
                                                                    const int *__restrict__ bias, uint32_t C, int8_t *__restrict__ acts,
                                                                    uint32_t acts_stride, uint32_t *__restrict__ counter, uint32_t grab) {
     extern __shared__ __attribute__((aligned(16))) uint8_t li_records[];      // per wave: [C][64] uint16 {f0 >> k, f1 >> k} then [C][32] uint8 k (one per image)
+    constexpr bool LI_PLANE2 = P2;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), nwaves = blockDim.x >> 6;
     const uint32_t n_tiles = (n + 31u) >> 5;
@@ -88,8 +92,22 @@ inline int li_conv3_slot(int prow, int pcol) { return 32 * (prow >> 2) + 16 * (p
 }  // namespace
 
 // frag_out: C * 6 KiB, bias_out: 2 C ints.  w1 / w2 / w3: [C][9] int8 kernels (row-major 3x3) of conv1 / conv2 / conv3.
-void bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int8_t *frag_out, int *bias_out) {
+// Returns whether conv3 needs its third operand plane: false when the weights bound EVERY pooled conv2 output below 2^16 - conv1's
+// sums reach at most 127 sum(w1+) + 128 sum(|w1-|) (inputs in -128 .. 127), its outputs m1 = that >> 4 (BitNetMCU_inference.c:261-271:
+// ReLU, then the shift); conv2 sees inputs in 0 .. m1, so its outputs reach at most (m1 sum(w2+)) >> 4, and pooling takes a maximum.
+bool bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int8_t *frag_out, int *bias_out) {
+    bool plane2 = false;
     for (uint32_t c = 0; c < C; c++) {
+        {
+            int64_t p1 = 0, n1 = 0, p2 = 0;
+            for (int k = 0; k < 9; k++) {
+                const int a = w1[9 * c + k], b = w2[9 * c + k];
+                if (a > 0) p1 += a; else n1 -= a;
+                if (b > 0) p2 += b;
+            }
+            const int64_t m1 = (127 * p1 + 128 * n1) >> 4, m2 = (m1 * p2) >> 4;
+            plane2 = plane2 || m2 >= 65536;
+        }
         int8_t A[3][32][64] = {};
         const int8_t *k1 = w1 + 9 * c, *k2 = w2 + 9 * c, *k3 = w3 + 9 * c;
         for (int h = 0; h < 2; h++) {
@@ -122,6 +140,7 @@ void bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uin
         bias_out[2 * c] = 128 * s2;
         bias_out[2 * c + 1] = (128 + 32768) * s3;
     }
+    return plane2;
 }
 
 // waves per workgroup (one workgroup per CU): the records take C x 160 bytes of LDS per wave; 0 = the kernel does not serve C
@@ -131,21 +150,22 @@ uint32_t bnmk_cnn_li_waves(uint32_t C) {
     return w >= (uint32_t)LI_WAVES ? (uint32_t)LI_WAVES : (w >= 6u ? w : 0u);      // fewer than six waves: the channel kernel serves the model
 }
 
-hipError_t bnmk_cnn_front_li(const int8_t *images, uint64_t n, const void *frags, const int *bias, uint32_t C, int8_t *acts,
+hipError_t bnmk_cnn_front_li(const int8_t *images, uint64_t n, const void *frags, const int *bias, uint32_t C, bool plane2, int8_t *acts,
                              uint32_t acts_stride, uint32_t *counter, uint32_t grab, hipStream_t s) {
     if (!n) return hipSuccess;
     const uint32_t waves = bnmk_cnn_li_waves(C);
     if (!waves || !counter || acts_stride < 4u * C || (acts_stride & 3u) || n >= (1ull << 31)) return hipErrorInvalidValue;
     if (!grab) grab = 1;
+    auto fn = plane2 ? cnn_li_kernel<true> : cnn_li_kernel<false>;
     static std::mutex mu;
-    static bool allowed[64] = {};
+    static bool allowed[2][64] = {};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     {
         std::lock_guard<std::mutex> g(mu);
-        if (dev < 64 && !allowed[dev]) {
-            if (hipError_t e = hipFuncSetAttribute((const void *)cnn_li_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
-            allowed[dev] = true;
+        if (dev < 64 && !allowed[plane2][dev]) {
+            if (hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
+            allowed[plane2][dev] = true;
         }
     }
     // a call with fewer tiles than the chip has wave slots spreads them over the CUs first: a wave's walk over the channels takes the
@@ -156,7 +176,7 @@ hipError_t bnmk_cnn_front_li(const int8_t *images, uint64_t n, const void *frags
     const uint64_t per_block = (uint64_t)waves_now * grab;
     uint64_t blocks = (tiles + per_block - 1) / per_block;
     if (blocks > cap) blocks = cap;
-    cnn_li_kernel<<<dim3((unsigned)blocks), dim3(64 * waves_now), waves_now * C * 160u, s>>>(images, (uint32_t)n, (const i32x4 *)frags, bias, C, acts,
+    fn<<<dim3((unsigned)blocks), dim3(64 * waves_now), waves_now * C * 160u, s>>>(images, (uint32_t)n, (const i32x4 *)frags, bias, C, acts,
                                                                                   acts_stride, counter, grab);
     return hipGetLastError();
 }

@@ -30,12 +30,14 @@ constexpr int LI_WAVES_F32 = 12;
 // images to class ids in one kernel for the CNN models as bnm_fused_f32_kernel.hpp does for the FC ones.
 // (the float form is compiled for three waves per SIMD: the quantisation in front of the channel loop does not fit the 128 registers
 // the int8 form sits at without spilling operands that live across the loop)
-template <bool DBL, bool FLT>
+// P2: conv3's third operand plane is in the kernel (bnm_cnn_li_tables says whether a model's weights can reach it).
+template <bool DBL, bool FLT, bool P2>
 __global__ __launch_bounds__(64 * (FLT ? LI_WAVES_F32 : LI_WAVES)) void cnn_li_fused_kernel(const int8_t *__restrict__ images, uint32_t n, const i32x4 *__restrict__ frags,
                                                                      const int *__restrict__ bias, uint32_t C, const char *__restrict__ tail_frags,
                                                                      BnmGenericDesc d, uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out,
                                                                      uint32_t *__restrict__ counter, uint32_t grab) {
     constexpr int MMAX = LI_TAIL_MMAX;
+    constexpr bool LI_PLANE2 = P2;
     extern __shared__ __attribute__((aligned(16))) uint8_t li_records[];      // per wave: [C][64] uint16 {f0 >> k, f1 >> k} then [C][32] uint8 k (one per image)
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), nwaves = blockDim.x >> 6;
@@ -141,22 +143,25 @@ bool bnmk_cnn_li_fused_supported(uint32_t C, const BnmGenericDesc &d) {
     return d.M[0] && d.M[1] && d.M[2] && d.n_classes && d.n_classes <= 256u;
 }
 
-hipError_t bnmk_cnn_li_fused(const void *images, bool float_images, uint64_t n, const void *frags, const int *bias, uint32_t C, const void *tail_frags,
+hipError_t bnmk_cnn_li_fused(const void *images, bool float_images, uint64_t n, const void *frags, const int *bias, uint32_t C, bool plane2, const void *tail_frags,
                              const BnmGenericDesc &d, bool dbl, uint32_t *cls, int32_t *logits, uint32_t *counter, uint32_t grab, hipStream_t s) {
     if (!n) return hipSuccess;
     uint32_t waves = bnmk_cnn_li_waves(C);
     if (float_images && waves > (uint32_t)LI_WAVES_F32) waves = (uint32_t)LI_WAVES_F32;
     if (!bnmk_cnn_li_fused_supported(C, d) || !counter || !cls || n >= (1ull << 31)) return hipErrorInvalidValue;
     if (!grab) grab = 1;
-    auto fn = float_images ? (dbl ? cnn_li_fused_kernel<true, true> : cnn_li_fused_kernel<false, true>)
-                           : (dbl ? cnn_li_fused_kernel<true, false> : cnn_li_fused_kernel<false, false>);
+    typedef void (*fn_t)(const int8_t *, uint32_t, const i32x4 *, const int *, uint32_t, const char *, BnmGenericDesc, uint32_t *, int32_t *, uint32_t *, uint32_t);
+    static const fn_t table[8] = {cnn_li_fused_kernel<false, false, false>, cnn_li_fused_kernel<true, false, false>, cnn_li_fused_kernel<false, true, false>,
+                                  cnn_li_fused_kernel<true, true, false>,   cnn_li_fused_kernel<false, false, true>, cnn_li_fused_kernel<true, false, true>,
+                                  cnn_li_fused_kernel<false, true, true>,   cnn_li_fused_kernel<true, true, true>};
+    const int which = (plane2 ? 4 : 0) + (float_images ? 2 : 0) + (dbl ? 1 : 0);
+    const fn_t fn = table[which];
     static std::mutex mu;
-    static bool allowed[4][64] = {};
+    static bool allowed[8][64] = {};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     {
         std::lock_guard<std::mutex> g(mu);
-        const int which = (float_images ? 2 : 0) + (dbl ? 1 : 0);
         if (dev < 64 && !allowed[which][dev]) {
             if (hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
             allowed[which][dev] = true;

@@ -181,7 +181,8 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
  * (act row of at most 256 bytes = 64 channels, FC layers at most 96 wide, no FP1.3.0 +128: every CNN of the reference's zoo) the
  * SAME wave also runs the tail - one kernel from the image bytes to the class id, nothing but 256 + 4 bytes per image through HBM
  * (bnm_ctx_cnn_tail_fused says so); 4 / 400 + g: the lane = image kernel with the tail as its own launch over act rows in per-stream
- * scratch (what every other model gets; kept selectable for A/B measurements).  1 (the default beyond 170
+ * scratch (what every other model gets; kept selectable for A/B measurements); 5: as 3 with conv3's third operand plane kept although
+ * the model's weights rule it out (bnm_ctx_cnn_planes; A/B measurements).  1 (the default beyond 170
  * channels): a lane = a channel, conv1 on the matrix cores, waves take batches of 8 images from a device-wide work counter; models
  * whose channel count leaves 1..16 channels beyond a multiple of 32 (16, 48, 80 ... channels) run those channels two images per
  * work item.  2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the
@@ -192,6 +193,10 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
  * bnm_ctx_last_kernel names what the last call really ran.  An explicit choice holds for every call size. */
 BNM_API int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant);
 BNM_API int bnm_ctx_get_cnn_variant(const bnm_ctx *c);      /* the setting: 3, 1 or 0 */
+/* Operand planes of conv3 in the lane = image kernels: 2 when the model's conv1 / conv2 weights bound every pooled conv2 output below
+ * 2^16 (the third plane - bits 16..23 - would be all zero: it is then not in the kernel; every CNN of the reference's zoo), else 3;
+ * 0 for FC models and CNNs the lane = image kernels do not serve. */
+BNM_API int bnm_ctx_cnn_planes(const bnm_ctx *c);
 BNM_API int bnm_ctx_cnn_tail_fused(const bnm_ctx *c);       /* 1: calls that take the lane = image front end run the one-kernel form */
 /* The kernels the context's LAST inference call launched (bnm_infer_device / _host / _float_device; the first chunk's of a call
  * that runs in chunks), by name and in launch order, joined by '+': e.g. "fused_fc_dual_kernel", "fused_fc_dual_kernel+fused_fc_kernel"

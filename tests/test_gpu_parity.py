@@ -202,9 +202,9 @@ def test_cnn_front_end_both_kernels(name, gpu_ok, orc):
                         np.full((2, 256), -128, np.int8), np.full((2, 256), 127, np.int8)])
     want = om.infer(x, logits=True)
     assert ctx.cnn_tail_fused        # every CNN of the zoo: the FC tail runs inside the lane = image kernel's wave (one kernel)
-    for variant in (3, 302, 4, 402, 1, 0):   # 4 / 402: the lane = image kernel with the tail as its own launch
+    for variant in (3, 302, 5, 4, 402, 1, 0):   # 4 / 402: the tail as its own launch; 5: conv3's third plane kept (the zoo's weights rule it out)
         ctx.set_cnn_variant(variant)
-        assert ctx.cnn_tail_fused == (variant in (3, 302))
+        assert ctx.cnn_tail_fused == (variant in (3, 302, 5)) and ctx.cnn_planes == (3 if variant == 5 else 2)
         # (<= 16 channels: two images per item, the last one or two images through the single-image instantiation)
         for n in (len(x), 1, 5, 2, 3, 4, 1000, 31, 32, 33, 65):
             got = ctx.infer(x[:n], logits=True)
@@ -1393,6 +1393,54 @@ def test_cnn_kernels_with_full_range_conv_weights(C, gpu_ok, orc):
             got = ctx.infer(x[:n], logits=True)
             assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (C, variant, n)
     ctx.close()
+
+
+def test_cnn_third_plane_is_dropped_exactly_when_the_weights_rule_it_out(gpu_ok, orc):
+    """The lane = image kernels carry conv3's third operand plane (bits 16..23 of the pooled conv2 values) only for models whose
+    weights can reach it (bnm_cnn_li_tables' bound: m1 = (127 sum(w1+) + 128 sum|w1-|) >> 4, m2 = (m1 sum(w2+)) >> 4 < 2^16).  Every
+    CNN of the zoo is below the bound; two crafted models sit right at it - all-positive kernels whose bound IS attained by the
+    all-127 image: pooled conv2 outputs of 65,205 (two planes, at their maximum) and 65,772 (needs the third) - and every form of
+    the kernel (one kernel, two launches, float input) must equal the oracle on them."""
+    import torch
+    from bitnetmcu_amd import harness
+    for name in [n for n in MODEL_NAMES if "cnn" in n]:
+        ctx = b.Context(util.load_golden_model(name))
+        assert ctx.cnn_planes == 2, name
+        ctx.close()
+    C = 8
+    for w2sum, planes in ((115, 2), (116, 3)):
+        w2 = [13] * 8 + [w2sum - 104]
+        rng = np.random.default_rng(w2sum)
+
+        def conv_weights(k):
+            return np.array(([127] * 9 if k == 2 else w2 if k == 4 else list(rng.integers(-128, 128, size=9))) * C)
+        model = b.Model.from_header_text(_random_cnn_text(rng, C, (16, 4, 4), (64, 32), 10, conv_weights))
+        om = util.OracleModel(model, orc)
+        x = np.concatenate([np.full((40, 256), 127, np.int8), np.full((3, 256), -128, np.int8), synth.images(5, 500, DIST_U),
+                            np.clip(synth.images(6, 500, DIST_M).astype(np.int16) + 100, -128, 127).astype(np.int8)])
+        want = om.infer(x, logits=True)
+        for variant in (3, 4, 1):
+            ctx = b.Context(model)
+            assert ctx.cnn_planes == planes, (w2sum, ctx.cnn_planes)
+            ctx.set_cnn_variant(variant)
+            for n in (len(x), 33):
+                got = ctx.infer(x[:n], logits=True)
+                assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (w2sum, variant, n)
+            ctx.close()
+        # float input: images that quantise to exactly these bytes
+        xf = x.astype(np.float32)
+        xf[:, 0] = np.where(np.abs(xf).max(axis=1) < 127, 127.0, xf[:, 0])      # (every image's max|x| = 127 or 128: scale 1 or 127/128)
+        q = harness.quantize_input(xf)
+        wantf = om.infer(q, logits=True)
+        ctx = b.Context(model)
+        ctx.set_cnn_variant(3)
+        cls = torch.empty(len(xf), dtype=torch.int32, device="cuda")
+        lg = torch.empty((len(xf), 10), dtype=torch.int32, device="cuda")
+        ctx.infer_float_device(torch.from_numpy(xf).cuda(), cls, lg)
+        torch.cuda.synchronize()
+        assert ctx.last_kernel == "cnn_li_fused_kernel<float>"
+        assert np.array_equal(cls.cpu().numpy().astype(np.uint32), wantf[0]) and np.array_equal(lg.cpu().numpy(), wantf[1]), w2sum
+        ctx.close()
 
 
 @pytest.mark.parametrize("name", ["mcu_cnn_16", "cnn_64"])
