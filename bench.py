@@ -193,7 +193,7 @@ def mfma_roofline(b, ctx, model, rate, kname, counters, model_key=None):
 
 def kernel_name(b, ctx, model, count=None, cnn_variant_named=False):
     """count / cnn_variant_named: a context nobody named a CNN front end on gives calls of fewer than 2 C^2 images to the channel
-    kernel whatever it reports (bnm_capi.cpp)."""
+    kernel whatever it reports (bnm_capi_infer.cpp)."""
     v = ctx.variant
     fused = {3: "fused_fc_dual_kernel", 5: "fused_fc_dual_kernel", 6: "fused_fc_dual_kernel", 4: "fused_fc_generic_kernel", 7: "fused_fc_generic_kernel",
              8: "fused_fc_generic_kernel", 9: "fused_fc_regw_kernel"}.get(v, "fused_fc_kernel")

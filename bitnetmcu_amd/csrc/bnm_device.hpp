@@ -109,7 +109,7 @@ BNM_DEVICE void work_take_issue(uint32_t &r, uint32_t *counter, uint32_t amount)
 BNM_DEVICE void work_take_wait(uint32_t &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+{s95}"(r)::"memory"); }
 
 // =================================================================================================
-// A launch's counter BLOCK (BNM_WORK_BLOCK_WORDS device words owned by the launch's stream, bnm_capi.cpp): the counter words
+// A launch's counter BLOCK (BNM_WORK_BLOCK_WORDS device words owned by the launch's stream, bnm_capi_ctx.cpp): the counter words
 // at block[16 k], k < 8, and at block[BNM_WORK_EXIT_WORD] the number of waves that have left the kernel.  A block is all zero
 // between launches: nobody zeroes it ahead of a launch (that was a hipMemsetAsync per launch: a second dispatch, 2 us of a
 // launch-bound call's 6-9) - the LAST wave to leave puts it back.  A leaving wave first retires every take it still has in

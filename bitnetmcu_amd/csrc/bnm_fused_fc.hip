@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void fused_fc_dual_kernel(const int8_t
         // The first iteration has nothing to store yet: the store issues with an empty exec mask (one asm statement, so the loop
         // body stays one basic block).  It must not write a placeholder that the real value overwrites later: the latency path of
         // bnm_infer_host polls the class words in page-locked host memory and takes the first change of a word as its result
-        // (bnm_capi.cpp, infer_host_small) - every word is written exactly once.
+        // (bnm_capi_host.cpp, infer_host_small) - every word is written exactly once.
         store_class_ids_masked(cls_out + img_prev, cls_prev, store_mask);
 #endif
         read_tile(1, bB);

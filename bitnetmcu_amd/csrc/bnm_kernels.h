@@ -56,7 +56,7 @@ struct BnmFusedArgs {
 };
 constexpr uint32_t BNM_WORK_DUMMY_WAVES = 4096;
 // A counter block: counter words at [16 k], k < 8 (64 bytes apart), the leave count at [BNM_WORK_EXIT_WORD].  Owned by one stream
-// (bnm_capi.cpp); all zero between launches - the last wave of a launch to leave puts it back (bnm_device.hpp, work_block_leave_*),
+// (bnm_capi_ctx.cpp); all zero between launches - the last wave of a launch to leave puts it back (bnm_device.hpp, work_block_leave_*),
 // so no launch is preceded by a memset.
 constexpr uint32_t BNM_WORK_BLOCK_WORDS = 256;
 constexpr uint32_t BNM_WORK_EXIT_WORD = 128;
@@ -68,7 +68,7 @@ hipError_t bnmk_fused_fc(const BnmFusedShape &sh, int variant, int grid_blocks, 
                          hipStream_t s);
 int bnmk_fused_default_variant(const BnmFusedShape &sh);
 // variant 9 (bnm_fused_regw.hip): weights resident in the register file at one wave per SIMD, for the 3..5-tile shapes.  Takes
-// whole 64-image pairs only (n % 64 == 0): the caller (bnm_capi.cpp, run_fused) gives the remainder to the generic kernel.
+// whole 64-image pairs only (n % 64 == 0): the caller (bnm_capi_infer.cpp, run_fused) gives the remainder to the generic kernel.
 constexpr int BNM_FUSED_REGW = 9;
 bool bnmk_regw_supported(const BnmFusedShape &sh);
 hipError_t bnmk_fused_regw(const BnmFusedShape &sh, int grid_blocks, const BnmFusedArgs &a, hipStream_t s);

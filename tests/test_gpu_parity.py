@@ -1446,7 +1446,7 @@ def test_cnn_third_plane_is_dropped_exactly_when_the_weights_rule_it_out(gpu_ok,
 @pytest.mark.parametrize("name", ["mcu_cnn_16", "cnn_64"])
 def test_cnn_default_front_end_on_both_sides_of_the_small_call_rule(name, gpu_ok, orc):
     """A context left to itself gives calls of fewer than 2 C^2 images to the channel kernel and larger ones to the lane = image
-    kernel (bnm_capi.cpp: a wave of the latter walks all channels, 2 us each, however few images there are): ids and logits on
+    kernel (bnm_capi_infer.cpp: a wave of the latter walks all channels, 2 us each, however few images there are): ids and logits on
     both sides of the threshold, and with each kernel chosen explicitly, equal the oracle's."""
     model = util.load_golden_model(name)
     C = model.layer(0).out_channels
