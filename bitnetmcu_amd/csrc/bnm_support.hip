@@ -3,6 +3,7 @@
 // BitNetMCU_inference.c:23-72 (ReLUNorm), :88-208 (processfclayer), :238-277 (conv), :300-322 (pool);
 // schedule BitNetMCU_MNIST_dll.c:48-121.
 #include "bnm_device.hpp"
+#include "bnm_quantise_f32.hpp"
 
 // =================================================================================================
 // Synthetic workload (host statement: oracle/synth.h)
@@ -148,26 +149,19 @@ hipError_t bnmk_build_fragments(const int8_t *rows, uint32_t stride, uint32_t n_
 // Input quantisation: the step immediately before the path, which the reference does in
 // Python for every image (test_inference.py:140-141, same formula BitNetMCU.py:435-436):
 //     scale = 127.0 / max(max|x|, 1e-5);  q = clip(round_half_even(x * scale), -128, 127)   all in float32.
-// One wavefront per image (256 floats = one float4 per lane); IEEE float32 divide/multiply and v_rndne_f32, so the
-// result is bit-identical to numpy's float32 arithmetic.
+// One wavefront per image (256 floats = one float4 per lane); IEEE float32 divide / multiply and the round-to-nearest-even of a
+// float32 add (bnm_quantise_f32.hpp), so the result is bit-identical to numpy's float32 arithmetic.
 // =================================================================================================
 __global__ __launch_bounds__(256) void quantize_input_kernel(const float *__restrict__ x, uint64_t n, int8_t *__restrict__ out) {
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     for (uint64_t img = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); img < n; img += (uint64_t)gridDim.x * 4u) {
-        f32x4 v = __builtin_nontemporal_load((const f32x4 *)(x + img * 256ull + 4u * lane));     // every byte is touched once
-        float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        const f32x4 v = __builtin_nontemporal_load((const f32x4 *)(x + img * 256ull + 4u * lane));     // every byte is touched once
+        uint32_t m = absmax4_bits(v);      // (non-negative floats order as unsigned integers)
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        const float scale = __fdiv_rn(127.0f, fmaxf(m, 1e-5f));
-        uint32_t d = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            float r = rintf(__fmul_rn(v[b], scale));
-            r = fminf(fmaxf(r, -128.0f), 127.0f);
-            d |= (uint32_t)(uint8_t)(int8_t)(int)r << (8 * b);
-        }
-        __builtin_nontemporal_store(d, (uint32_t *)(out + img * 256ull + 4u * lane));
+        for (int off = 32; off > 0; off >>= 1) m = umax(m, (uint32_t)__shfl_xor((int)m, off));
+        // the same per-value arithmetic as the fused float-input kernels (bnm_quantise_f32.hpp): identical bytes for EVERY input,
+        // non-finite ones included (out of contract: numpy's own result for them is platform-defined)
+        __builtin_nontemporal_store(quantise4(v, quantise_scale(m)), (uint32_t *)(out + img * 256ull + 4u * lane));
     }
 }
 

@@ -238,7 +238,9 @@ BNM_API int bnm_unpack_layer_host(const void *weights, int32_t bits_per_weight, 
 
 /* Input quantisation on the GPU — the step the reference does in Python before every Inference() call
  * (test_inference.py:140-141; BitNetMCU.py:435-436): scale = 127/max(max|x|,1e-5), round half to even, clip.
- * d_x: float32 [n][256], d_out: int8 [n][256]; bit-identical to the numpy float32 formula. */
+ * d_x: float32 [n][256], d_out: int8 [n][256]; bit-identical to the numpy float32 formula for finite inputs (non-finite values are
+ * outside the contract - numpy's own result for them is platform-defined; this kernel and the fused float-input kernels give the
+ * same bytes for them: an image that holds an infinity quantises to zeros). */
 BNM_API int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_out, void *stream);
 /* The two steps of the reference's per-image Python flow (test_inference.py:140-150: quantise, then Inference()) for a batch of
  * float images resident on the GPU: d_x float32 [n][256] -> class ids (and the int32 logits if d_logits != NULL), asynchronous on

@@ -681,7 +681,10 @@ def test_fuzz_fused_float_input_kernel_on_random_models(seed, gpu_ok, orc):
     model = b.Model.from_header_text(_random_model_text(rng, codecs, tuple(widths), n_classes))
     ctx = b.Context(model)
     # (a model whose weights - two planes for FP1.3.0's +128 - leave LDS for fewer than four waves runs the two-kernel path)
-    x = _float_edge_rows(rng, 3001) * np.float32(rng.choice([1e-3, 1.0, 37.5]))
+    x = _float_edge_rows(rng, 3001)
+    x[11] /= np.float32(64.0)                     # (the near-FLT_MAX row stays finite under the scale below: inputs are finite by contract)
+    x = x * np.float32(rng.choice([1e-3, 1.0, 37.5]))
+    assert np.isfinite(x).all()
     want_cls, want_lg = util.OracleModel(model, orc).infer(harness.quantize_input(x), logits=True)
     xd = torch.from_numpy(x).cuda()
     for n in (3001, 64, 5):
