@@ -666,6 +666,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         float_row("fc_float_input", "fc_4bitsym_64", n_f, 10, 3, 0, "float images -> class ids, ONE kernel (bnm_fused_f32_kernel.hpp): HBM roofline on 1,028 B per inference")
         float_row("fc_float_input_two_kernels", "fc_4bitsym_64", n_f, 3, 1, 2, "the same call as quantise + infer (1,540 B moved per inference): what the fused kernel replaces")
         float_row("tern_float_input", "tern_96", n_f, 5, 2, 0, "the 4-tile class of the fused float-input kernel (ternary 96-96-96)")
+        float_row("binary160_float_input", "doc12k_binary", n_f, 5, 2, 0, "the 6-tile class of the fused float-input kernel (binary 160-160-160: one landing group per wave)")
         # ... and the CNN: the one-kernel form with the quantisation in front of its convolution operands (VALU-bound like the int8 form:
         # the HBM fraction of its 1,028 B per inference is small; `value` is what to compare with the cnn_64 row)
         n_fc = min(n_f, 10_000_000)

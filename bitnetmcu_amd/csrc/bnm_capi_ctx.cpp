@@ -512,10 +512,10 @@ int bnm_ctx_cnn_tail_fused(const bnm_ctx *c) {
 }
 
 int bnm_ctx_set_float_mode(bnm_ctx *c, int mode, int groups) {
-    if (!c || mode < 0 || mode > 2 || (groups != 0 && groups != 2 && groups != 4)) return fail(BNM_EINVAL, "bad argument");
+    if (!c || mode < 0 || mode > 2 || (groups != 0 && groups != 1 && groups != 2 && groups != 4)) return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (mode == 1 && !c->f32_ok && !c->cnn_fused_ok)
-        return fail(BNM_EUNSUPPORTED, "the fused float-input kernels serve FC models whose layers are at most 128 wide and CNN models "
+        return fail(BNM_EUNSUPPORTED, "the fused float-input kernels serve FC models whose layers are at most 192 wide and CNN models "
                                       "of up to 64 channels whose FC layers are at most 96 wide");
     if (groups && c->f32_ok && !bnmk_fused_f32_supported(c->gdesc, c->shape.dbl, groups))
         return fail(BNM_EUNSUPPORTED, "this many groups in flight are not instantiated for the model's tile class");

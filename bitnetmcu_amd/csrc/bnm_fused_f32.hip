@@ -1,5 +1,5 @@
 // Fused float-input whole-model FC kernel: planning and dispatch (the kernel lives in bnm_fused_f32_kernel.hpp and is instantiated
-// per tile class in bnm_fused_f32_m{2,4}.hip).  It runs on the generic kernel's descriptor and fragment image (weights in LDS).
+// per tile class in bnm_fused_f32_m{2,4,6}.hip).  It runs on the generic kernel's descriptor and fragment image (weights in LDS).
 #include "bnm_device.hpp"
 #include "bnm_kernels.h"
 
@@ -9,6 +9,7 @@
 DECL(bnmk_f32_launch_m2_g4);
 DECL(bnmk_f32_launch_m2_g2);
 DECL(bnmk_f32_launch_m4_g2);
+DECL(bnmk_f32_launch_m6_g1);
 #undef DECL
 
 namespace {
@@ -19,6 +20,7 @@ typedef hipError_t (*launch_fn)(uint32_t, bool, unsigned, unsigned, unsigned, hi
 launch_fn launcher_of(uint32_t mmax, int groups) {
     if (mmax == 2) return groups == 2 ? bnmk_f32_launch_m2_g2 : bnmk_f32_launch_m2_g4;
     if (mmax == 4) return (groups == 0 || groups == 2) ? bnmk_f32_launch_m4_g2 : nullptr;
+    if (mmax == 6) return (groups == 0 || groups == 1) ? bnmk_f32_launch_m6_g1 : nullptr;      // (the 6-tile accumulators leave room for one group)
     return nullptr;
 }
 // waves per workgroup (one workgroup per CU): an 8 KiB int8 tile buffer (+ 2 KiB logits staging) per wave beside the weights
@@ -30,7 +32,7 @@ uint32_t f32_waves(const BnmGenericDesc &d, bool stage) {
 }
 }  // namespace
 
-// groups: landing groups in flight per wave (0 = the library's choice: 4 in the 2-tile class, 2 in the 4-tile class)
+// groups: landing groups in flight per wave (0 = the library's choice: 4 in the 2-tile class, 2 in the 4-tile class, 1 in the 6-tile class)
 bool bnmk_fused_f32_supported(const BnmGenericDesc &d, bool dbl, int groups) {
     if (d.KT0 != 8 || (d.sp == 2 && dbl) || (d.sp != 1 && d.sp != 2)) return false;
     launch_fn f = launcher_of(d.mmax, groups);

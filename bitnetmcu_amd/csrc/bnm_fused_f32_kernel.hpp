@@ -69,7 +69,7 @@ BNM_DEVICE void group_scales(const f32x4 (&v)[8], float (&scale)[8]) {
 
 }  // namespace
 
-// NG: groups of 8 images in flight per wave (2 or 4: 64 or 128 landing registers).  WPS: waves per SIMD the register budget is
+// NG: groups of 8 images in flight per wave (1, 2 or 4: 32, 64 or 128 landing registers).  WPS: waves per SIMD the register budget is
 // compiled for.  KT0 = 8 (rows of 256 values), one tile per wave and iteration.
 template <int MMAX, int SP, bool DBL, int NG, int WPS>
 __global__ __launch_bounds__(256 * WPS) void fused_fc_f32_kernel(const float *__restrict__ x, uint64_t n,
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_f32_kernel(const float *__
                                                                  uint32_t *__restrict__ counter, uint32_t batch_arg) {
     constexpr int KT0 = 8, T = 1;
     using G = RowGeom<256>;
-    static_assert(NG == 2 || NG == 4, "a tile's four groups must map to fixed landing slots");
+    static_assert(NG == 1 || NG == 2 || NG == 4, "a tile's four groups must map to fixed landing slots");
     const uint32_t batch = batch_arg & 0xFFFFu;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63;

@@ -248,14 +248,14 @@ BNM_API int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_ou
 BNM_API int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d_cls, int32_t *d_logits, void *stream);
 /* How bnm_infer_float_device runs.  ONE kernel that reads the floats, quantises them in registers and feeds the matrix-core operands
  * (1,028 bytes of HBM traffic per image; exactly one dispatch, nothing allocated: capturable) for
- *   - FC models on the fused MFMA path whose layers are at most 128 wide (tile classes 2 and 4 of the generic kernel; every FC
- *     model of the reference's zoo except the documented 160-160-160 binary one): fused_fc_f32_kernel;
+ *   - FC models on the fused MFMA path whose layers are at most 192 wide (tile classes 2, 4 and 6 of the generic kernel: every FC
+ *     model of the reference's zoo, the documented 160-160-160 binary one included): fused_fc_f32_kernel;
  *   - CNN models the one-kernel CNN form serves (up to 64 channels, FC layers at most 96 wide: every CNN of the zoo), for the calls
  *     that take it (bnm_ctx_set_cnn_variant: not the small calls of a context left to itself): cnn_li_fused_kernel in its float form;
  * everything else runs bnm_quantize_input_device into per-stream scratch followed by the model's kernels (1,540 bytes per image).
  * mode 0 (default): one kernel where it exists; 1: one kernel or BNM_EUNSUPPORTED; 2: always two kernels (A/B measurements).
- * groups (FC kernel only): 8-image groups of floats in flight per wave: 0 = default (4 in the 2-tile class, 2 in the 4-tile class),
- * 2 or 4.  Results are identical in every mode. */
+ * groups (FC kernel only): 8-image groups of floats in flight per wave: 0 = default (4 in the 2-tile class, 2 in the 4-tile class, 1 in
+ * the 6-tile class), 1, 2 or 4 where instantiated.  Results are identical in every mode. */
 BNM_API int bnm_ctx_set_float_mode(bnm_ctx *c, int mode, int groups);
 BNM_API int bnm_ctx_float_fused(const bnm_ctx *c);      /* 1: float calls of this context run one kernel now (CNN: those that take the one-kernel form); 0: two kernels */
 

@@ -583,12 +583,14 @@ def test_fused_float_input_kernel_equals_quantise_then_oracle(name, gpu_ok, orc)
     want_cls, want_lg = om.infer(q, logits=True)
     xd = torch.from_numpy(x).cuda()
     ncls = model.num_classes
-    expect_fused = name != "doc12k_binary"        # 160-wide layers: the 6-tile class has no float-input instantiation
+    expect_fused = True                           # (every FC model of the zoo: tile classes 2, 4 and - 160-160-160 - 6)
     assert ctx.float_fused == expect_fused, name
-    if not expect_fused:
-        with pytest.raises(b.BnmError):
-            ctx.set_float_mode(1)
-    modes = [(0, 0)] + ([(1, 2)] if expect_fused else []) + [(2, 0)]
+    modes = [(0, 0), (2, 0)]
+    try:
+        ctx.set_float_mode(1, 2)
+        modes.append((1, 2))
+    except b.BnmError:
+        assert name == "doc12k_binary"             # (the 6-tile class holds one group only)
     try:
         ctx.set_float_mode(1, 4)
         modes.append((1, 4))
