@@ -196,7 +196,12 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_f32_kernel(const float *__
                 relunorm_pack<mt, DBL, MMAX>(acc[0], act[0], h);
                 if constexpr (mt >= MMAX - 1) {
                     if (uniform) {
-                        uniform_tail<mt, MMAX, SP, DBL, T>(smem, l16, d, act, h, j, lane, cls, logits_out, stage, first_img, n, nc, few_classes);
+                        {
+#ifdef BNM_DIAG_TIMING
+                        PhaseStamps st{};      // (the diagnostic build stamps the generic kernel only)
+#endif
+                        uniform_tail<mt, MMAX, SP, DBL, T>(smem, l16, d, act, h, j, lane, cls, logits_out, stage, first_img, n, nc, few_classes BNM_ST_ARG);
+                        }
                         done = true;
                     }
                 }

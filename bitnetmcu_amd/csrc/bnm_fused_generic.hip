@@ -1,5 +1,6 @@
 // Generic fused whole-model FC kernel: planning and dispatch (the kernels live in bnm_fused_generic_kernel.hpp and are
 // instantiated per tile class and tiles-per-wave in bnm_fused_generic_m{2,4}.hip, _m2_t2.hip and _m8_k{2,4,8,16}.hip).
+#include <cstdlib>
 #include "bnm_device.hpp"
 #include "bnm_kernels.h"
 
@@ -110,6 +111,9 @@ hipError_t bnmk_fused_generic(const BnmGenericDesc &d_in, bool dbl, int tiles, i
     uint32_t waves = generic_waves(d, T, false);
     d.stage = (want_stage && generic_waves(d, T, true) == waves) ? 1u : 0u;
     if (!waves) return hipErrorInvalidValue;
+#ifdef BNM_DIAG      // diagnostic libraries only: fewer waves per workgroup (profiles/r05/r05_generic_phases.py)
+    if (const char *e = getenv("BNM_GENERIC_WAVES")) { uint32_t w = (uint32_t)atoi(e); if (w && w < waves) waves = w; }
+#endif
     // one word serves ~88 M takes per second device-wide, eight ~430 M/s (profiles/r02/s_atomic_rate_r02.log): with the counter
     // split eight ways batches of 4 tiles (3.1 M tiles per 1e8 images -> 0.8 M takes per launch) stay far below it
     if (!batch) batch = T == 2 ? 2u : 4u;

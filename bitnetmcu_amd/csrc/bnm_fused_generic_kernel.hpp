@@ -31,7 +31,36 @@
 #include "bnm_fused_tile.hpp"
 #include "bnm_fused_math.hpp"
 
+// fragment reads in flight ahead of their MFMAs (a translation unit may set it before including this header)
+#ifndef BNM_FRAG_DEPTH
+#define BNM_FRAG_DEPTH 4
+#endif
+
 namespace {
+
+// Diagnostic build only (build.py --diag-timing): shader-clock stamps at the phase boundaries of the uniform path, summed per wave
+// and written where the caller's `logits` point (profiles/r05/r05_generic_phases.py).  Nothing of it exists in the product build.
+#ifdef BNM_DIAG_TIMING
+struct PhaseStamps {
+    uint64_t last;
+    uint32_t sum[12];
+    BNM_DEVICE void start() { last = __builtin_amdgcn_s_memtime(); }
+    BNM_DEVICE void tick(int k) {
+        __builtin_amdgcn_sched_barrier(0);      // (a wave issues in order: the stamp is taken once everything before it has been issued)
+        const uint64_t t = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        sum[k] += (uint32_t)(t - last);
+        last = t;
+    }
+};
+#define BNM_ST_PARAM , PhaseStamps &st
+#define BNM_ST_ARG , st
+#define BNM_TICK(k) st.tick(k)
+#else
+#define BNM_ST_PARAM
+#define BNM_ST_ARG
+#define BNM_TICK(k)
+#endif
 
 // wave-uniform values that the compiler may nevertheless have placed in VGPRs: back to SGPRs for the "s" constraints
 BNM_DEVICE uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -105,7 +134,7 @@ template <int MT, int NS, int S0, int KTOT, int SP, bool INIT, int T, int NB = N
 BNM_DEVICE void mma_l1(const char *a, const i32x4 (&b)[T][NB], i32x16 (&acc)[T][MT]) {
     static_assert(NS <= NB, "operand array too short");
     constexpr int N = SP * NS * MT;
-    constexpr int DEPTH = N < 4 ? N : 4;
+    constexpr int DEPTH = N < BNM_FRAG_DEPTH ? N : BNM_FRAG_DEPTH;
     auto frag = [&](auto I) -> i32x4 {
         constexpr int i = decltype(I)::value;
         constexpr int pp = i / (NS * MT), ss = (i % (NS * MT)) / MT, mm = i % MT;
@@ -162,7 +191,7 @@ BNM_DEVICE void hidden_steps(const char *a, uint32_t K, const i32x4 (&in)[T][MMA
 
 template <int MT, int SP, int T, int MMAX>
 BNM_DEVICE void hidden_mma(const char *a, uint32_t K, const i32x4 (&in)[T][MMAX], i32x16 (&acc)[T][MT]) {
-    constexpr int DEPTH = MMAX * MT < 4 ? MMAX * MT : 4;
+    constexpr int DEPTH = MMAX * MT < BNM_FRAG_DEPTH ? MMAX * MT : BNM_FRAG_DEPTH;
     static_for<0, SP>([&](auto PI) {
         constexpr int p = decltype(PI)::value;
         const char *ap = a;
@@ -239,25 +268,29 @@ BNM_DEVICE void final_layer(const char *smem, uint32_t lane16, uint32_t off, uin
 // are compile-time counts (no exits), no case boundaries between the layers (no PHI copies of the packed activations: the
 // general path spends 7-26 v_mov per layer on them), and hipcc schedules across layers as in the shape-specialised kernels.
 template <int MT, int MMAX, int SP, bool DBL, int T>
-BNM_DEVICE void uniform_layer(const char *a, i32x4 (&act)[T][MMAX], int h) {
+BNM_DEVICE void uniform_layer(const char *a, i32x4 (&act)[T][MMAX], int h BNM_ST_PARAM, int k0 = 0) {
     i32x16 acc[T][MT];
     mma_l1<MT, MT, 0, MT, SP, true, T, MMAX>(a, act, acc);
+    BNM_TICK(k0);
 #pragma unroll
     for (int t = 0; t < T; t++) relunorm_pack<MT, DBL, MMAX>(acc[t], act[t], h);
+    BNM_TICK(k0 + 1);
 }
 template <int MT, int MMAX, int SP, bool DBL, int T>
 BNM_DEVICE void uniform_tail(const char *smem, uint32_t lane16, const BnmGenericDesc &d, i32x4 (&act)[T][MMAX], int h, int j, int lane,
                              uint32_t (&cls)[T], int32_t *logits_out, int32_t *stage, uint64_t first_img, uint64_t n, uint32_t n_classes,
-                             bool few_classes) {
-    uniform_layer<MT, MMAX, SP, DBL, T>(smem + (d.frag_off[1] + lane16), act, h);
+                             bool few_classes BNM_ST_PARAM) {
+    uniform_layer<MT, MMAX, SP, DBL, T>(smem + (d.frag_off[1] + lane16), act, h BNM_ST_ARG, 3);
     uint32_t off_last = d.frag_off[2];
     if (d.M[3]) {
-        uniform_layer<MT, MMAX, SP, DBL, T>(smem + (d.frag_off[2] + lane16), act, h);
+        uniform_layer<MT, MMAX, SP, DBL, T>(smem + (d.frag_off[2] + lane16), act, h BNM_ST_ARG, 5);
         off_last = d.frag_off[3];
     }
     i32x16 acc[T][1];
     mma_l1<1, MT, 0, MT, SP, true, T, MMAX>(smem + (off_last + lane16), act, acc);
+    BNM_TICK(7);
     classify<1, T>(acc, h, j, lane, cls, logits_out, stage, first_img, n, n_classes, few_classes);
+    BNM_TICK(8);
 }
 
 }  // namespace
@@ -291,7 +324,6 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
     const uint32_t tile_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem + tile_off;
     // logits staging area of the wave (2 KiB behind all tile buffers) when the launcher reserved one
     int32_t *const stage = d.stage ? (int32_t *)(smem + d.w_bytes + nwaves * (uint32_t)UNIT + wave * 2048u) : nullptr;
-
     // Lane constants that stay in registers across the persistent loop: the lane id, the B-operand base, the fragment base and
     // the NV distinct DMA source offsets (DMA piece t, lane l: LDS byte 1024t + 16l = row t*RPP + rl, slot c'; source slot
     // c = c' ^ mask(row)).  The loop body works on opaque per-iteration copies of them: left to itself hipcc hoists dozens of
@@ -376,9 +408,18 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         const uint64_t img = (uint64_t)unit_prev * (uint64_t)(32 * T) + (uint64_t)(T == 2 ? l : (l & 31u));
         if (img < n && (T == 2 || l < 32u)) __builtin_nontemporal_store(cls_prev, cls_out + img);
     };
+#ifdef BNM_DIAG_TIMING
+    PhaseStamps st{};
+    int32_t *const records = logits_out;
+    logits_out = nullptr;
+    uint32_t iters = 0;
+    st.start();
+#endif
     while (unit < n_units) {
         if (left == 0u) work_take_issue(taken, counter + 16u * my_word, 1u);
+        BNM_TICK(9);                 // loop overhead behind the previous tile's last stamp
         bnm_wait_vmcnt<0>();
+        BNM_TICK(0);                 // the wait for the tile
         uint32_t next_unit = unit + 1u, next_left = left - 1u;
         // per-iteration opaque copies of the three lane values the arithmetic starts from (one v_mov each): what is derived from
         // them inside the iteration cannot be hoisted out of the persistent loop
@@ -422,11 +463,13 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
                     }
                     mma_l1<mt, KC, ch * KC, KT0, SP, ch == 0, T>(smem + (d.frag_off[0] + l16), b0, acc);
                 });
+                BNM_TICK(1);
 #pragma unroll
                 for (int t = 0; t < T; t++) relunorm_pack<mt, DBL, MMAX>(acc[t], act[t], h);
+                BNM_TICK(2);
                 if constexpr (mt >= MMAX - 1) {
                     if (uniform) {      // all hidden layers have mt tiles, one classifier tile: straight-line code from here on
-                        uniform_tail<mt, MMAX, SP, DBL, T>(smem, l16, d, act, h, j, lane, cls, logits_out, stage, first_img, n, nc, few_classes);
+                        uniform_tail<mt, MMAX, SP, DBL, T>(smem, l16, d, act, h, j, lane, cls, logits_out, stage, first_img, n, nc, few_classes BNM_ST_ARG);
                         done = true;
                     }
                 }
@@ -449,7 +492,19 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_generic_kernel(const int8_
         pend = true;
         unit = next_unit;
         left = next_left;
+#ifdef BNM_DIAG_TIMING
+        iters++;
+#endif
     }
+#ifdef BNM_DIAG_TIMING
+    if (records != nullptr && lane == 0) {
+        int32_t *r = records + 16u * wave_id;
+        for (int k = 0; k < 12; k++) r[k] = (int32_t)st.sum[k];
+        r[12] = (int32_t)iters;
+        r[13] = (int32_t)(__builtin_amdgcn_s_getreg((31 << 11) | 4));
+        r[14] = (int32_t)wave;
+    }
+#endif
     flush_cls();
     bnm_wait_vmcnt<0>();   // no LDS-DMA may outlive the workgroup's LDS allocation
     work_block_leave_s(counter, total_waves);   // the last wave to leave puts the counter block back to all-zero
