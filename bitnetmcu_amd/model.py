@@ -241,7 +241,7 @@ class Context:
 
     def set_float_mode(self, mode=0, groups=0):
         """How infer_float_device runs: 0 the fused float-input kernel where it exists, 1 fused or an error, 2 always
-        quantise + infer (two kernels); groups: 8-image groups in flight per wave of the fused kernel (0 = default, 2, 4)."""
+        quantise + infer (two kernels); groups: 8-image groups in flight per wave of the fused kernel (0 = default; 1, 2, 4: what the tile class has)."""
         L.check(self._lib, self._lib.bnm_ctx_set_float_mode(self._h, mode, groups), "bnm_ctx_set_float_mode")
 
     @property
