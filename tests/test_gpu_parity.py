@@ -666,8 +666,8 @@ def test_float_input_cnn_in_one_kernel(name, gpu_ok, orc):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_fuzz_fused_float_input_kernel_on_random_models(seed, gpu_ok, orc):
-    """Random FC models (a codec per layer out of all seven - FP1.3.0's +128 second weight plane among them -, widths up to 128,
-    2 to 64 classes) through the float-input kernel vs numpy quantisation + oracle."""
+    """Random FC models (a codec per layer out of all seven - FP1.3.0's +128 second weight plane among them -, widths up to 192:
+    the 2-, 4- and 6-tile classes of the kernel -, 2 to 64 classes) through the float-input kernel vs numpy quantisation + oracle."""
     import torch
     from bitnetmcu_amd import harness
     rng = np.random.default_rng(4400 + seed)
@@ -677,7 +677,7 @@ def test_fuzz_fused_float_input_kernel_on_random_models(seed, gpu_ok, orc):
     widths = []
     for k in range(1, n_layers):
         g = need[codecs[k]]
-        hi = int(rng.choice([32, 64, 128]))
+        hi = int(rng.choice([32, 64, 128, 192]))
         widths.append(int(rng.integers(1, hi // g + 1)) * g)
     n_classes = int(rng.integers(2, 65))
     model = b.Model.from_header_text(_random_model_text(rng, codecs, tuple(widths), n_classes))
