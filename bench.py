@@ -206,7 +206,7 @@ def kernel_name(b, ctx, model, count=None, cnn_variant_named=False):
         if count < 2 * model.layers()[0].out_channels ** 2:
             cnn = "cnn_front_mfma_kernel"
     if model.kind == b.KIND_CNN and cnn == "cnn_li_kernel" and ctx.path == b.PATH_FUSED_MFMA and ctx.cnn_tail_fused:
-        return "cnn_li_fused_kernel"        # front end + FC tail in one kernel: the only launch of the call
+        return "cnn_li_fused_pipe_kernel" if ctx.cnn_pipelined else "cnn_li_fused_kernel"        # front end + FC tail in one kernel: the only launch of the call
     return k + ("+" + cnn if model.kind == b.KIND_CNN else "")
 
 
@@ -626,7 +626,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         _, rd_ms = timed_steps(torch, lambda: b.synth.stream_read_device(xf, sink), 3, 1)
         rd = float(np.median(rd_ms))
         fused = ctx.float_fused
-        fused_name = "cnn_li_fused_kernel<float>" if model.kind == b.KIND_CNN else "fused_fc_f32_kernel"
+        fused_name = ("cnn_li_fused_pipe_kernel<float>" if ctx.cnn_pipelined else "cnn_li_fused_kernel<float>") if model.kind == b.KIND_CNN else "fused_fc_f32_kernel"
         bpi = BYTES_PER_INFERENCE_FLOAT
         g = rate * bpi / 1e9
         res[name] = {"model": model_name, "model_source": src, "images": count, "dist": "U", "steps": steps, "warmup": warmup,
@@ -689,7 +689,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     def cnn_row(name, model_name, note, cnn_variant=-1):
         r, m = run(name, model_name, n_cnn, 3, 1, note=note, cnn_variant=cnn_variant)
         kern = res[name]["kernel"].split("+")[-1]
-        li = kern in ("cnn_li_kernel", "cnn_li_fused_kernel")
+        li = kern in ("cnn_li_kernel", "cnn_li_fused_kernel", "cnn_li_fused_pipe_kernel")
         macs = model_macs(b, m)
         # (the three-plane A/B form of the one-kernel CNN is another binary than the one the replayed counters describe)
         c = None if cnn_variant == 5 else (cj.get(f"{kern}@{model_name}") or cj.get(kern))
@@ -720,6 +720,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
                                           "the Toeplitz form issues ~12 x the algorithmic int8 operations"}
         res[name]["roofline"] = roof
     cnn_row("cnn_64", "cnn_64", "BASELINE configs[3]")
+    cnn_row("cnn_64_four_waves", "cnn_64", "the one-kernel form at four waves per SIMD (round 5's first form: SDWA conv1 epilogue, a wave waits for its MFMA results; A/B)", cnn_variant=6)
     cnn_row("cnn_64_three_planes", "cnn_64", "the one-kernel form with conv3's third operand plane kept (the model's weights rule it out: bnm_cnn_li_tables; A/B)", cnn_variant=5)
     cnn_row("cnn_64_two_launches", "cnn_64", "the same front end with the FC tail as its own launch over act rows in HBM (round 4's form: 772 B moved per image)", cnn_variant=4)
     cnn_row("cnn_64_channel_kernel", "cnn_64", "the same model on round 3's front end (a lane = a channel, conv1 only on the matrix cores)", cnn_variant=1)

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "bnm_infer_float_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "bnm_ctx_cnn_tail_fused": (C.c_int, [_vp]),
     "bnm_ctx_cnn_planes": (C.c_int, [_vp]),
+    "bnm_ctx_cnn_pipelined": (C.c_int, [_vp]),
     "bnm_ctx_last_kernel": (C.c_char_p, [_vp]),
     "bnm_ctx_set_float_mode": (C.c_int, [_vp, C.c_int, C.c_int]),
     "bnm_ctx_float_fused": (C.c_int, [_vp]),

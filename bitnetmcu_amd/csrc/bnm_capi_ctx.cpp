@@ -204,7 +204,8 @@ int ctx_build(bnm_ctx *c) {
             std::vector<int8_t> fr((size_t)C * 6 * 1024);
             std::vector<int> bi((size_t)C * 2);
             c->cnn_li_plane2 = c->cnn_li_plane2_model = bnm_cnn_li_tables((const int8_t *)m.layers[0].weights.data(), (const int8_t *)m.layers[1].weights.data(),
-                              (const int8_t *)m.layers[3].weights.data(), C, fr.data(), bi.data());
+                              (const int8_t *)m.layers[3].weights.data(), C, fr.data(), bi.data(), &c->cnn_li_sums16);
+            c->cnn_li_pipe = c->cnn_li_sums16;
             void *p = nullptr, *q = nullptr;
             if (int e = dev_alloc(c, &p, fr.size())) return e;
             if (int e = dev_alloc(c, &q, bi.size() * sizeof(int))) return e;
@@ -484,16 +485,17 @@ const char *bnm_ctx_last_kernel(bnm_ctx *c) {
 }
 
 int bnm_ctx_set_cnn_variant(bnm_ctx *c, int variant) {
-    if (!c || variant < 0 || (variant > 5 && variant < 101) || (variant > 164 && variant < 301) || (variant > 316 && variant < 401) || variant > 416)
+    if (!c || variant < 0 || (variant > 6 && variant < 101) || (variant > 164 && variant < 301) || (variant > 316 && variant < 401) || variant > 416)
         return fail(BNM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     c->cnn_auto = false;      // (an explicit choice holds for every call size)
-    if (variant == 3 || variant == 4 || variant == 5 || variant > 300) {      // the lane = image kernel (301..316: tiles per take; 4 / 401..416: the FC tail as its own launch)
+    if (variant == 3 || variant == 4 || variant == 5 || variant == 6 || variant > 300) {      // the lane = image kernel (301..316: tiles per take; 4 / 401..416: the FC tail as its own launch)
         if (!c->cnn_li_frags) return fail(BNM_EUNSUPPORTED, "the lane = image front end serves CNN models of up to 170 channels");
         c->cnn_variant = 3;
         c->cnn_fuse_tail = !(variant == 4 || variant > 400);
         c->cnn_li_grab = variant > 400 ? (uint32_t)(variant - 400) : variant > 300 ? (uint32_t)(variant - 300) : 1u;
         c->cnn_li_plane2 = variant == 5 ? true : c->cnn_li_plane2_model;      // 5: as 3 with conv3's third plane kept whatever the weights say (A/B)
+        c->cnn_li_pipe = variant == 6 ? false : c->cnn_li_sums16;              // 6: as 3 in the four-waves-per-SIMD form whatever the weights say (A/B)
         return BNM_OK;
     }
     c->cnn_variant = variant == 0 ? 0 : 1;
@@ -509,6 +511,11 @@ int bnm_ctx_cnn_planes(const bnm_ctx *c) {
 int bnm_ctx_cnn_tail_fused(const bnm_ctx *c) {
     if (!c) return BNM_EINVAL;
     return (c->cnn_fused_ok && c->cnn_fuse_tail && c->cnn_variant == 3 && c->path == BNM_PATH_FUSED_MFMA) ? 1 : 0;
+}
+
+int bnm_ctx_cnn_pipelined(const bnm_ctx *c) {
+    if (!c) return BNM_EINVAL;
+    return (bnm_ctx_cnn_tail_fused(c) == 1 && c->cnn_li_pipe) ? 1 : 0;
 }
 
 int bnm_ctx_set_float_mode(bnm_ctx *c, int mode, int groups) {

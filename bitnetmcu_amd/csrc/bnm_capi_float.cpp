@@ -36,9 +36,9 @@ int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d
     if (c->float_mode != 2 && cnn_one_kernel_call(c, n)) {
         uint32_t *block = nullptr;
         if (int e = work_block(c, s, &block)) return e;
-        HIP_TRY(bnmk_cnn_li_fused(d_x, true, n, c->cnn_li_frags, c->cnn_li_bias, c->channels, c->cnn_li_plane2, c->gfrags, c->gdesc, c->shape.dbl, d_cls, d_logits,
+        HIP_TRY(bnmk_cnn_li_fused(d_x, true, n, c->cnn_li_frags, c->cnn_li_bias, c->channels, c->cnn_li_plane2, c->cnn_li_pipe, c->gfrags, c->gdesc, c->shape.dbl, d_cls, d_logits,
                                   block, c->cnn_li_grab, s));
-        c->last_kernel = "cnn_li_fused_kernel<float>";
+        c->last_kernel = c->cnn_li_pipe ? "cnn_li_fused_pipe_kernel<float>" : "cnn_li_fused_kernel<float>";
         return BNM_OK;
     }
     if (c->float_mode == 1) return fail(BNM_EUNSUPPORTED, "no fused float-input kernel serves this call on the context's current path");

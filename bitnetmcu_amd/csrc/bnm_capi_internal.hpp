@@ -182,6 +182,8 @@ struct bnm_ctx {
     uint32_t cnn_li_grab = 1;      // 32-image tiles a wave of the lane = image front end takes at a time
     bool cnn_li_plane2 = true;     // the lane = image kernels carry conv3's third operand plane (the weights can reach pooled conv2 values >= 2^16)
     bool cnn_li_plane2_model = true;   // ... what the model's weights say (bnm_cnn_li_tables); cnn_li_plane2 differs only under bnm_ctx_set_cnn_variant(5)
+    bool cnn_li_sums16 = false;    // every conv1 sum the weights allow fits 16 bits (bnm_cnn_li_tables): the pipelined one-kernel form serves the model
+    bool cnn_li_pipe = false;      // ... and runs (the default where it serves; bnm_ctx_set_cnn_variant(6): the four-waves-per-SIMD form, A/B)
     bool cnn_fused_ok = false;     // the lane = image kernel with the FC tail in the same wave serves this model (bnm_cnn_li_fused.hip)
     bool cnn_fuse_tail = true;     // ... and runs whenever the lane = image front end would (bnm_ctx_set_cnn_variant 3 / 300+g; 4 = unfused)
     // Work counters of the persistent kernels that hand their work out dynamically (dual-tile kernel, generic fused kernel, CNN

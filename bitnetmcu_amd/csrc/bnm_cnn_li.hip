@@ -95,8 +95,8 @@ inline int li_conv3_slot(int prow, int pcol) { return 32 * (prow >> 2) + 16 * (p
 // Returns whether conv3 needs its third operand plane: false when the weights bound EVERY pooled conv2 output below 2^16 - conv1's
 // sums reach at most 127 sum(w1+) + 128 sum(|w1-|) (inputs in -128 .. 127), its outputs m1 = that >> 4 (BitNetMCU_inference.c:261-271:
 // ReLU, then the shift); conv2 sees inputs in 0 .. m1, so its outputs reach at most (m1 sum(w2+)) >> 4, and pooling takes a maximum.
-bool bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int8_t *frag_out, int *bias_out) {
-    bool plane2 = false;
+bool bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int8_t *frag_out, int *bias_out, bool *sums16) {
+    bool plane2 = false, s16 = true;
     for (uint32_t c = 0; c < C; c++) {
         {
             int64_t p1 = 0, n1 = 0, p2 = 0;
@@ -107,6 +107,7 @@ bool bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uin
             }
             const int64_t m1 = (127 * p1 + 128 * n1) >> 4, m2 = (m1 * p2) >> 4;
             plane2 = plane2 || m2 >= 65536;
+            s16 = s16 && 127 * p1 + 128 * n1 <= 65535;      // conv1's largest possible sum (inputs -128 .. 127)
         }
         int8_t A[3][32][64] = {};
         const int8_t *k1 = w1 + 9 * c, *k2 = w2 + 9 * c, *k3 = w3 + 9 * c;
@@ -140,6 +141,7 @@ bool bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uin
         bias_out[2 * c] = 128 * s2;
         bias_out[2 * c + 1] = (128 + 32768) * s3;
     }
+    if (sums16) *sums16 = s16;
     return plane2;
 }
 

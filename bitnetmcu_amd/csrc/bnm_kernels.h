@@ -146,8 +146,9 @@ hipError_t bnmk_cnn_front(const int8_t *d_images, uint64_t n, const int8_t *d_w1
 // channel count whose records fit the LDS beside six waves (C <= 170), n_shift 4.  frags / bias: bnm_cnn_li_tables' output on the
 // device (6 KiB + 8 bytes per channel); counter: the launch's counter block.
 // returns whether conv3 needs its third operand plane (a pooled conv2 output of 2^16 or more is possible with these weights): the
-// launchers take the answer as `plane2`
-bool bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int8_t *frag_out, int *bias_out);
+// launchers take the answer as `plane2`; *sums16 (optional): no conv1 sum of any channel can exceed 65535 with these weights - what
+// the pipelined one-kernel form (cnn_li_fused_pipe_kernel) requires
+bool bnm_cnn_li_tables(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int8_t *frag_out, int *bias_out, bool *sums16 = nullptr);
 uint32_t bnmk_cnn_li_waves(uint32_t C);      // waves per workgroup; 0: the kernel does not serve this channel count
 hipError_t bnmk_cnn_front_li(const int8_t *d_images, uint64_t n, const void *d_frags, const int *d_bias, uint32_t C, bool plane2, int8_t *d_acts,
                              uint32_t acts_stride, uint32_t *d_counter, uint32_t grab, hipStream_t s);
@@ -156,7 +157,8 @@ hipError_t bnmk_cnn_front_li(const int8_t *d_images, uint64_t n, const void *d_f
 // image must be followed by 16 KiB of readable padding: fragment reads run a few KiB ahead of the last fragment).
 bool bnmk_cnn_li_fused_supported(uint32_t C, const BnmGenericDesc &d);
 // float_images: d_images is float32 [n][256], quantised in front of the operands (test_inference.py:140-141) instead of int8 [n][256]
-hipError_t bnmk_cnn_li_fused(const void *d_images, bool float_images, uint64_t n, const void *d_frags, const int *d_bias, uint32_t C, bool plane2,
+// pipe: the pipelined three-waves-per-SIMD form (only for models whose bnm_cnn_li_tables said sums16)
+hipError_t bnmk_cnn_li_fused(const void *d_images, bool float_images, uint64_t n, const void *d_frags, const int *d_bias, uint32_t C, bool plane2, bool pipe,
                              const void *d_tail_frags,
                              const BnmGenericDesc &d, bool dbl, uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t grab,
                              hipStream_t s);

@@ -163,14 +163,20 @@ class Context:
     def set_cnn_variant(self, variant):
         """1: conv1 on the matrix cores, a lane = a channel, dynamic image batches; 2: fixed share per wave; 100 + g: batches of g
         images; 0: the all-VALU front end of round 1; 3: the lane = image kernel (all three convolutions on the matrix cores;
-        300 + g: g tiles per take; the FC tail runs in the same wave where it fits - 4 / 400 + g: the tail as its own launch)"""
+        300 + g: g tiles per take; the FC tail runs in the same wave where it fits - 4 / 400 + g: the tail as its own launch; 5: conv3's
+        third plane kept; 6: the four-waves-per-SIMD form instead of the pipelined one - A/B measurements)"""
         L.check(self._lib, self._lib.bnm_ctx_set_cnn_variant(self._h, variant), "bnm_ctx_set_cnn_variant")
-        self.cnn_variant = 0 if variant == 0 else 3 if (variant in (3, 4, 5) or variant > 300) else 1
+        self.cnn_variant = 0 if variant == 0 else 3 if (variant in (3, 4, 5, 6) or variant > 300) else 1
 
     @property
     def cnn_planes(self):
         """conv3 operand planes of the lane = image CNN kernels: 2 when the weights bound the pooled conv2 outputs below 2^16, else 3."""
         return self._lib.bnm_ctx_cnn_planes(self._h)
+
+    @property
+    def cnn_pipelined(self):
+        """The one-kernel CNN form runs as cnn_li_fused_pipe_kernel (conv1 sums below 2^16: every CNN of the reference's zoo)."""
+        return self._lib.bnm_ctx_cnn_pipelined(self._h) == 1
 
     @property
     def cnn_tail_fused(self):

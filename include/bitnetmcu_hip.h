@@ -182,7 +182,10 @@ BNM_API int bnm_infer_host(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_
  * SAME wave also runs the tail - one kernel from the image bytes to the class id, nothing but 256 + 4 bytes per image through HBM
  * (bnm_ctx_cnn_tail_fused says so); 4 / 400 + g: the lane = image kernel with the tail as its own launch over act rows in per-stream
  * scratch (what every other model gets; kept selectable for A/B measurements); 5: as 3 with conv3's third operand plane kept although
- * the model's weights rule it out (bnm_ctx_cnn_planes; A/B measurements).  1 (the default beyond 170
+ * the model's weights rule it out (bnm_ctx_cnn_planes; A/B measurements); 6: as 3 in the four-waves-per-SIMD form
+ * (cnn_li_fused_kernel) although the model's weights allow the pipelined form (cnn_li_fused_pipe_kernel: three waves per SIMD that
+ * never wait for a matrix-core result, conv1's ReLU and packing in one v_cvt_pk_i16_i32 per pair - the form kernel 3 takes for every
+ * model whose conv1 sums stay below 2^16, i.e. every CNN of the reference's zoo; bnm_ctx_last_kernel names the form).  1 (the default beyond 170
  * channels): a lane = a channel, conv1 on the matrix cores, waves take batches of 8 images from a device-wide work counter; models
  * whose channel count leaves 1..16 channels beyond a multiple of 32 (16, 48, 80 ... channels) run those channels two images per
  * work item.  2 the same kernel with a fixed share of the images per wave; 100 + g (g = 1..64): batches of g images; 0 the
@@ -198,6 +201,8 @@ BNM_API int bnm_ctx_get_cnn_variant(const bnm_ctx *c);      /* the setting: 3, 1
  * 0 for FC models and CNNs the lane = image kernels do not serve. */
 BNM_API int bnm_ctx_cnn_planes(const bnm_ctx *c);
 BNM_API int bnm_ctx_cnn_tail_fused(const bnm_ctx *c);       /* 1: calls that take the lane = image front end run the one-kernel form */
+/* 1: ... and that form is the pipelined one (cnn_li_fused_pipe_kernel: the model's conv1 sums stay below 2^16 and nobody chose variant 6) */
+BNM_API int bnm_ctx_cnn_pipelined(const bnm_ctx *c);
 /* The kernels the context's LAST inference call launched (bnm_infer_device / _host / _float_device; the first chunk's of a call
  * that runs in chunks), by name and in launch order, joined by '+': e.g. "fused_fc_dual_kernel", "fused_fc_dual_kernel+fused_fc_kernel"
  * (a remainder of fewer than 64 images), "cnn_li_kernel+fused_fc_kernel", "cnn_front_mfma_kernel+fused_fc_kernel" (an AUTO context's
@@ -251,7 +256,7 @@ BNM_API int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uin
  *   - FC models on the fused MFMA path whose layers are at most 192 wide (tile classes 2, 4 and 6 of the generic kernel: every FC
  *     model of the reference's zoo, the documented 160-160-160 binary one included): fused_fc_f32_kernel;
  *   - CNN models the one-kernel CNN form serves (up to 64 channels, FC layers at most 96 wide: every CNN of the zoo), for the calls
- *     that take it (bnm_ctx_set_cnn_variant: not the small calls of a context left to itself): cnn_li_fused_kernel in its float form;
+ *     that take it (bnm_ctx_set_cnn_variant: not the small calls of a context left to itself): cnn_li_fused_pipe_kernel / cnn_li_fused_kernel in their float form;
  * everything else runs bnm_quantize_input_device into per-stream scratch followed by the model's kernels (1,540 bytes per image).
  * mode 0 (default): one kernel where it exists; 1: one kernel or BNM_EUNSUPPORTED; 2: always two kernels (A/B measurements).
  * groups (FC kernel only): 8-image groups of floats in flight per wave: 0 = default (4 in the 2-tile class, 2 in the 4-tile class, 1 in

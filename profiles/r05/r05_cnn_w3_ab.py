@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of the one-kernel CNN: four waves per SIMD (product) against the software-pipelined three-wave form (BNM_CNN_W3=1, read at
-every launch) in ONE process, launches alternating; class ids compared value for value."""
+"""A/B of the one-kernel CNN: the product (mode 0) against experimental forms selected by BNM_CNN_W3 = mode (read at every launch:
+1 = three waves per SIMD, software-pipelined; 2 = four waves with the cvt_pk epilogue) in ONE process, launches alternating;
+class ids compared value for value with mode MODES[0]."""
 import json
 import os
 import sys
@@ -12,6 +13,9 @@ import torch  # noqa: E402
 import bitnetmcu_amd as b  # noqa: E402
 
 
+MODES = [int(m) for m in os.environ.get("MODES", "0,1").split(",")]
+
+
 def main():
     n = int(float(os.environ.get("N", "1e7")))
     x = torch.empty((n, 256), dtype=torch.int8, device="cuda")
@@ -20,10 +24,10 @@ def main():
         model = b.Model.from_zoo(name)
         ctx = b.Context(model)
         ctx.set_cnn_variant(3)
-        cls = {m: torch.empty(n, dtype=torch.int32, device="cuda") for m in (0, 1)}
-        ms = {0: [], 1: []}
+        cls = {m: torch.empty(n, dtype=torch.int32, device="cuda") for m in MODES}
+        ms = {m: [] for m in MODES}
         for rnd in range(9):
-            for m in (0, 1):
+            for m in MODES:
                 os.environ["BNM_CNN_W3"] = str(m)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -32,10 +36,11 @@ def main():
                 torch.cuda.synchronize()
                 if rnd:
                     ms[m].append(e0.elapsed_time(e1))
-        diff = int((cls[0] != cls[1]).sum().item())
-        print(json.dumps({"model": name, "n": n, "kernel": ctx.last_kernel, "differing_class_ids": diff,
-                          "four_waves": {"median_ms": round(float(np.median(ms[0])), 3), "inf_per_s": round(n / np.median(ms[0]) * 1e3)},
-                          "three_waves_pipelined": {"median_ms": round(float(np.median(ms[1])), 3), "inf_per_s": round(n / np.median(ms[1]) * 1e3)}}), flush=True)
+        out = {"model": name, "n": n, "kernel": ctx.last_kernel}
+        for m in MODES:
+            out[f"mode{m}"] = {"median_ms": round(float(np.median(ms[m])), 3), "inf_per_s": round(n / np.median(ms[m]) * 1e3),
+                               "differing_class_ids": int((cls[MODES[0]] != cls[m]).sum().item())}
+        print(json.dumps(out), flush=True)
         ctx.close()
 
 

@@ -44,6 +44,26 @@ def test_lane_image_formulation_equals_the_oracle(C, wmax, seed, orc_funcs):
     assert np.array_equal(li.relunorm_from_records(rec, mx), want_a)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_pipelined_epilogue_equals_the_oracle_up_to_its_bound(seed, orc_funcs):
+    """cnn_li_fused_pipe_kernel's stage 1 (accumulators from -32768, saturating int16 pack = ReLU, hi plane as (w >> 8) - 8) on
+    models whose conv1 sums stay below 2^16 - two channels sit AT the bound (65,532 and 65,408, attained by the all-127 / all -128 image)."""
+    rng = np.random.default_rng(100 + seed)
+    f = orc_funcs
+    C = 5
+    w1 = rng.integers(-50, 51, size=(C, 9)).astype(np.int8)
+    w1[0] = [58] * 8 + [52]
+    w1[1] = [-57] * 8 + [-55]
+    assert all(127 * int(w[w > 0].sum()) - 128 * int(w[w < 0].sum()) <= 65535 for w in w1.astype(np.int64))
+    w2, w3 = (rng.integers(-128, 128, size=(C, 9)).astype(np.int8) for _ in range(2))
+    x = np.concatenate([synth.images(seed, 20, DIST_U), synth.images(seed, 20, DIST_M), np.full((2, 256), -128, np.int8),
+                        np.full((2, 256), 127, np.int8), np.zeros((1, 256), np.int8)])
+    want_f, want_a = oracle_front_end(f, x, w1, w2, w3)
+    got_f, (rec, mx) = li.front_end_features(x, w1, w2, w3, pipelined=True)
+    assert np.array_equal(got_f, want_f)
+    assert np.array_equal(li.relunorm_from_records(rec, mx), want_a)
+
+
 def test_toeplitz_fragments_are_int8_and_translation_invariant():
     w = np.array([1, -2, 3, -4, 5, -6, 7, -8, 9], np.int8)
     for T in (li.toeplitz_conv1(w), li.toeplitz_conv2(w), li.toeplitz_conv3(w)):

@@ -202,9 +202,10 @@ def test_cnn_front_end_both_kernels(name, gpu_ok, orc):
                         np.full((2, 256), -128, np.int8), np.full((2, 256), 127, np.int8)])
     want = om.infer(x, logits=True)
     assert ctx.cnn_tail_fused        # every CNN of the zoo: the FC tail runs inside the lane = image kernel's wave (one kernel)
-    for variant in (3, 302, 5, 4, 402, 1, 0):   # 4 / 402: the tail as its own launch; 5: conv3's third plane kept (the zoo's weights rule it out)
+    for variant in (3, 302, 5, 6, 4, 402, 1, 0):   # 4 / 402: the tail as its own launch; 5: conv3's third plane kept (the zoo's weights rule it out); 6: the four-wave form
         ctx.set_cnn_variant(variant)
-        assert ctx.cnn_tail_fused == (variant in (3, 302, 5)) and ctx.cnn_planes == (3 if variant == 5 else 2)
+        assert ctx.cnn_tail_fused == (variant in (3, 302, 5, 6)) and ctx.cnn_planes == (3 if variant == 5 else 2)
+        assert ctx.cnn_pipelined == (variant in (3, 302, 5))
         # (<= 16 channels: two images per item, the last one or two images through the single-image instantiation)
         for n in (len(x), 1, 5, 2, 3, 4, 1000, 31, 32, 33, 65):
             got = ctx.infer(x[:n], logits=True)
@@ -408,7 +409,7 @@ def test_one_kernel_calls_capture_without_a_warm_up(gpu_ok, orc):
     g2 = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g2, stream=side2):
         ctx.infer_device(x8, cls, lg)
-    assert ctx.last_kernel == "cnn_li_fused_kernel"
+    assert ctx.last_kernel == "cnn_li_fused_pipe_kernel"
     for k in range(3):
         xin = synth.images(1000 * k, n, DIST_U)
         x8.copy_(torch.from_numpy(xin).cuda())
@@ -656,7 +657,7 @@ def test_float_input_cnn_in_one_kernel(name, gpu_ok, orc):
                 torch.cuda.synchronize()
                 one = mode == 0 and (named or n >= 2 * C * C)
                 if one:
-                    assert ctx.last_kernel == "cnn_li_fused_kernel<float>", (name, named, mode, n, ctx.last_kernel)
+                    assert ctx.last_kernel == "cnn_li_fused_pipe_kernel<float>", (name, named, mode, n, ctx.last_kernel)      # (zoo models: conv1 sums < 2^16)
                 else:
                     assert ctx.last_kernel.startswith("quantize_input_kernel+"), (name, named, mode, n, ctx.last_kernel)
                 assert np.array_equal(cls.cpu().numpy().astype(np.uint32), want_cls[:n]), (name, named, mode, n)
@@ -737,13 +738,17 @@ def test_last_kernel_names_what_the_call_ran(gpu_ok):
     assert ctx.last_kernel == ""
     C = model.layer(0).out_channels
     assert C == 64 and ctx.cnn_variant == 3
-    for n, front in ((2 * C * C - 1, "cnn_front_mfma_kernel"), (2 * C * C, "cnn_li_fused_kernel"), (1, "cnn_front_mfma_kernel")):
+    for n, front in ((2 * C * C - 1, "cnn_front_mfma_kernel"), (2 * C * C, "cnn_li_fused_pipe_kernel"), (1, "cnn_front_mfma_kernel")):
         got = ran(ctx, n)
         assert got.split("+")[0] == front, (n, got)
         assert ctx._lib.bnm_ctx_get_cnn_variant(ctx._h) == 3             # the setting does not move
         assert set(bench.kernel_name(b, ctx, model, n, False).split("+")) == set(got.split("+")), (n, got)
     ctx.set_cnn_variant(3)                                               # named: holds for every call size
-    assert ran(ctx, 7) == "cnn_li_fused_kernel"                          # (front end + FC tail: the call's only launch)
+    assert ran(ctx, 7) == "cnn_li_fused_pipe_kernel"                     # (front end + FC tail: the call's only launch; the pipelined form)
+    assert ctx.cnn_pipelined
+    ctx.set_cnn_variant(6)                                               # the four-waves-per-SIMD form of the same
+    assert ran(ctx, 7) == "cnn_li_fused_kernel" and not ctx.cnn_pipelined
+    assert bench.kernel_name(b, ctx, model, 7, True) == "cnn_li_fused_kernel"
     ctx.set_cnn_variant(4)                                               # the tail as its own launch
     assert ran(ctx, 7) == "cnn_li_kernel+fused_fc_kernel"
     ctx.set_cnn_variant(1)
@@ -836,7 +841,7 @@ def test_bench_json_contract(gpu_ok):
     assert fl["roofline"]["algorithmic_bytes_per_inference"] == 1028 and 0 < fl["roofline"]["frac"] <= 1
     assert ex["fc_float_input_two_kernels"]["kernel"].startswith("quantize_input_kernel+") and ex["fc_float_input_two_kernels"]["verified_vs_oracle"] is True
     # the CNN is one launch per call; its row says what binds it in the kernel's own terms
-    assert ex["cnn_64"]["launched"] in ("cnn_li_fused_kernel", "cnn_front_mfma_kernel+fused_fc_kernel")
+    assert ex["cnn_64"]["launched"] in ("cnn_li_fused_pipe_kernel", "cnn_front_mfma_kernel+fused_fc_kernel")
     assert "int8_ops_algorithmic" in ex["cnn_64"]["roofline"] and ex["cnn_64"]["roofline"]["int8_ops_algorithmic"]["per_image"] == 2 * 236416
     # every row once more, compact, inside roofline (kept whole by the driver) and as the line's last key
     assert set(d["summary_rows"]) == set(k for k in ex if "roofline" in ex[k]) and list(d)[-1] == "summary_rows"
@@ -1446,6 +1451,60 @@ def test_cnn_third_plane_is_dropped_exactly_when_the_weights_rule_it_out(gpu_ok,
         assert ctx.last_kernel == "cnn_li_fused_kernel<float>"
         assert np.array_equal(cls.cpu().numpy().astype(np.uint32), wantf[0]) and np.array_equal(lg.cpu().numpy(), wantf[1]), w2sum
         ctx.close()
+
+
+def test_cnn_pipelined_form_runs_exactly_when_conv1_sums_fit_16_bits(gpu_ok, orc):
+    """cnn_li_fused_pipe_kernel starts conv1's accumulators at -32768 and lets v_cvt_pk_i16_i32 be the ReLU and the int16 packing:
+    right only while no conv1 sum exceeds 65535 (bnm_cnn_li_tables' sums16: 127 sum(w1+) + 128 sum|w1-| per channel).  Every CNN of
+    the zoo is below the bound.  Crafted models AT it, whose bound is attained by an image of the test: positive kernels summing to
+    516 (all-127 image: 65,532 - pipelined, conv1 outputs at the top of their 12 bits) and 517 (65,659: the four-wave form);
+    negative kernels summing to -511 (all -128 image: 65,408 - pipelined) and -512 (65,536: not).  Every form equals the oracle."""
+    import torch
+    from bitnetmcu_amd import harness
+    for name in [n for n in MODEL_NAMES if "cnn" in n]:
+        ctx = b.Context(util.load_golden_model(name))
+        ctx.set_cnn_variant(3)
+        assert ctx.cnn_pipelined, name
+        ctx.close()
+    C = 8
+    for w1, piped in (([58] * 8 + [52], True), ([58] * 8 + [53], False), ([-57] * 8 + [-55], True), ([-57] * 8 + [-56], False)):
+        for small_w2 in (False, True):
+            rng = np.random.default_rng(abs(sum(w1)) + small_w2)
+
+            def conv_weights(k):
+                if k == 2:
+                    return np.array(w1 * C)
+                if k == 4 and small_w2:
+                    return np.array(list(rng.integers(-128, 20, size=9)) * C)      # (pooled conv2 outputs below 2^16: two conv3 planes)
+                return np.array(list(rng.integers(-128, 128, size=9)) * C)
+            model = b.Model.from_header_text(_random_cnn_text(rng, C, (16, 4, 4), (64, 32), 10, conv_weights))
+            om = util.OracleModel(model, orc)
+            x = np.concatenate([np.full((40, 256), 127, np.int8), np.full((40, 256), -128, np.int8), synth.images(5, 500, DIST_U),
+                                np.clip(synth.images(6, 500, DIST_M).astype(np.int16) + 100, -128, 127).astype(np.int8)])
+            want = om.infer(x, logits=True)
+            for variant in (3, 6, 4, 1):
+                ctx = b.Context(model)
+                ctx.set_cnn_variant(variant)
+                assert ctx.cnn_pipelined == (piped and variant == 3), (w1, variant)
+                assert not small_w2 or ctx.cnn_planes == 2, (w1, ctx.cnn_planes)
+                for n in (len(x), 33):
+                    got = ctx.infer(x[:n], logits=True)
+                    assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n]), (w1, small_w2, variant, n)
+                if variant in (3, 6):
+                    assert ctx.last_kernel == ("cnn_li_fused_pipe_kernel" if piped and variant == 3 else "cnn_li_fused_kernel")
+                ctx.close()
+            xf = x.astype(np.float32)
+            xf[:, 0] = np.where(np.abs(xf).max(axis=1) < 127, 127.0, xf[:, 0])
+            wantf = om.infer(harness.quantize_input(xf), logits=True)
+            ctx = b.Context(model)
+            ctx.set_cnn_variant(3)
+            cls = torch.empty(len(xf), dtype=torch.int32, device="cuda")
+            lg = torch.empty((len(xf), 10), dtype=torch.int32, device="cuda")
+            ctx.infer_float_device(torch.from_numpy(xf).cuda(), cls, lg)
+            torch.cuda.synchronize()
+            assert ctx.last_kernel == ("cnn_li_fused_pipe_kernel<float>" if piped else "cnn_li_fused_kernel<float>")
+            assert np.array_equal(cls.cpu().numpy().astype(np.uint32), wantf[0]) and np.array_equal(lg.cpu().numpy(), wantf[1]), (w1, small_w2)
+            ctx.close()
 
 
 @pytest.mark.parametrize("name", ["mcu_cnn_16", "cnn_64"])
