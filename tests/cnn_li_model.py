@@ -102,8 +102,9 @@ def front_end_features(images, w1, w2, w3, pipelined=False):
     """images int8 [N][256]; w*: int8 [C][9].  Returns (features int64 [N][4C], records): the features as the reference orders
     them (channel-major, 2x2 pool output row-major) and the compressed per-(channel, lane half) records of the fused ReLUNorm.
     pipelined: stage 1's epilogue as cnn_li_fused_pipe_kernel computes it (bnm_cnn_li_tile_body_pipe.inc) - the accumulators start
-    at -32768, v_cvt_pk_i16_i32's saturation is the ReLU, an arithmetic shift gives w - 2048 whose low byte is w's and whose high
-    byte is (w >> 8) - 8; conv2's bias carries the hi plane's offset.  Valid while no conv1 sum exceeds 65535 (asserted)."""
+    at -32768, v_cvt_pk_i16_i32's saturation is the ReLU; of u = relu(sum) - 32768 the high byte is the A plane (A - 128, A =
+    relu(sum) >> 8) and (low byte & 0xF0) ^ 0x80 the B plane (16 B - 128, B = bits 4..7): conv1's output is 16 A + B, conv2's two
+    sums combine as 256 dA + dB = 16 x the conv2 sum, the offsets travel in its bias.  Valid while no conv1 sum exceeds 65535 (asserted)."""
     N, C = images.shape[0], w1.shape[0]
     img = images.astype(np.int64).reshape(N, 16, 16)
     # B operands of stage 1: K-step s, slot 16 (row & 1) + col
@@ -123,10 +124,11 @@ def front_end_features(images, w1, w2, w3, pipelined=False):
                 regs = lane_regs(D, h)
                 if pipelined:
                     assert regs[:14].max() <= 65535, "the pipelined form serves models whose conv1 sums stay below 2^16"
-                    t = np.clip(regs[:14] - 32768, -32768, 32767) >> 4      # v_cvt_pk_i16_i32 (saturating), v_pk_ashrrev_i16: w - 2048
-                    lo[r][16 * h:16 * h + 14] = (t & 255) - 128             # low byte of w - 2048 = w's; ^ 0x80 read as int8
-                    hi[r][16 * h:16 * h + 14] = t >> 8                      # (w >> 8) - 8 as a signed byte: -8 .. 7
-                    hi[r][16 * h + 14:16 * h + 16] = 0
+                    u = np.clip(regs[:14] - 32768, -32768, 32767)          # v_cvt_pk_i16_i32 (saturating): relu(sum) - 32768
+                    # w = relu(sum) >> 4 = 16 A + B, A = relu(sum) >> 8, B = bits 4..7 of relu(sum)
+                    lo[r][16 * h:16 * h + 14] = (u & 0xF0) - 128            # the B plane: (low byte & 0xF0) ^ 0x80 read as int8 = 16 B - 128
+                    hi[r][16 * h:16 * h + 14] = u >> 8                      # the A plane: u's high byte as a signed byte = A - 128
+                    hi[r][16 * h + 14:16 * h + 16] = -128                   # (padding halves hold 0x8000)
                 else:
                     v = np.maximum(regs[:14], 0) >> 4
                     lo[r][16 * h:16 * h + 14] = (v & 255) - 128
@@ -141,7 +143,10 @@ def front_end_features(images, w1, w2, w3, pipelined=False):
                 rl, rh = lane_regs(DL, h), lane_regs(DH, h)
                 for t in range(3):
                     s = rl[4 * t:4 * t + 4] + 256 * rh[4 * t:4 * t + 4]
-                    P = np.maximum(s.max(axis=0) + (17 if pipelined else 1) * 128 * sw2, 0) >> 4      # (pipelined: + 8 x 256 x the weight sum for the hi plane's offset)
+                    if pipelined:      # s is 16 x the conv2 sum less the planes' offsets: (32768 + 128) x the weight sum
+                        P = np.maximum(s.max(axis=0) + 257 * 128 * sw2, 0) >> 8
+                    else:
+                        P = np.maximum(s.max(axis=0) + 128 * sw2, 0) >> 4
                     k = conv3_slot(r2, 2 * t + h)
                     p[0][k >> 5][k & 31] = (P & 255) - 128
                     p[1][k >> 5][k & 31] = ((P >> 8) & 255) - 128
