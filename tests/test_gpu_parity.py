@@ -1306,8 +1306,10 @@ def test_fuzz_random_cnn_models(seed, gpu_ok, orc):
         codecs = (16,) + codecs[1:]          # 4 C act bytes are a multiple of 16: any codec but binary / 2-bit fits every C
     widths = tuple(int(rng.integers(1, 128 // need[codecs[k]] + 1)) * need[codecs[k]] for k in (1, 2))
     n_classes = int(rng.integers(2, 41))
-    # odd seeds: conv kernels over the whole int8 range (the zoo's do: -128 .. 127), even seeds: small ones
-    conv_weights = (lambda k: rng.integers(-128, 128, size=9 * C)) if seed % 2 else None
+    # odd seeds: conv kernels over the whole int8 range (the zoo's do: -128 .. 127), seeds 0 mod 4: small ones; seeds 2 mod 4: conv1
+    # kernels up to +-56 - conv1 sums up to 64,512: the pipelined one-kernel form (sums below 2^16) over its whole range - the others full range
+    conv_weights = ((lambda k: rng.integers(-128, 128, size=9 * C)) if seed % 2 else
+                    (lambda k: rng.integers(-56, 57, size=9 * C) if k == 2 else rng.integers(-128, 128, size=9 * C)) if seed % 4 == 2 else None)
     model = b.Model.from_header_text(_random_cnn_text(rng, C, codecs, widths, n_classes, conv_weights))
     om = util.OracleModel(model, orc)
     x = np.concatenate([synth.images(seed, 120, DIST_U), synth.images(seed, 121, DIST_M), np.full((2, 256), -128, np.int8),
