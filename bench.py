@@ -47,6 +47,101 @@ MACS_PER_WAVE_DOT4 = 4 * 64    # one wave64 v_dot4_i32_i8: 4 MACs per lane
 ORACLE_DIGEST_1E8 = 0x81b56c9fafee6636
 
 
+LINE_LIMIT = 4096      # the driver recovers the LAST stdout line; round 5's 37 KB line did not survive its buffer
+
+
+def sig(x, digits=5):
+    """floats to `digits` significant digits (the compact line is for reading and for the driver's consistency check, the full
+    precision is in bench_full.json)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{digits}g}")
+
+
+def compact_line(out):
+    """The ONE line the driver parses: the contract keys, the dominant kernel's roofline, the CPU baseline and every other row as
+    [inferences/s, binding roofline, fraction of it, verified vs oracle].  Everything else of `out` (definitions, sources, per-row
+    detail) is in bench_full.json and on the '# ' stdout lines before this one.  Pure function of `out`: tests/test_bench_cpu.py
+    runs it over committed full records."""
+    cfg = out["config"]
+    src = cfg.get("model_source") or ""
+    c = {"workload": cfg["workload"].replace(" synthetic 16x16 int8 images per GPU resident in HBM", " synthetic images/GPU in HBM"),
+         "images_per_gpu": cfg["images_per_gpu"], "global_images": cfg["global_images"],
+         "model_source": ("reference's own header bytes" if "the reference's own" in src else
+                          "reference exporter's header" if "exportquant.py" in src else
+                          "header file" if src.startswith("exporter-written header file") else "blob re-emitted as header text")
+                         + ", run-time parser",
+         "parallelism": cfg["parallelism"].split(",")[0]}
+    for k in ("dist_backend", "rccl_ranks"):
+        if cfg.get(k) is not None:
+            c[k] = cfg[k]
+    if cfg.get("ranks_share_device"):
+        c["ranks_share_device"] = True
+    rf = out["roofline"]
+    r = {k: sig(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac")}
+    r["traffic"] = sig(rf["traffic"], 6) if isinstance(rf.get("traffic"), float) else rf.get("traffic")
+    ts = rf.get("traffic_source")
+    r["traffic_source"] = None if ts is None else ("pmc replay " + (ts.split("--pmc pass ")[1].split(";")[0] if "--pmc pass " in ts else ""))[:60]
+    r["kernel"] = rf["kernel"]
+    if rf.get("launched") and rf["launched"] != rf["kernel"]:
+        r["launched"] = rf["launched"]
+    for k in ("avg_launch_ms", "median_launch_ms", "min_launch_ms"):
+        r[k] = sig(rf[k])
+    r["algorithmic_bytes_per_launch"] = rf["algorithmic_bytes_per_launch"]
+    if rf.get("stream_read"):
+        r["stream_read"] = {"GB/s": sig(rf["stream_read"]["GB/s"])}
+        r["time_vs_stream_read"] = sig(rf["time_vs_stream_read"], 4)
+    if rf.get("mfma"):
+        r["mfma"] = {"per_image": rf["mfma"]["per_image"], "frac": sig(rf["mfma"]["frac"], 4)}
+        if "busy_frac" in rf["mfma"]:
+            r["mfma"]["busy_frac"] = sig(rf["mfma"]["busy_frac"], 4)
+    if rf.get("counters_dropped"):
+        r["counters_dropped"] = len(rf["counters_dropped"])
+    line = {k: sig(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["metric"] = line["metric"].replace(" (BitNetMCU_model_fc.h)", "")
+    line["config"] = c
+    line["roofline"] = r
+    if out.get("per_rank_ms_per_step"):
+        line["per_rank_ms_per_step"] = [sig(x, 4) for x in out["per_rank_ms_per_step"]]
+    if out.get("cpu_baseline"):
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample"].replace("reference BitMnistInference (gcc -O3 -march=x86-64-v3)", "ref gcc -O3")
+                                                      .replace(", 8192 resident synthetic images per thread", "")[:110]}
+    line["verified_vs_oracle"] = out["verified_vs_oracle"]
+    line["digest"] = out["digest"]
+    if out.get("digest_expected"):
+        line["digest_ok"] = out["digest"] == out["digest_expected"]
+    ex = out.get("extra_configs")
+    if ex:
+        line["rows_format"] = "[inf/s, bound, frac, verified]"
+        line["rows"] = {k: [sig(v["value"], 4), v["roofline"]["bound"], sig(float(v["roofline"]["frac"]), 4), v["verified_vs_oracle"]]
+                        for k, v in ex.items() if "roofline" in v}
+        for k in ("ternary_alu", "cnn_64"):           # configs[2] / configs[3]: the reference's CPU rate on the same host cores
+            if k in ex and "cpu_baseline" in ex[k]:
+                line.setdefault("rows_cpu", {})[k] = sig(ex[k]["cpu_baseline"]["value"], 4)
+        line["full"] = "bench_full.json"
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, f"bench line is {len(text)} bytes (limit {LINE_LIMIT}): move detail to bench_full.json"
+    return text
+
+
+def emit(out, full_path):
+    """bench_full.json beside the script + '# ' lines on stdout (every detail, one line per row; no line but the last starts with
+    '{'), then the compact line as the LAST stdout line."""
+    line = compact_line(out)
+    try:
+        with open(full_path, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        print(f"# {full_path} not written: {e}", flush=True)
+    for k, v in (out.get("extra_configs") or {}).items():
+        print(f"# row {k} " + json.dumps(v), flush=True)
+    print("# full " + json.dumps({k: v for k, v in out.items() if k != "extra_configs"}), flush=True)
+    print(line, flush=True)
+
+
 def checker():
     """The oracle-backed checker (oracle/checker.py): imported only for verification outside the timed region and for the
     cpu_baseline leg.  The product package never imports it."""
@@ -329,6 +424,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs section (N = 1 only)")
+    ap.add_argument("--full-json", default=os.path.join(REPO, "bench_full.json"), help="where rank 0 writes the full record (every row in detail)")
     ap.add_argument("--header", default=None, help="load the model from this exporter-written BitNetMCU_model.h (text parser) "
                                                   "instead of bitnetmcu_amd/zoo/<model>.bnm")
     a = ap.parse_args()
@@ -451,8 +547,8 @@ def main():
         avg_ms = float(np.mean(launch_ms))
         achieved = n * bpi / (avg_ms * 1e-3) / 1e9
         kname = kernel_name(b, ctx, model, n, a.cnn_variant >= 0)
-        if a.input == "float":
-            kname = "fused_fc_f32_kernel" if ctx.float_fused else "quantize_input_kernel+" + kname
+        if a.input == "float":      # what the library says the timed call ran (CNNs: cnn_li_fused_pipe_kernel<float>; short calls: two kernels)
+            kname = ctx.last_kernel
         # the box's plain read rate over the same resident images, same process, same stream (bnm_stream_read_device)
         sink = torch.zeros(1, dtype=torch.int32, device=dev)
         src_t = xf if a.input == "float" else images
@@ -531,14 +627,7 @@ def main():
                 # configs[2] / configs[3]: the reference's CPU path on the same host cores, a quarter of the headline's sample each
                 for row, name in (("ternary_alu", "tern_96"), ("cnn_64", "cnn_64")):
                     out["extra_configs"][row]["cpu_baseline"] = cpu_baseline(b, name, 0, max(1.0, a.cpu_seconds / 4))
-        if "extra_configs" in out:
-            # every row once more in a few characters: inside "roofline" (an object the driver keeps whole) and as the LAST key of
-            # the line (the driver also keeps the line's tail)
-            rows = {k: [float(f"{v['value']:.4g}"), v["roofline"]["bound"], round(v["roofline"]["frac"], 4), v["verified_vs_oracle"]]
-                    for k, v in out["extra_configs"].items() if "roofline" in v}
-            out["roofline"]["rows"] = {"format": "[inferences/s, binding roofline, fraction of it, verified vs oracle]", **rows}
-            out["summary_rows"] = rows
-        print(json.dumps(out), flush=True)
+        emit(out, a.full_json)
     if distributed:
         td.barrier()
         td.destroy_process_group()
@@ -571,7 +660,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
                       "valu_per_image_source": f"instruction count replayed from profiles/pmc_counters.json (SQ_INSTS_VALU, which counts MFMA instructions too; pass {c.get('source')})"})
         return r
 
-    def run(name, model_name, count, steps, warmup, dist=0, want_logits=False, variant=-1, path=0, note=None, cnn_variant=-1):
+    def run(name, model_name, count, steps, warmup, dist=0, want_logits=False, variant=-1, path=0, note=None, cnn_variant=-1, want_planes=False):
         model, src = load_model_through_the_text_parser(b, model_name)
         ctx = b.Context(model, device=dev.index)
         if cnn_variant >= 0:
@@ -594,9 +683,10 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
                      "mfma_per_image": model_mfmas_per_image(b, model) if ctx.path == b.PATH_FUSED_MFMA else None}
         if note:
             res[name]["note"] = note
+        planes = ctx.cnn_planes if want_planes else None      # conv3 operand planes of the lane = image kernels (bnm_ctx_cnn_planes)
         ctx.close()
         del lg
-        return rate, model
+        return (rate, model, planes) if want_planes else (rate, model)
 
     def hbm_entry(name, rate, bpi):
         g = rate * bpi / 1e9
@@ -687,7 +777,7 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
     # the ALGORITHMIC int8 operations (2 x MACs of the reference's loops) against the dense int8 matrix-core peak, the issued MFMAs
     # against the same peak, and the HBM fraction of the 260 algorithmic bytes (+ counter traffic where measured)
     def cnn_row(name, model_name, note, cnn_variant=-1):
-        r, m = run(name, model_name, n_cnn, 3, 1, note=note, cnn_variant=cnn_variant)
+        r, m, planes = run(name, model_name, n_cnn, 10, 2, note=note, cnn_variant=cnn_variant, want_planes=True)
         kern = res[name]["kernel"].split("+")[-1]
         li = kern in ("cnn_li_kernel", "cnn_li_fused_kernel", "cnn_li_fused_pipe_kernel")
         macs = model_macs(b, m)
@@ -713,11 +803,12 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
                                         "definition": "2 x the reference loops' multiply-accumulates per image x inferences/s / dense int8 peak (5.03e15 op/s)"}
         roof["hbm_frac"] = r * BYTES_PER_INFERENCE / 1e9 / HBM_PEAK_GBS
         if li:
-            per = 44.0 * m.layer(0).out_channels / 32.0 + model_mfmas_per_image(b, m)
-            roof["mfma"] = {"per_image": per, "achieved_per_s": r * per, "peak_per_s": MFMA_I8_32X32X32_PEAK_PER_S,
-                            "frac": r * per / MFMA_I8_32X32X32_PEAK_PER_S,
-                            "definition": "44 v_mfma_i32_32x32x32_i8 per channel and 32-image tile (conv1 14, conv2 24, conv3 6) + the FC tail's: "
-                                          "the Toeplitz form issues ~12 x the algorithmic int8 operations"}
+            per_tile = 14 + 24 + 2 * planes      # conv1 14, conv2 24 (two operand planes), conv3 2 per operand plane
+            per = per_tile * m.layer(0).out_channels / 32.0 + model_mfmas_per_image(b, m)
+            roof["mfma"] = {"per_image": per, "per_channel_tile": per_tile, "conv3_planes": planes, "achieved_per_s": r * per,
+                            "peak_per_s": MFMA_I8_32X32X32_PEAK_PER_S, "frac": r * per / MFMA_I8_32X32X32_PEAK_PER_S,
+                            "definition": f"{per_tile} v_mfma_i32_32x32x32_i8 per channel and 32-image tile (conv1 14, conv2 24, conv3 {2 * planes}: "
+                                          "bnm_ctx_cnn_planes) + the FC tail's: the Toeplitz form issues ~12 x the algorithmic int8 operations"}
         res[name]["roofline"] = roof
     cnn_row("cnn_64", "cnn_64", "BASELINE configs[3]")
     cnn_row("cnn_64_four_waves", "cnn_64", "the one-kernel form at four waves per SIMD (round 5's first form: SDWA conv1 epilogue, a wave waits for its MFMA results; A/B)", cnn_variant=6)

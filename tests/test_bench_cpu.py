@@ -95,3 +95,45 @@ def test_replayed_counters_are_tied_to_the_kernel_binaries_of_the_loaded_library
     text = " | ".join(c["dropped"])
     assert "stale" in text and "unstamped" in text and "gone" in text and "pmc_traffic.json" in text and "different binary" in text
     assert bench.load_counters(None)["pmc_counters.json"] == {}
+
+
+def test_bench_line_is_short_enough_for_the_driver():
+    """round 5's line was 37 KB and the driver's record of the round held no parsed headline.  The LAST stdout
+    line is bench.compact_line(full record): under 4 KB (asserted inside it too), contract keys + roofline + cpu_baseline + compact
+    rows; checked here over committed full records of real runs and over an 8-rank record with twice the rows."""
+    import copy
+    import glob
+    import json
+    import bench
+    recs = sorted(glob.glob(os.path.join(REPO, "profiles", "r05", "r05zz_bench*.json")))
+    assert recs
+    for p in recs:
+        full = json.load(open(p))
+        text = bench.compact_line(full)
+        assert len(text) < 4096 and "\n" not in text
+        c = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "verified_vs_oracle", "digest", "rows"):
+            assert k in c, k
+        assert abs(c["value"] - full["value"]) <= 1e-4 * full["value"] and c["steps"] == full["steps"] and c["warmup"] == full["warmup"]
+        assert abs(c["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-4 and abs(c["roofline"]["traffic"] - full["roofline"]["traffic"]) <= 1e-5 * full["roofline"]["traffic"]
+        assert c["roofline"]["traffic_source"] is None or len(c["roofline"]["traffic_source"]) <= 60
+        assert set(c["rows"]) == set(k for k, v in full["extra_configs"].items() if "roofline" in v)
+        assert "workload" in c["config"] and "model" not in c["config"]
+    # the --gpus N line: per-rank times, no rows
+    multi = copy.deepcopy(full)
+    multi.pop("extra_configs")
+    multi.pop("cpu_baseline")
+    multi.update(n_gpus=8, per_rank_ms_per_step=[4.0123456789] * 8, per_rank_kernel_ms=[4.0] * 8)
+    multi["config"].update(dist_backend="nccl", rccl_ranks=8, parallelism="dp8 image-shard (weak scaling), no data-path collective")
+    c = json.loads(bench.compact_line(multi))
+    assert c["n_gpus"] == 8 and len(c["per_rank_ms_per_step"]) == 8 and c["config"]["rccl_ranks"] == 8 and "rows" not in c
+    # twice the rows still fit; a record that cannot fit fails loudly instead of printing a line the driver drops
+    big = copy.deepcopy(full)
+    for k, v in list(big["extra_configs"].items()):
+        big["extra_configs"][k + "_again"] = v
+    assert len(bench.compact_line(big)) < 4096
+    for i in range(200):
+        big["extra_configs"][f"row_with_a_long_name_{i}"] = v
+    with pytest.raises(AssertionError, match="bench line is"):
+        bench.compact_line(big)

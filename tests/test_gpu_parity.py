@@ -805,17 +805,50 @@ def test_mixed_stream_probe_writes_the_fold_of_what_it_read(gpu_ok):
         assert np.array_equal(got[:tiles * units * 4], want) and (got[tiles * units * 4:] == 0xFFFFFFFF).all(), mode
 
 
-def test_bench_json_contract(gpu_ok):
-    """bench.py on a small N: one JSON line with the contract's keys, verified against the oracle."""
+BENCH_CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                       "dtype", "data", "config", "roofline")
+
+
+def _check_bench_stdout(stdout):
+    """The LAST stdout line is the one the driver parses: the only line that starts with '{', under 4 KB,
+    the contract's keys in it."""
+    import json
+    lines = stdout.splitlines()
+    js = [l for l in lines if l.startswith("{")]
+    assert len(js) == 1 and lines[-1] == js[0], "ONE JSON line, the last of stdout, from rank 0"
+    assert len(js[0]) < 4096, len(js[0])
+    c = json.loads(js[0])
+    for k in BENCH_CONTRACT_KEYS:
+        assert k in c, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_bytes_per_launch"):
+        assert k in c["roofline"], k
+    assert "workload" in c["config"]
+    return c
+
+
+def test_bench_json_contract(gpu_ok, tmp_path):
+    """bench.py on a small N: ONE short JSON line with the contract's keys as the last stdout line, every detail in the full record
+    (--full-json), verified against the oracle."""
     import json
     import subprocess
     import sys
+    full = str(tmp_path / "full.json")
     out = subprocess.run([sys.executable, os.path.join(util.REPO, "bench.py"), "--images", "300000", "--steps", "3", "--warmup", "1",
-                          "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
+                          "--cpu-seconds", "1", "--full-json", full], capture_output=True, text=True, timeout=900)
+    c = _check_bench_stdout(out.stdout)
+    d = json.load(open(full))
+    # the compact line against the full record
+    assert c["n_gpus"] == 1 and c["steps"] == 3 and c["warmup"] == 1 and c["dtype"] == "i8" and c["vs_baseline"] is None
+    assert abs(c["value"] - d["value"]) <= 1e-4 * d["value"] and abs(c["ms_per_step"] - d["ms_per_step"]) <= 1e-4 * d["ms_per_step"]
+    assert abs(c["roofline"]["frac"] - d["roofline"]["frac"]) < 1e-4 and c["roofline"]["kernel"] == d["roofline"]["kernel"]
+    assert c["verified_vs_oracle"] is True and c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] in ("reference", "port")
+    assert c["roofline"]["stream_read"]["GB/s"] > 0 and 0 < c["roofline"]["mfma"]["frac"] < 1 and 0 < c["roofline"]["mfma"]["busy_frac"] < 1
+    assert set(c["rows"]) == set(k for k in d["extra_configs"] if "roofline" in d["extra_configs"][k])
+    assert all(v[3] is True and v[0] > 0 and 0 < v[2] <= 1 for v in c["rows"].values()), c["rows"]
+    assert c["rows_cpu"]["cnn_64"] > 0 and c["rows_cpu"]["ternary_alu"] > 0
+    # ... and the '# ' lines carry the same detail on stdout
+    assert any(l.startswith("# row cnn_64 {") for l in out.stdout.splitlines()) and any(l.startswith("# full {") for l in out.stdout.splitlines())
+    for k in BENCH_CONTRACT_KEYS + ("cpu_baseline",):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "i8" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["verified_vs_oracle"] is True and "workload" in d["config"]
@@ -843,9 +876,9 @@ def test_bench_json_contract(gpu_ok):
     # the CNN is one launch per call; its row says what binds it in the kernel's own terms
     assert ex["cnn_64"]["launched"] in ("cnn_li_fused_pipe_kernel", "cnn_front_mfma_kernel+fused_fc_kernel")
     assert "int8_ops_algorithmic" in ex["cnn_64"]["roofline"] and ex["cnn_64"]["roofline"]["int8_ops_algorithmic"]["per_image"] == 2 * 236416
-    # every row once more, compact, inside roofline (kept whole by the driver) and as the line's last key
-    assert set(d["summary_rows"]) == set(k for k in ex if "roofline" in ex[k]) and list(d)[-1] == "summary_rows"
-    assert d["roofline"]["rows"]["cnn_64"] == d["summary_rows"]["cnn_64"]
+    # the CNN row's MFMA count is the kernel's own (bnm_ctx_cnn_planes): 14 + 24 + 2 x 2 per channel and tile x 64 channels / 32 + the tail's 5
+    assert ex["cnn_64"]["roofline"]["mfma"]["per_channel_tile"] == 42 and ex["cnn_64"]["roofline"]["mfma"]["per_image"] == 85.0
+    assert ex["cnn_64"]["steps"] >= 10 and ex["cnn_64"]["warmup"] >= 2
     for k in ("ternary_alu", "ternary_mfma_generic", "cnn_64", "fc_generic_kernel", "fc_logits", "fc_dist_m", "doc12k_binary",
               "doc12k_ternary", "doc12k_2bit", "doc12k_8bit"):
         assert ex[k]["verified_vs_oracle"] is True and ex[k]["value"] > 0 and "roofline" in ex[k], k
@@ -1603,7 +1636,7 @@ def test_evaluate_binding_and_latency_numbers(gpu_ok, orc, capsys):
     ctx.close()
 
 
-def test_bench_under_torchrun_single_rank(gpu_ok):
+def test_bench_under_torchrun_single_rank(gpu_ok, tmp_path):
     """The N>1 launch contract with one rank: torch.distributed.run -> RCCL process group, model broadcast, barriers,
     MAX-reduced time, all-reduced digest (the driver runs the same command with 2/4/8 ranks)."""
     import json
@@ -1614,29 +1647,35 @@ def test_bench_under_torchrun_single_rank(gpu_ok):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    full = str(tmp_path / "full.json")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(util.REPO, "bench.py"), "--gpus", "1", "--steps", "2",
-                          "--warmup", "1", "--images", "1000000", "--no-cpu", "--scaling", "strong"], capture_output=True, text=True,
+                          "--warmup", "1", "--images", "1000000", "--no-cpu", "--scaling", "strong", "--full-json", full], capture_output=True, text=True,
                          timeout=900, env=env)
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert lines, out.stderr[-2000:]
-    d = json.loads(lines[-1])
+    assert "{" in out.stdout, out.stderr[-2000:]
+    c = _check_bench_stdout(out.stdout)
+    assert c["config"]["rccl_ranks"] == 1 and c["config"]["dist_backend"] == "nccl" and c["scaling"] == "strong"
+    d = json.load(open(full))
     assert d["n_gpus"] == 1 and d["verified_vs_oracle"] is True and sum(d["class_histogram"]) == 1000000
     assert d["scaling"] == "strong" and d["config"]["global_images"] == 1000000 and "extra_configs" in d
     assert d["config"]["rccl_ranks"] == 1 and d["config"]["dist_backend"] == "nccl"
 
 
 def _bench_json(args, timeout=900):
+    """-> (the full record, the compact last line)"""
     import json
     import subprocess
     import sys
+    import tempfile
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(util.REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert lines, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
-    assert len(lines) == 1, "ONE JSON line, from rank 0"
-    return json.loads(lines[-1])
+    with tempfile.TemporaryDirectory() as td:
+        full = os.path.join(td, "full.json")
+        out = subprocess.run([sys.executable, os.path.join(util.REPO, "bench.py")] + args + ["--full-json", full], capture_output=True, text=True,
+                             timeout=timeout, env=env)
+        assert "{" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+        c = _check_bench_stdout(out.stdout)
+        return json.load(open(full)), c
 
 
 def test_bench_launches_its_own_ranks_two_ranks_share_the_gpu(gpu_ok):
@@ -1645,8 +1684,10 @@ def test_bench_launches_its_own_ranks_two_ranks_share_the_gpu(gpu_ok):
     blob broadcast from rank 0, barriers, MAX-reduced time - and the ALL-REDUCED digest of the two shards' class ids must be the
     oracle's digest of all 10^8 images."""
     n = int(os.environ.get("BNM_FULL_N", "100000000"))
-    d = _bench_json(["--gpus", "2", "--dist-backend", "gloo", "--ranks-share-device", "--scaling", "strong", "--images", str(n),
-                     "--steps", "3", "--warmup", "1", "--no-cpu"])
+    d, c = _bench_json(["--gpus", "2", "--dist-backend", "gloo", "--ranks-share-device", "--scaling", "strong", "--images", str(n),
+                        "--steps", "3", "--warmup", "1", "--no-cpu"])
+    assert c["n_gpus"] == 2 and c["config"]["ranks_share_device"] is True and len(c["per_rank_ms_per_step"]) == 2 and "rows" not in c
+    assert c["verified_vs_oracle"] is True and c["config"]["global_images"] == n
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_images"] == n
     assert d["config"]["images_per_gpu"] == n // 2 and d["config"]["dist_backend"] == "gloo" and d["config"]["ranks_share_device"] is True
     assert d["config"]["rccl_ranks"] is None and "extra_configs" not in d
