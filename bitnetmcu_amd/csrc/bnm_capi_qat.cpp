@@ -43,4 +43,39 @@ int bnm_qat_bitconv2d_forward_device(const float *d_x, uint64_t n, uint32_t cin,
     return BNM_OK;
 }
 
+uint64_t bnm_qat_model_workspace_bytes(uint32_t n_layers, const uint32_t *widths) {
+    if (!widths || n_layers < 2u || n_layers > (uint32_t)BNM_QAT_MODEL_MAX_LAYERS) return 0;
+    return bnmk_qat_model_workspace_bytes(n_layers, widths);
+}
+
+int bnm_qat_model_supported(uint32_t n_layers, const uint32_t *widths, const int *quant_types, int norm_type) {
+    if (!widths || !quant_types || n_layers < 2u || n_layers > (uint32_t)BNM_QAT_MODEL_MAX_LAYERS) return 0;
+    return bnmk_qat_model_supported(n_layers, widths, quant_types, norm_type) ? 1 : 0;
+}
+
+int bnm_qat_model_forward_device(const float *d_x, uint64_t n, uint32_t n_layers, const uint32_t *widths, const float *const *d_w,
+                                 const float *const *d_s, const uint32_t *s_count, const int *quant_types, int norm_type,
+                                 float *d_logits, float *d_hidden, float *const *d_w_deq, void *d_workspace, uint64_t workspace_bytes,
+                                 void *stream) {
+    if (!widths || !d_w || !d_s || !s_count || !quant_types || !d_workspace || (n && (!d_x || !d_logits))) return fail(BNM_EINVAL, "null pointer");
+    if (n_layers < 2u || n_layers > (uint32_t)BNM_QAT_MODEL_MAX_LAYERS) return fail(BNM_EINVAL, "need 2 <= n_layers <= BNM_QAT_MODEL_MAX_LAYERS");
+    for (uint32_t l = 0; l < n_layers; l++) {
+        if (!d_w[l] || !d_s[l]) return fail(BNM_EINVAL, "null weight or clipping-scalar pointer");
+        if (quant_types[l] < BNM_QAT_NONE || quant_types[l] > BNM_QAT_8BIT) return fail(BNM_EINVAL, "unknown quant_type");
+        if (widths[l + 1] == 0u) return fail(BNM_EINVAL, "zero width");
+        if (s_count[l] != 1u && s_count[l] != widths[l + 1]) return fail(BNM_EINVAL, "s_count must be 1 (PerTensor) or the layer's outputs (PerOutput)");
+    }
+    if (norm_type < BNM_QAT_NORM_RMS || norm_type > BNM_QAT_NORM_NONE) return fail(BNM_EINVAL, "unknown norm_type");
+    if (!bnmk_qat_model_supported(n_layers, widths, quant_types, norm_type))
+        return fail(BNM_EUNSUPPORTED, "the fused model forward serves 256 inputs, hidden widths <= 128, <= 64 classes, int8-level QuantTypes "
+                                      "and NormType RMS / Lin (bnm_qat_model_supported); run the layers with bnm_qat_bitlinear_forward_device");
+    if (workspace_bytes < bnmk_qat_model_workspace_bytes(n_layers, widths)) return fail(BNM_EINVAL, "workspace too small (bnm_qat_model_workspace_bytes)");
+    if (((uintptr_t)d_workspace & 15u) || ((uintptr_t)d_logits & 15u) || ((uintptr_t)d_x & 15u))
+        return fail(BNM_EINVAL, "d_x, d_logits and the workspace must be 16-byte aligned");
+    if (n >= (1ull << 36)) return fail(BNM_EINVAL, "n too large for one call");
+    HIP_TRY(bnmk_qat_model_forward(d_x, n, n_layers, widths, d_w, d_s, s_count, quant_types, norm_type, d_logits, d_hidden, d_w_deq,
+                                   d_workspace, (hipStream_t)stream));
+    return BNM_OK;
+}
+
 }  // extern "C"

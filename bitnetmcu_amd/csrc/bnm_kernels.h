@@ -207,6 +207,12 @@ hipError_t bnmk_qat_bitlinear_forward(const float *d_x, uint64_t n, uint32_t d, 
                                       float *d_workspace, float *d_x_int_out, float *d_x_scale_out, float *d_w_deq_out,
                                       hipStream_t s);
 // BitConv2d forward: any groups / stride, zero padding `pad`, PerTensor clipping scalar.
+// whole-model QAT forward (bnm_qat_model.hip): widths[0 .. n_layers]; workspace bnmk_qat_model_workspace_bytes (0: shape not served)
+size_t bnmk_qat_model_workspace_bytes(uint32_t n_layers, const uint32_t *widths);
+bool bnmk_qat_model_supported(uint32_t n_layers, const uint32_t *widths, const int *quant_types, int norm_type);
+hipError_t bnmk_qat_model_forward(const float *d_x, uint64_t n, uint32_t n_layers, const uint32_t *widths, const float *const *d_w,
+                                  const float *const *d_s, const uint32_t *s_count, const int *quant_types, int norm_type,
+                                  float *d_logits, float *d_hidden, float *const *d_w_deq, void *d_workspace, hipStream_t stream);
 // workspace: bnmk_qat_workspace_bytes((cin / groups) * kh * kw, cout) bytes; dynamic LDS: bnmk_qat_bitconv2d_lds_bytes (<= 160 KiB).
 size_t bnmk_qat_bitconv2d_lds_bytes(uint32_t cin, uint32_t h, uint32_t w, uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad,
                                     uint32_t groups);

@@ -82,6 +82,68 @@ def bitlinear_forward(x, w, s, quant_type, norm_type, return_int=False, return_w
     return (y,) + extra if extra else y
 
 
+def fc_model_supported(widths, quant_types, norm_type):
+    """True when the ONE-kernel whole-model forward serves this stack of BitLinear layers (bnm_qat_model_supported): 256 inputs,
+    hidden widths <= 128, <= 64 classes, QuantTypes whose levels are int8, NormType RMS or Lin."""
+    if any(q not in QUANT_TYPES for q in quant_types) or norm_type not in NORM_TYPES:
+        return False
+    nl = len(quant_types)
+    if len(widths) != nl + 1 or not 2 <= nl <= 4:
+        return False
+    wa = (C.c_uint32 * (nl + 1))(*widths)
+    qa = (C.c_int * nl)(*[QUANT_TYPES[q] for q in quant_types])
+    return L.load().bnm_qat_model_supported(nl, wa, qa, NORM_TYPES[norm_type]) == 1
+
+
+_model_workspaces = {}
+
+
+def fc_model_forward(x, weights, scalars, quant_types, norm_type, return_hidden=False, return_w_deq=False):
+    """The forward pass of a stack of BitLinear layers with ReLU between them (models.py:70-90 FCMNIST) in ONE kernel
+    (bnm_qat_model_forward_device, csrc/bnm_qat_model.hip) behind a weight-preparation launch.
+    x [n, 256] (or [n, 1, 16, 16]: flattened), weights [w_l [k_l, d_l]], scalars [s_l] (each a scalar tensor or [k_l] / [k_l, 1]),
+    quant_types [str] one per layer, all float32 CUDA tensors.  Returns logits [n, classes]; with return_hidden also the hidden
+    layers' outputs after ReLU as ONE tensor [n, sum of hidden widths] (layer after layer within a row); with return_w_deq also
+    the list of fake-quantised weights w_int / w_scale."""
+    if not x.is_cuda:
+        raise RuntimeError("fc_model_forward is a GPU op: x must be a CUDA tensor (there is no CPU path)")
+    lib = L.load()
+    nl = len(weights)
+    x2 = x.reshape(x.shape[0], -1).contiguous().float()
+    n, d = x2.shape
+    ws = [w.contiguous().float() for w in weights]
+    ss = [torch.as_tensor(s, dtype=torch.float32, device=x.device).reshape(-1).contiguous() for s in scalars]
+    widths = [d] + [w.shape[0] for w in ws]
+    for l, w in enumerate(ws):
+        if w.shape[1] != widths[l]:
+            raise ValueError(f"layer {l}: weight is {tuple(w.shape)}, its input has {widths[l]} values")
+    if not fc_model_supported(widths, quant_types, norm_type):
+        raise NotImplementedError(f"fc_model_forward: widths {widths} / QuantTypes {list(quant_types)} / NormType {norm_type} are not served by the "
+                                  "fused kernel (fc_model_supported); run the layers with bitlinear_forward")
+    wa = (C.c_uint32 * (nl + 1))(*widths)
+    qa = (C.c_int * nl)(*[QUANT_TYPES[q] for q in quant_types])
+    sc = (C.c_uint32 * nl)(*[s.numel() for s in ss])
+    wp = (C.c_void_p * nl)(*[w.data_ptr() for w in ws])
+    sp = (C.c_void_p * nl)(*[s.data_ptr() for s in ss])
+    logits = torch.empty((n, widths[-1]), dtype=torch.float32, device=x.device)
+    hidden = torch.empty((n, sum(widths[1:-1])), dtype=torch.float32, device=x.device) if return_hidden else None
+    wdq = [torch.empty_like(w) for w in ws] if return_w_deq else None
+    dq = (C.c_void_p * nl)(*[t.data_ptr() for t in wdq]) if return_w_deq else None
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        key = (x.device.index, stream, tuple(widths))
+        wsp = _model_workspaces.get(key)
+        if wsp is None:
+            wsp = torch.empty((int(lib.bnm_qat_model_workspace_bytes(nl, wa)) + 3) // 4, dtype=torch.float32, device=x.device)
+            _model_workspaces[key] = wsp
+        L.check(lib, lib.bnm_qat_model_forward_device(
+            C.c_void_p(x2.data_ptr()), n, nl, wa, wp, sp, sc, qa, NORM_TYPES[norm_type], C.c_void_p(logits.data_ptr()),
+            C.c_void_p(hidden.data_ptr()) if return_hidden else None, dq, C.c_void_p(wsp.data_ptr()), wsp.numel() * 4,
+            C.c_void_p(stream)), "bnm_qat_model_forward_device")
+    out = (logits,) + ((hidden,) if return_hidden else ()) + ((wdq,) if return_w_deq else ())
+    return out if len(out) > 1 else logits
+
+
 def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
@@ -365,3 +427,95 @@ class BitConv2d(nn.Conv2d):
 
     octav = BitLinear.octav
     update_clipping_scalar = BitLinear.update_clipping_scalar
+
+
+def fc_model_reference(x, weights, scalars, quant_types, norm_type):
+    """models.py:70-90 FCMNIST.forward as the restated differentiable PyTorch ops (`ste_formula` layer after layer, ReLU between):
+    -> (logits, hidden [n, sum of hidden widths]).  What tests pin against the reference module and what the fused op's backward
+    differentiates."""
+    h = x.reshape(x.shape[0], -1)
+    hidden = []
+    for l, (w, s, qt) in enumerate(zip(weights, scalars, quant_types)):
+        h = ste_formula(h, w, s, qt, norm_type)
+        if l + 1 < len(weights):
+            h = F.relu(h)
+            hidden.append(h)
+    return h, torch.cat(hidden, dim=1)
+
+
+def fc_model_backward(x, hidden, w_deq, gy, norm_type, outs):
+    """Gradients of the whole-model forward from what the fused op saved: x, the hidden layers' outputs after ReLU (one tensor,
+    layer after layer within a row) and w_int / w_scale per layer.  Per layer, last to first: activation_quant of the saved layer
+    input by the restated formula, the straight-through gradients (`ste_backward`), ReLU's mask.  -> (gx, [gw per layer])"""
+    n_layers = len(w_deq)
+    x2 = x.reshape(x.shape[0], -1)
+    offs = [0]
+    for k in outs[:-1]:
+        offs.append(offs[-1] + k)
+    gws = [None] * n_layers
+    g, gx = gy, None
+    for l in range(n_layers - 1, -1, -1):
+        xin = x2 if l == 0 else hidden[:, offs[l - 1]:offs[l]]
+        xi, xs = activation_quant(normalize(xin, norm_type))
+        gx, gws[l] = ste_backward(xin, g, norm_type, xi / xs, w_deq[l])
+        if l > 0:
+            g = gx * (xin > 0).to(gx.dtype)
+    return gx.reshape(x.shape), gws
+
+
+class _FCModelFn(torch.autograd.Function):
+    """Forward: the ONE-kernel whole-model op, which also writes what a backward pass needs (every hidden layer's output after ReLU
+    = the next layer's input, and w_int / w_scale per layer).  Backward: per layer, last to first, the straight-through gradients
+    (`ste_backward`: two library GEMMs + Normalize's own backward through autograd) with activation_quant of the saved layer input
+    recomputed by the restated formula, and ReLU's mask from the saved outputs.  No hand-written backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, norm_type, quant_types, n_layers, *ws):
+        weights, scalars = ws[:n_layers], ws[n_layers:]
+        logits, hidden, wdq = fc_model_forward(x, weights, scalars, quant_types, norm_type, return_hidden=True, return_w_deq=True)
+        ctx.save_for_backward(x, hidden, *wdq)
+        ctx.cfg = (norm_type, n_layers, [w.shape[0] for w in weights])
+        return logits
+
+    @staticmethod
+    def backward(ctx, gy):
+        norm_type, n_layers, outs = ctx.cfg
+        x, hidden = ctx.saved_tensors[:2]
+        gx, gws = fc_model_backward(x, hidden, ctx.saved_tensors[2:], gy, norm_type, outs)
+        return (gx, None, None, None) + tuple(gws) + (None,) * n_layers
+
+
+class FCMNIST(nn.Module):
+    """Stand-in for the reference's FCMNIST (models.py:56-90): same constructor, same module / parameter names (`model.1`, `model.3`,
+    `model.fc3`, `classifier`), so the reference's checkpoints load.  On CUDA inputs the whole forward pass is ONE kernel
+    (`fc_model_forward`) when the fused op serves the configuration, else layer by layer through `BitLinear`'s fused op."""
+
+    def __init__(self, network_width1=64, network_width2=64, network_width3=64, QuantType="Binary", WScale="PerTensor", NormType="RMS",
+                 num_classes: int = 10):
+        super().__init__()
+        self.network_width1, self.network_width2, self.network_width3 = network_width1, network_width2, network_width3
+        self.model = nn.Sequential(
+            nn.Flatten(),
+            BitLinear(1 * 16 * 16, network_width1, QuantType=QuantType, NormType=NormType, WScale=WScale),
+            nn.ReLU(),
+            BitLinear(network_width1, network_width2, QuantType=QuantType, NormType=NormType, WScale=WScale),
+            nn.ReLU())
+        if network_width3 > 0:
+            self.model.add_module("fc3", BitLinear(network_width2, network_width3, QuantType=QuantType, NormType=NormType, WScale=WScale))
+            self.model.add_module("relu_fc2", nn.ReLU())
+        last_width = network_width3 if network_width3 > 0 else network_width2
+        self.classifier = BitLinear(last_width, num_classes, QuantType=QuantType, NormType=NormType, WScale=WScale)
+
+    def bitlinear_layers(self):
+        return [m for m in self.model if isinstance(m, BitLinear)] + [self.classifier]
+
+    def fused(self, x):
+        """True when forward(x) runs the one-kernel op."""
+        ls = self.bitlinear_layers()
+        return x.is_cuda and fc_model_supported([ls[0].in_features] + [m.out_features for m in ls], [m.QuantType for m in ls], ls[0].NormType)
+
+    def forward(self, x):
+        if not self.fused(x):
+            return self.classifier(self.model(x))
+        ls = self.bitlinear_layers()
+        return _FCModelFn.apply(x, ls[0].NormType, [m.QuantType for m in ls], len(ls), *[m.weight for m in ls], *[m.s for m in ls])

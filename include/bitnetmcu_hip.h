@@ -307,6 +307,30 @@ BNM_API int bnm_qat_bitconv2d_forward_device(const float *d_x, uint64_t n, uint3
                                              uint32_t stride, uint32_t groups, const float *d_s, int quant_type, int norm_type,
                                              float *d_y, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
+/* Whole-model QAT forward (models.py:56-90 FCMNIST; the FC stack of CNNMNIST, :120-135): n_layers BitLinear layers
+ * (BitNetMCU.py:214-235, bias-free) with ReLU between them, ONE kernel per call behind a per-call weight preparation launch:
+ *   widths[0] = 256 inputs (the 16x16 image, or CNNMNIST's 64 channels x 4), widths[1 .. n_layers-1] the hidden widths
+ *   (each <= 128), widths[n_layers] the classes (<= 64); 2 <= n_layers <= BNM_QAT_MODEL_MAX_LAYERS.
+ *   d_w[l] [widths[l+1]][widths[l]] float32, d_s[l] the layer's clipping scalar(s), s_count[l] 1 (PerTensor) or widths[l+1]
+ *   (PerOutput), quant_types[l] the layer's QuantType - d_w / d_s / s_count / quant_types / widths are HOST arrays (of device
+ *   pointers where they hold pointers).
+ *   quant_types: those whose levels (x 2 for the half-integer types) are int8 - Binary, BinarySym, Ternary, 2bitsym, 4bitsym,
+ *   5bitsym, 8bit; norm_type: BNM_QAT_NORM_RMS or BNM_QAT_NORM_LIN (BatchNorm needs the whole batch per layer).  Anything else:
+ *   BNM_EUNSUPPORTED (bnm_qat_model_supported tells beforehand) - run the layers one by one with bnm_qat_bitlinear_forward_device.
+ *   d_x [n][256] float32 in, d_logits [n][classes] float32 out (16-byte aligned).  Optional: d_hidden [n][sum of the hidden widths]
+ *   - every hidden layer's output after ReLU, i.e. the next layer's input, layer after layer within a row - and d_w_deq[l]
+ *   [widths[l+1]][widths[l]] = w_int / w_scale: together with d_x what a straight-through backward pass needs.
+ *   workspace: bnm_qat_model_workspace_bytes(n_layers, widths) bytes, 16-byte aligned, owned by the call's stream while it runs.
+ * Floating point: within the tolerances of tests/test_gpu_qat_model.py of the reference module, not bit-exact.  A row whose input
+ * to some layer is all zero gets NaN logits, as in the reference (0 / 0 in Normalize). */
+#define BNM_QAT_MODEL_MAX_LAYERS 4
+BNM_API uint64_t bnm_qat_model_workspace_bytes(uint32_t n_layers, const uint32_t *widths);
+BNM_API int bnm_qat_model_supported(uint32_t n_layers, const uint32_t *widths, const int *quant_types, int norm_type);
+BNM_API int bnm_qat_model_forward_device(const float *d_x, uint64_t n, uint32_t n_layers, const uint32_t *widths,
+                                         const float *const *d_w, const float *const *d_s, const uint32_t *s_count,
+                                         const int *quant_types, int norm_type, float *d_logits, float *d_hidden,
+                                         float *const *d_w_deq, void *d_workspace, uint64_t workspace_bytes, void *stream);
+
 /* ---- synthetic workload + digests ---------------------------------------- */
 #define BNM_DIST_U 0
 #define BNM_DIST_M 1

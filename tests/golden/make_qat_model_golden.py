@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Golden vectors for the whole-model QAT forward, generated HERE by importing the
+reference's own FCMNIST (/root/reference/models.py:56-90 over BitNetMCU.py's BitLinear, CPU PyTorch) - the reference cannot
+travel to the GPU box, the vectors can.
+
+  python tests/golden/make_qat_model_golden.py      -> tests/golden/qat_fc_model.npz
+
+Per configuration: the inputs, every layer's weights / clipping scalars / weight levels and scale, the reference's logits and
+every hidden layer's output after ReLU; for configuration "a" also the gradients of all weights and of the input.
+Inputs look like the reference's training images (transforms.Normalize((0.1307,), (0.3081,)) of [0, 1] pixels: background
+-0.4242) plus a tiny row, a huge row and an ALL-ZERO row (the reference's Normalize divides 0 / 0: its logits are NaN).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+# tag: (width1, width2, width3, QuantType, WScale, NormType, classes, rows, clipping algorithm)
+CONFIGS = {
+    "a": (64, 64, 64, "4bitsym", "PerTensor", "RMS", 10, 333, "octav"),       # the reference's headline FC model
+    "b": (96, 64, 0, "4bitsym", "PerTensor", "RMS", 10, 70, "octav"),         # trainingparameters.yaml's widths: three layers
+    "c": (96, 96, 96, "Ternary", "PerTensor", "Lin", 10, 45, "octav"),
+    "d": (128, 128, 128, "8bit", "PerTensor", "RMS", 47, 97, "octav"),        # four tiles per layer, two class tiles (EMNIST balanced)
+    "e": (80, 40, 72, "2bitsym", "PerOutput", "RMS", 10, 41, "prop"),         # widths off the 32-row tiles, per-output clipping scalars
+    "f": (64, 64, 64, "Binary", "PerTensor", "RMS", 10, 33, "octav"),
+}
+ZERO_ROW = 5
+
+
+def images(n, gen):
+    x = torch.full((n, 256), -0.4242)
+    on = torch.rand(n, 256, generator=gen) < 0.25
+    x[on] = (torch.rand(int(on.sum()), generator=gen) * 3.2 - 0.4)
+    x[1] *= 1e-3
+    x[2] *= 1e3
+    x[ZERO_ROW] = 0.0
+    return x
+
+
+def main():
+    sys.path.insert(0, REF)
+    import models as ref          # the reference module, unmodified
+    out = {}
+    for tag, (w1, w2, w3, qt, wscale, nt, ncls, n, algo) in CONFIGS.items():
+        torch.manual_seed(20240324 + ord(tag))
+        gen = torch.Generator().manual_seed(7 + ord(tag))
+        model = ref.FCMNIST(w1, w2, w3, QuantType=qt, WScale=wscale, NormType=nt, num_classes=ncls)
+        layers = [m for m in model.model if hasattr(m, "weight_quant")] + [model.classifier]
+        for m in layers:
+            m.update_clipping_scalar(m.weight.data, algo, 0.25)          # as training.py does before the first epoch
+        x = images(n, gen)
+        xr = x.clone().requires_grad_(True)
+        hidden = []
+        hooks = [m.register_forward_hook(lambda mod, i, o: hidden.append(o.detach().numpy().copy()))
+                 for m in model.model if isinstance(m, torch.nn.ReLU)]
+        logits = model(xr.reshape(n, 1, 16, 16))
+        [h.remove() for h in hooks]
+        out[f"{tag}/x"] = x.numpy()
+        out[f"{tag}/logits"] = logits.detach().numpy()
+        out[f"{tag}/hidden"] = np.concatenate(hidden, axis=1)
+        out[f"{tag}/cfg"] = np.array([w1, w2, w3, ncls], dtype=np.int64)
+        for l, m in enumerate(layers):
+            u, wsc, _ = m.weight_quant(m.weight.data)
+            out[f"{tag}/w{l}"] = m.weight.detach().numpy()
+            out[f"{tag}/s{l}"] = m.s.detach().numpy().reshape(-1).astype(np.float32)
+            out[f"{tag}/w_int{l}"] = u.numpy()
+            out[f"{tag}/w_scale{l}"] = np.asarray(torch.as_tensor(wsc).detach().numpy(), dtype=np.float32).reshape(-1)
+        if tag == "a":
+            # gradients over the rows without the all-zero one (its NaNs would poison every gradient): a second forward pass
+            keep = torch.ones(n, dtype=torch.bool)
+            keep[ZERO_ROW] = False
+            gy = torch.randn(n - 1, ncls, generator=gen)
+            xg = x[keep].clone().requires_grad_(True)
+            loss = (model(xg.reshape(n - 1, 1, 16, 16)) * gy).sum()
+            grads = torch.autograd.grad(loss, [xg] + [m.weight for m in layers])
+            out[f"{tag}/gy"] = gy.numpy()
+            out[f"{tag}/gx"] = grads[0].numpy()
+            for l, g in enumerate(grads[1:]):
+                out[f"{tag}/gw{l}"] = g.numpy()
+    path = os.path.join(HERE, "qat_fc_model.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes;", {t: (out[f"{t}/logits"].shape, bool(np.isnan(out[f"{t}/logits"][ZERO_ROW]).all())) for t in CONFIGS})
+
+
+if __name__ == "__main__":
+    main()

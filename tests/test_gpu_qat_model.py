@@ -1,0 +1,196 @@
+"""Whole-model QAT forward on the GPU: csrc/bnm_qat_model.hip through the C ABI against
+fixtures generated from the reference's own FCMNIST module (tests/golden/make_qat_model_golden.py).
+
+This is a FLOATING-POINT kernel, so parity is within tolerance, and the tolerances are:
+  * w_int / w_scale per layer: equal to the reference's, except at most 0.2 % of the weights where the value being rounded lies at a
+    rounding tie (an ulp of the scale);
+  * LAYER BY LAYER, each layer fed with the KERNEL'S OWN input of that layer (so that one flipped activation step cannot cascade):
+    the layer's outputs equal a float64 evaluation of the reference's formula - Normalize, activation_quant, the exact integer
+    product, / x_scale / w_scale, ReLU - within 2e-5 of the row's largest output, on every row whose quantised activations sit more
+    than 2e-3 away from a rounding tie (at least 90 % of the rows), and within one activation step of one input (3e-2) on the rest;
+  * END TO END against the reference module's float32 logits and hidden activations: at least 90 % of the rows within 5e-4 of the
+    row's largest value, every row within 6e-2 (a flipped activation step somewhere in four layers);
+  * the all-zero row: NaN logits, as the reference's 0 / 0 produces;
+  * gradients through the module: 2e-3 relative to the largest gradient entry.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bitnetmcu_amd as b
+from bitnetmcu_amd import qat
+from util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+GM = np.load(os.path.join(GOLDEN, "qat_fc_model.npz"))
+CONFIGS = {"a": ("4bitsym", "RMS"), "b": ("4bitsym", "RMS"), "c": ("Ternary", "Lin"), "d": ("8bit", "RMS"), "e": ("2bitsym", "RMS"),
+           "f": ("Binary", "RMS")}
+ZERO_ROW = 5
+TIE = 2e-3
+
+
+def case(tag):
+    w1, w2, w3, ncls = (int(v) for v in GM[f"{tag}/cfg"])
+    nl = 4 if w3 else 3
+    ws = [torch.from_numpy(GM[f"{tag}/w{l}"]).cuda() for l in range(nl)]
+    ss = [torch.from_numpy(GM[f"{tag}/s{l}"]).cuda() for l in range(nl)]
+    widths = [256, w1, w2] + ([w3] if w3 else []) + [ncls]
+    return torch.from_numpy(GM[f"{tag}/x"]).cuda(), ws, ss, widths
+
+
+def layer_f64(xin, w_q_levels, w_scale, nt):
+    """One BitLinear layer in float64 from a float32 input, the reference's formula with float32 rounding where the reference rounds
+    (Normalize's quotient, the scale, the product that is rounded to an integer) -> (y, distance of every product from a tie)."""
+    x = xin.astype(np.float32)
+    if nt == "RMS":
+        den = np.sqrt(np.mean(x.astype(np.float64) ** 2, axis=1, keepdims=True)).astype(np.float32)
+    else:
+        den = np.mean(np.abs(x.astype(np.float64)), axis=1, keepdims=True).astype(np.float32)
+    with np.errstate(all="ignore"):
+        xn = (x / den).astype(np.float32)
+        scale = (np.float32(127.0) / np.maximum(np.abs(xn).max(axis=1, keepdims=True), np.float32(1e-5))).astype(np.float32)
+        p = (xn * scale).astype(np.float32).astype(np.float64)
+        xi = np.clip(np.rint(p), -128, 127)
+        tie = np.abs(np.abs(p - np.floor(p)) - 0.5)
+        y = (xi @ w_q_levels.T.astype(np.float64)) / scale.astype(np.float64) / w_scale.astype(np.float64)[None, :]
+    return y, tie
+
+
+def check(tag, n_rows=None):
+    qt, nt = CONFIGS[tag]
+    x, ws, ss, widths = case(tag)
+    if n_rows is not None:
+        x = x[:n_rows]
+    n = x.shape[0]
+    nl = len(ws)
+    assert qat.fc_model_supported(widths, [qt] * nl, nt)
+    logits, hidden, wdq = qat.fc_model_forward(x.reshape(n, 1, 16, 16), ws, ss, [qt] * nl, nt, return_hidden=True, return_w_deq=True)
+    plain = qat.fc_model_forward(x, ws, ss, [qt] * nl, nt)          # without the optional outputs: the same logits
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(plain, nan=-7.0), torch.nan_to_num(logits, nan=-7.0))
+    logits, hidden = logits.cpu().numpy(), hidden.cpu().numpy()
+    rows = np.ones(n, bool)
+    if n > ZERO_ROW:
+        rows[ZERO_ROW] = False
+        assert np.isnan(logits[ZERO_ROW]).all(), tag
+    assert not np.isnan(logits[rows]).any() and not np.isnan(hidden[rows]).any(), tag
+    # ---- weights ----
+    levels, wscales = [], []
+    for l in range(nl):
+        ref_u, ref_sc = GM[f"{tag}/w_int{l}"].astype(np.float64), GM[f"{tag}/w_scale{l}"].astype(np.float64)
+        sc = ref_sc if ref_sc.size > 1 else np.full(ref_u.shape[0], ref_sc[0])
+        got = wdq[l].cpu().numpy().astype(np.float64) * sc[:, None]
+        bad = np.abs(got - ref_u) > 1e-4
+        assert bad.mean() <= 2e-3, (tag, l, bad.mean())
+        levels.append(np.where(bad, np.round(got * 2) / 2, ref_u))      # the kernel's own levels where a tie flipped
+        wscales.append(sc)
+    # ---- layer by layer on the kernel's own inputs ----
+    offs = np.concatenate([[0], np.cumsum(widths[1:-1])])
+    xin = x.cpu().numpy()
+    for l in range(nl):
+        y, tie = layer_f64(xin, levels[l], wscales[l], nt)
+        last = l == nl - 1
+        got = logits if last else hidden[:, offs[l]:offs[l + 1]]
+        want = y if last else np.maximum(y, 0.0)
+        err = np.abs(got - want)[rows].max(axis=1) / np.maximum(np.abs(want)[rows].max(axis=1), 1e-30)
+        clean = (tie[rows] > TIE).all(axis=1)
+        assert clean.mean() >= 0.9 or n < 40, (tag, l, clean.mean())
+        assert (err[clean] <= 2e-5).all(), (tag, l, err[clean].max())
+        assert (err <= 3e-2).all(), (tag, l, err.max())
+        xin = got
+    # ---- end to end against the reference module ----
+    for got, ref in ((logits, GM[f"{tag}/logits"][:n]), (hidden, GM[f"{tag}/hidden"][:n])):
+        scale = np.maximum(np.abs(ref[rows]).max(axis=1), 1e-30)
+        err = np.abs(got - ref)[rows].max(axis=1) / scale
+        assert (err <= 5e-4).mean() >= 0.9 and err.max() <= 6e-2, (tag, (err <= 5e-4).mean(), err.max())
+
+
+@pytest.mark.parametrize("tag", sorted(CONFIGS))
+def test_whole_model_forward_against_the_reference_module(tag, gpu_ok):
+    check(tag)
+
+
+def test_batch_sizes_ragged_tiles_and_empty(gpu_ok):
+    """n = 0, 1, one row short of a tile, a tile, a tile + 1, and a batch that leaves some waves without work."""
+    for n in (1, 31, 32, 33, 200):
+        check("a", n)
+    x, ws, ss, widths = case("a")
+    out = qat.fc_model_forward(x[:0], ws, ss, ["4bitsym"] * 4, "RMS")
+    assert out.shape == (0, 10)
+
+
+def test_large_batch_rows_do_not_depend_on_the_batch(gpu_ok):
+    """300,000 rows (more tiles than the launch has waves: the work counter hands them out): every row's logits equal the logits
+    the same row gets in a 64-row batch, bit for bit - rows are independent and the arithmetic per row is fixed."""
+    x, ws, ss, widths = case("a")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    big = torch.randn(300_000, 256, device="cuda", generator=g) * (torch.rand(300_000, 1, device="cuda", generator=g) * 2 + 0.01)
+    full = qat.fc_model_forward(big, ws, ss, ["4bitsym"] * 4, "RMS")
+    for first in (0, 12_345, 299_936):
+        part = qat.fc_model_forward(big[first:first + 64].clone(), ws, ss, ["4bitsym"] * 4, "RMS")
+        assert torch.equal(part, full[first:first + 64]), first
+    # ... and equal the restated formula (torch's own GPU kernels as the fp32 reference) on nearly every row
+    want, _ = qat.fc_model_reference(big[:20_000], ws, [s[0] for s in ss], ["4bitsym"] * 4, "RMS")
+    err = (full[:20_000] - want).abs().max(dim=1).values / want.abs().max(dim=1).values
+    assert (err <= 5e-4).float().mean() >= 0.9 and err.max() <= 6e-2
+
+
+def test_unsupported_configurations_are_refused_not_emulated(gpu_ok):
+    x, ws, ss, widths = case("a")
+    assert not qat.fc_model_supported(widths, ["4bit"] * 4, "RMS")              # levels carry + 0.01: not int8
+    assert not qat.fc_model_supported(widths, ["FP130"] * 4, "RMS")             # + 128 does not fit int8
+    assert not qat.fc_model_supported(widths, ["4bitsym"] * 4, "BatchNorm")     # needs the whole batch per layer
+    assert not qat.fc_model_supported([256, 200, 64, 64, 10], ["4bitsym"] * 4, "RMS")
+    assert not qat.fc_model_supported([128, 64, 64, 64, 10], ["4bitsym"] * 4, "RMS")
+    with pytest.raises(NotImplementedError):
+        qat.fc_model_forward(x, ws, ss, ["NF4"] * 4, "RMS")
+    lib = b.load()      # return codes: include/bitnetmcu_hip.h BNM_OK 0, BNM_EINVAL -1, BNM_EUNSUPPORTED -3
+    import ctypes as C
+    wa = (C.c_uint32 * 5)(*widths)
+    assert lib.bnm_qat_model_workspace_bytes(4, wa) > 0 and lib.bnm_qat_model_workspace_bytes(5, wa) == 0
+    qa = (C.c_int * 4)(6, 6, 6, 6)
+    sc = (C.c_uint32 * 4)(1, 1, 1, 1)
+    wp = (C.c_void_p * 4)(*[w.data_ptr() for w in ws])
+    sp = (C.c_void_p * 4)(*[s.data_ptr() for s in ss])
+    y = torch.empty((x.shape[0], 10), device="cuda")
+    wsp = torch.empty(1 << 16, device="cuda")
+    args = lambda **k: [C.c_void_p(x.data_ptr()), x.shape[0], 4, wa, wp, sp, sc, qa, k.get("nt", 0), C.c_void_p(k.get("y", y.data_ptr())), None, None,
+                        C.c_void_p(wsp.data_ptr()), k.get("wsb", wsp.numel() * 4), None]
+    assert lib.bnm_qat_model_forward_device(*args()) == 0
+    assert lib.bnm_qat_model_forward_device(*args(wsb=64)) == -1              # workspace too small
+    assert lib.bnm_qat_model_forward_device(*args(y=y.data_ptr() + 4)) == -1  # logits not 16-byte aligned
+    assert lib.bnm_qat_model_forward_device(*args(nt=2)) == -3          # BatchNorm
+    torch.cuda.synchronize()
+
+
+def test_fcmnist_module_forward_backward(gpu_ok):
+    """qat.FCMNIST (the reference module's mirror) with the reference's weights: forward = the one-kernel op; backward from the
+    tensors it saved equals the reference's autograd gradients."""
+    x, ws, ss, widths = case("a")
+    m = qat.FCMNIST(64, 64, 64, QuantType="4bitsym", NormType="RMS", WScale="PerTensor").cuda()
+    layers = m.bitlinear_layers()
+    with torch.no_grad():
+        for l, layer in enumerate(layers):
+            layer.weight.copy_(ws[l])
+            layer.s = torch.nn.Parameter(ss[l].reshape(()).clone(), requires_grad=False)
+    keep = torch.ones(x.shape[0], dtype=torch.bool, device="cuda")
+    keep[ZERO_ROW] = False
+    xk = x[keep].reshape(-1, 1, 16, 16).clone().requires_grad_(True)
+    assert m.fused(xk)
+    y = m(xk)
+    (y * torch.from_numpy(GM["a/gy"]).cuda()).sum().backward()
+    ref = GM["a/logits"][keep.cpu().numpy()]
+    err = np.abs(y.detach().cpu().numpy() - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    assert (err <= 5e-4).mean() >= 0.9 and err.max() <= 6e-2
+    gx = xk.grad.reshape(-1, 256).cpu().numpy()
+    assert np.abs(gx - GM["a/gx"]).max() <= 2e-2 * np.abs(GM["a/gx"]).max()       # (a flipped step moves one row's gradient)
+    rows_ok = np.abs(gx - GM["a/gx"]).max(axis=1) <= 2e-3 * np.abs(GM["a/gx"]).max()
+    assert rows_ok.mean() >= 0.9
+    for l, layer in enumerate(layers):
+        ref_g = GM[f"a/gw{l}"]
+        assert np.abs(layer.weight.grad.cpu().numpy() - ref_g).max() <= 2e-3 * np.abs(ref_g).max(), l
+    # a configuration the fused op does not serve runs layer by layer through BitLinear's op - same module, same result shape
+    m2 = qat.FCMNIST(64, 64, 64, QuantType="4bitsym", NormType="BatchNorm").cuda()
+    assert not m2.fused(xk) and m2(xk.detach()).shape == (x.shape[0] - 1, 10)

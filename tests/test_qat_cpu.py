@@ -140,3 +140,64 @@ def test_backward_from_quantised_operands_equals_reference_gradients(qt, nt):
     ref_gx, ref_gw = t(f"a/{qt}/{nt}/gx"), t(f"a/{qt}/{nt}/gw")
     assert (gx - ref_gx).abs().max() <= 1e-5 * ref_gx.abs().max()
     assert (gw - ref_gw).abs().max() <= 1e-5 * ref_gw.abs().max()
+
+
+# ---- whole model (models.py:56-90 FCMNIST): fixtures from the reference module itself (tests/golden/make_qat_model_golden.py) ----
+GM = np.load(os.path.join(GOLDEN, "qat_fc_model.npz"))
+MODEL_CONFIGS = {"a": ("4bitsym", "RMS"), "b": ("4bitsym", "RMS"), "c": ("Ternary", "Lin"), "d": ("8bit", "RMS"), "e": ("2bitsym", "RMS"),
+                 "f": ("Binary", "RMS")}
+
+
+def model_case(tag):
+    w1, w2, w3, ncls = (int(v) for v in GM[f"{tag}/cfg"])
+    nl = 4 if w3 else 3
+    ws = [torch.from_numpy(GM[f"{tag}/w{l}"]) for l in range(nl)]
+    ss = [torch.from_numpy(GM[f"{tag}/s{l}"]) for l in range(nl)]
+    ss = [s[0] if s.numel() == 1 else s for s in ss]
+    return torch.from_numpy(GM[f"{tag}/x"]), ws, ss, (w1, w2, w3, ncls)
+
+
+@pytest.mark.parametrize("tag", sorted(MODEL_CONFIGS))
+def test_whole_model_formula_equals_the_reference_module(tag):
+    """qat.fc_model_reference (what the fused op's backward differentiates) == the reference's FCMNIST.forward, bit for bit on CPU
+    PyTorch: logits, every hidden layer's output, NaN logits for the all-zero row."""
+    qt, nt = MODEL_CONFIGS[tag]
+    x, ws, ss, _ = model_case(tag)
+    logits, hidden = qat.fc_model_reference(x, ws, ss, [qt] * len(ws), nt)
+    ref_logits, ref_hidden = GM[f"{tag}/logits"], GM[f"{tag}/hidden"]
+    assert np.isnan(ref_logits[5]).all() and not np.isnan(np.delete(ref_logits, 5, axis=0)).any()
+    assert np.array_equal(logits.numpy(), ref_logits, equal_nan=True)
+    assert np.array_equal(hidden.numpy(), ref_hidden, equal_nan=True)
+    for l, w in enumerate(ws):
+        u, sc = qat.weight_quant(w, ss[l].reshape(-1, 1) if ss[l].numel() > 1 else ss[l], qt)
+        assert torch.equal(u, torch.from_numpy(GM[f"{tag}/w_int{l}"]))
+        assert torch.equal(torch.as_tensor(sc).reshape(-1), torch.from_numpy(GM[f"{tag}/w_scale{l}"]))
+
+
+def test_whole_model_backward_from_saved_tensors_equals_reference_gradients():
+    """The fused op's backward never re-runs the forward: it works from x, the saved hidden activations and w_int / w_scale.  Fed
+    with the reference's own hidden activations it must reproduce the reference's autograd gradients (fp32 GEMM rounding apart)."""
+    x, ws, ss, (w1, w2, w3, ncls) = model_case("a")
+    keep = np.ones(len(x), bool)
+    keep[5] = False
+    xk = x[keep]
+    hidden = torch.from_numpy(GM["a/hidden"][keep])
+    wdq = [torch.from_numpy(GM[f"a/w_int{l}"]) / float(GM[f"a/w_scale{l}"][0]) for l in range(4)]
+    gx, gws = qat.fc_model_backward(xk, hidden, wdq, torch.from_numpy(GM["a/gy"]), "RMS", [w1, w2, w3, ncls])
+    assert (gx - torch.from_numpy(GM["a/gx"])).abs().max() <= 1e-4 * np.abs(GM["a/gx"]).max()
+    for l in range(4):
+        ref = torch.from_numpy(GM[f"a/gw{l}"])
+        assert (gws[l] - ref).abs().max() <= 1e-4 * ref.abs().max(), l
+
+
+def test_fcmnist_module_mirrors_the_reference_module():
+    """Same constructor, same parameter names as models.py's FCMNIST (a reference checkpoint's state_dict loads); CPU tensors refused."""
+    m = qat.FCMNIST(96, 64, 0, QuantType="4bitsym", NormType="RMS", WScale="PerTensor", num_classes=47)
+    assert sorted(m.state_dict()) == ["classifier.s", "classifier.weight", "model.1.s", "model.1.weight", "model.3.s", "model.3.weight"]
+    m4 = qat.FCMNIST(64, 64, 64, QuantType="Ternary")
+    assert sorted(k for k in m4.state_dict() if k.endswith("weight")) == ["classifier.weight", "model.1.weight", "model.3.weight", "model.fc3.weight"]
+    assert [l.out_features for l in m4.bitlinear_layers()] == [64, 64, 64, 10] and m.classifier.out_features == 47
+    with pytest.raises(RuntimeError, match="GPU op"):
+        m(torch.randn(3, 1, 16, 16))
+    with pytest.raises(RuntimeError, match="GPU op"):
+        qat.fc_model_forward(torch.randn(3, 256), [torch.randn(8, 256), torch.randn(4, 8)], [torch.ones(1)] * 2, ["8bit"] * 2, "RMS")
