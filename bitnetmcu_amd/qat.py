@@ -109,7 +109,7 @@ def fc_model_forward(x, weights, scalars, quant_types, norm_type, return_hidden=
         raise RuntimeError("fc_model_forward is a GPU op: x must be a CUDA tensor (there is no CPU path)")
     lib = L.load()
     nl = len(weights)
-    x2 = x.reshape(x.shape[0], -1).contiguous().float()
+    x2 = x.flatten(1).contiguous().float()
     n, d = x2.shape
     ws = [w.contiguous().float() for w in weights]
     ss = [torch.as_tensor(s, dtype=torch.float32, device=x.device).reshape(-1).contiguous() for s in scalars]
@@ -433,7 +433,7 @@ def fc_model_reference(x, weights, scalars, quant_types, norm_type):
     """models.py:70-90 FCMNIST.forward as the restated differentiable PyTorch ops (`ste_formula` layer after layer, ReLU between):
     -> (logits, hidden [n, sum of hidden widths]).  What tests pin against the reference module and what the fused op's backward
     differentiates."""
-    h = x.reshape(x.shape[0], -1)
+    h = x.flatten(1)
     hidden = []
     for l, (w, s, qt) in enumerate(zip(weights, scalars, quant_types)):
         h = ste_formula(h, w, s, qt, norm_type)
@@ -448,7 +448,7 @@ def fc_model_backward(x, hidden, w_deq, gy, norm_type, outs):
     layer after layer within a row) and w_int / w_scale per layer.  Per layer, last to first: activation_quant of the saved layer
     input by the restated formula, the straight-through gradients (`ste_backward`), ReLU's mask.  -> (gx, [gw per layer])"""
     n_layers = len(w_deq)
-    x2 = x.reshape(x.shape[0], -1)
+    x2 = x.flatten(1)
     offs = [0]
     for k in outs[:-1]:
         offs.append(offs[-1] + k)
