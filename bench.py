@@ -763,6 +763,48 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         float_row("cnn_float_input", "cnn_64", n_fc, 3, 1, 0, "float images -> class ids through the one-kernel CNN (quantisation fused; three waves per SIMD)")
         float_row("cnn_float_input_two_kernels", "cnn_64", n_fc, 3, 1, 2, "the same call as quantise + the one-kernel CNN on int8")
 
+    # the reference's training forward (models.py:70-90 FCMNIST over BitLinear, BitNetMCU.py:214-235)
+    # as ONE kernel behind a weight-preparation launch - float32 rows in, float32 logits out
+    def qat_row(name, rows, note):
+        from bitnetmcu_amd import qat
+        torch.manual_seed(20240324)
+        widths = [256, 64, 64, 64, 10]
+        ws = [torch.randn(widths[l + 1], widths[l], device=dev) * 0.08 for l in range(4)]
+        ss = [w.abs().mean().reshape(1) / 0.25 for w in ws]          # update_clipping_scalar(..., 'prop', 0.25), BitNetMCU.py:107-110
+        qts = ["4bitsym"] * 4
+        xq = b.synth.float_images_device(images[:rows])
+        torch.cuda.synchronize()
+        out = [None]
+        def step():
+            out[0] = qat.fc_model_forward(xq, ws, ss, qts, "RMS")
+        _, ms = timed_steps(torch, step, 20, 3)
+        rate = rows / (float(np.median(ms)) * 1e-3)
+        ok = None
+        if not a.no_verify:
+            # a floating-point op: against the restated reference formula on torch's own fp32 kernels (bitnetmcu_amd/qat.py
+            # fc_model_reference, pinned bit for bit to the reference module by tests/test_qat_cpu.py), tolerances of
+            # tests/test_gpu_qat_model.py: 90 % of the rows within 5e-4 of the row's largest logit, all within 6e-2
+            m = min(rows, 50_000)
+            want, _ = qat.fc_model_reference(xq[:m], ws, [t[0] for t in ss], qts, "RMS")
+            err = (out[0][:m] - want).abs().max(dim=1).values / want.abs().max(dim=1).values
+            ok = bool((err <= 5e-4).float().mean() >= 0.9 and err.max() <= 6e-2 and not torch.isnan(out[0]).any())
+        bpr = 1024 + 4 * widths[-1]
+        g = rate * bpr / 1e9
+        res[name] = {"model": "FCMNIST 64-64-64 4bitsym RMS PerTensor (random weights, clipping scalars as training.py's 'prop')", "rows": rows,
+                     "steps": 20, "warmup": 3, "value": rate, "unit": "rows/s", "median_call_ms": float(np.median(ms)), "min_call_ms": float(np.min(ms)),
+                     "avg_call_ms": float(np.mean(ms)), "kernel": "qat_model_prep_kernel+qat_fc_model_fwd_kernel", "launches_per_step": 2,
+                     "verified_vs_oracle": ok, "verified_against": "the restated reference formula in fp32 (floating-point op: tolerances, not bit-exact)",
+                     "note": note,
+                     "roofline": {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_row": bpr,
+                                  "definition": "(1,024 B of float32 read + 4 B x classes written) x rows / the median time of a whole call (both launches)"}}
+        del xq
+        torch.cuda.empty_cache()
+    if a.model == "fc_4bitsym_64" and n >= 1000:
+        qat_row("qat_fc_forward", min(n, 1_000_000), "QAT forward of the whole FC model, 1e6 rows per call (VERDICT r05 next #4)")
+        if n >= 10_000_000:
+            qat_row("qat_fc_forward_1e7", 10_000_000, "the same at 1e7 rows per call")
+
     n_cnn = min(n, 10_000_000)
     # configs[2]: ternary 96-96-96, bit-unpack / sign-accumulate ALU kernel, no MFMA — bound by the VALU issue rate
     # (selected by name: the library's AUTO path runs ternary models on the MFMA kernels, 5x faster - next entry)

@@ -5,7 +5,7 @@
 // needs, are written once).  gfx950 only.  Floating point: parity with the reference module is within the tolerances
 // tests/test_gpu_qat_model.py states, not bit-exact.
 //
-//   qat_model_prep_kernel     one workgroup per layer, once per call: weight_quant of the layer's float weights (the level of every
+//   qat_model_prep_kernel     16 workgroups per layer, once per call: weight_quant of the layer's float weights (the level of every
 //                             weight, BitNetMCU.py:150-177, x 2 for the half-integer types: an int8) written as the A-operand
 //                             fragments of v_mfma_i32_32x32x32_i8, the reciprocal weight scales, optionally w_int / w_scale (the
 //                             straight-through backward's operand); zeroes the work counter of the launch behind it
@@ -31,11 +31,15 @@
 // A row whose layer input is all zero has den = 0: the reference divides 0 / 0 and the row's logits are NaN; so are they here.
 #include "bnm_qat_math.hpp"
 #include "bnm_quantise_f32.hpp"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
 constexpr int QM_MAX_LAYERS = BNM_QAT_MODEL_MAX_LAYERS;
+constexpr uint32_t QM_PREP_SPLIT = 16;  // workgroups per layer of the weight preparation (each reduces the tensor's statistics itself)
 constexpr uint32_t QM_BATCH = 4;       // consecutive 32-row tiles per take from the work counter
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct QatModelDesc {
     uint32_t n_layers;                 // 2 .. 4
@@ -45,6 +49,7 @@ struct QatModelDesc {
     uint32_t frag_off[QM_MAX_LAYERS];  // byte offsets inside the weight image
     uint32_t winv_off[QM_MAX_LAYERS];  // reciprocal weight scales (floats, M x 32 per layer), byte offsets inside the image
     float inv_factor[QM_MAX_LAYERS];   // 1 / (int8 level factor)
+    float inv_width[QM_MAX_LAYERS];    // 1 / (true output width): the mean of Normalize over the NEXT layer's inputs
     uint32_t image_bytes;              // multiple of 16
     uint32_t hidden_stride;            // floats per row of the hidden-activation output (sum of the hidden widths)
     uint32_t hidden_off[QM_MAX_LAYERS];
@@ -108,37 +113,33 @@ BNM_DEVICE float halves_max(float v) {
     return fmaxf(__uint_as_float((uint32_t)r[0]), __uint_as_float((uint32_t)r[1]));
 }
 
-// Normalize's denominator and activation_quant's scale of a row from its sum (of squares / of absolute values) and max|x|
-// (BitNetMCU.py:237-246, :125-127).  NORM 0: RMS, 1: Lin.  Returns {1 / den, scale}; scale is NaN for an all-zero row (0 / 0 in
-// the reference).
+// Per-row scalars of Normalize + activation_quant (BitNetMCU.py:237-246, :125-127) from the row's sum (of squares: NORM 0 'RMS'; of
+// absolute values: 1 'Lin') and its max |x|:
+//     x_norm = x / den,  scale = 127 / max|x_norm| = 127 den / max|x|,  x_int = rne(x_norm scale) = rne(x c) with c = 127 / max|x|
+// (max|x_norm| >= 1 for both norms, so the reference's clamp at 1e-5 never acts on a row that is not all zero).  c does not depend
+// on den; scale = c den.  v_rcp_f32 / v_sqrt_f32 (1 ulp) - see the header comment on what an ulp of a scale can do.  An all-zero
+// row: c = inf, scale = inf * 0 = NaN, which reaches the row's logits as the reference's 0 / 0 does.
 template <int NORM>
-BNM_DEVICE void row_scales(float sum, float mx, float width, float &inv_den, float &scale) {
-    const float mean = __fdiv_rn(sum, width);
-    const float den = NORM == 0 ? __fsqrt_rn(mean) : mean;
-    inv_den = __fdiv_rn(1.0f, den);
-    const float m = __fmul_rn(mx, inv_den);      // = max |x * (1 / den)|: rounding is monotonic
-    scale = sum > 0.0f ? __fdiv_rn(127.0f, fmaxf(m, 1e-5f)) : __uint_as_float(0x7fc00000u);
+BNM_DEVICE void row_scalars(float sum, float mx, float inv_width, float &c, float &scale) {
+    const float mean = sum * inv_width;
+    const float den = NORM == 0 ? __builtin_amdgcn_sqrtf(mean) : mean;
+    c = 127.0f * __builtin_amdgcn_rcpf(mx);
+    scale = c * den;
 }
 
-// rne(t * scale) of four values as four int8 in one dword (byte b = value b); t = v * inv_den rounded to float32 first
-BNM_DEVICE uint32_t norm_quantise4(float v0, float v1, float v2, float v3, float inv_den, float scale) {
-    const float v[4] = {v0, v1, v2, v3};
-    uint32_t q[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        float t = __fmul_rn(v[b], inv_den);
-        asm("" : "+v"(t));
-        float p = __fmul_rn(t, scale);
-        asm("" : "+v"(p));                     // no fma: the product is rounded to float32 before the rounding add
-        q[b] = __float_as_uint(__fadd_rn(p, 12582912.0f));
-    }
-    const uint32_t lo = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0400u), hi = __builtin_amdgcn_perm(q[3], q[2], 0x04000c0cu);
-    return lo | hi;
+// rne(v c) of four values as four int8 in one dword (byte b = value b): v c + 1.5 * 2^23 as two v_pk_fma_f32 (the sum's ulp is 1, so
+// the fma rounds the exact product to the nearest integer, ties to even), the four low bytes gathered by v_perm_b32
+BNM_DEVICE uint32_t quantise4_pk(f32x2 lo, f32x2 hi, float c) {
+    const f32x2 cc = {c, c}, magic = {12582912.0f, 12582912.0f};
+    const f32x2 a = __builtin_elementwise_fma(lo, cc, magic), b = __builtin_elementwise_fma(hi, cc, magic);
+    const uint32_t p = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x0c0c0400u);
+    const uint32_t q = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x04000c0cu);
+    return p | q;
 }
 
 }  // namespace
 
-// ---- weight preparation: one workgroup per layer ------------------------------------------------------------------------------
+// ---- weight preparation: QM_PREP_SPLIT workgroups per layer ------------------------------------------------------------------------------
 // Fragment order of layer l: [m][s][lane][16 bytes]; lane (i, h) of tile m, K-step s holds row 32 m + i and the 16 K columns
 //   layer 0: 32 s + 16 h + r                       (the LDS tile's natural byte order)
 //   layer l > 0: 32 s + (r & 3) + 8 (r >> 2) + 4 h    (the D-fragment order the previous layer's outputs are packed in)
@@ -146,8 +147,8 @@ __global__ __launch_bounds__(1024) void qat_model_prep_kernel(QatPrepArgs a, Qat
                                                               uint32_t *__restrict__ counter) {
     __shared__ double sa[16], sw[16];
     __shared__ float stats[2];
-    const uint32_t l = blockIdx.x;
-    if (l == 0 && threadIdx.x < 144u) counter[threadIdx.x] = 0u;      // eight counter words, 64 bytes apart
+    const uint32_t l = blockIdx.x, part = blockIdx.y, tid = part * 1024u + threadIdx.x, stride = 1024u * QM_PREP_SPLIT;
+    if (l == 0 && part == 0 && threadIdx.x < 144u) counter[threadIdx.x] = 0u;      // eight counter words, 64 bytes apart
     const float *w = a.w[l];
     const uint32_t k = d.width[l], din = a.d_in[l];
     const int qt = a.qt[l];
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(1024) void qat_model_prep_kernel(QatPrepArgs a, Qat
     const float factor = (float)qat_i8_factor(qt);
     const uint32_t Mt = d.M[l], Ks = d.KS[l];
     int8_t *frag = (int8_t *)(image + d.frag_off[l]);
-    for (uint32_t o = threadIdx.x; o < Mt * Ks * 1024u; o += 1024u) {
+    for (uint32_t o = tid; o < Mt * Ks * 1024u; o += stride) {
         const uint32_t r = o & 15u, lane = (o >> 4) & 63u, ms = o >> 10, s = ms % Ks, m = ms / Ks;
         const uint32_t i = lane & 31u, h = lane >> 5;
         const uint32_t row = 32u * m + i;
@@ -191,19 +192,26 @@ __global__ __launch_bounds__(1024) void qat_model_prep_kernel(QatPrepArgs a, Qat
         frag[o] = b;
     }
     float *winv = (float *)(image + d.winv_off[l]);
-    for (uint32_t row = threadIdx.x; row < Mt * 32u; row += 1024u)
+    for (uint32_t row = tid; row < Mt * 32u; row += stride)
         winv[row] = row < k ? __fdiv_rn(1.0f, qat_weight_scale(qt, a.s[l][a.s_count[l] > 1 ? row : 0], mean_abs)) : 0.0f;
     if (a.w_deq[l])
-        for (uint64_t i = threadIdx.x; i < count; i += 1024) {
+        for (uint64_t i = tid; i < count; i += stride) {
             const float sc = qat_weight_scale(qt, a.s[l][a.s_count[l] > 1 ? (uint32_t)(i / din) : 0], mean_abs);
             a.w_deq[l][i] = __fdiv_rn(qat_weight_level(qt, w[i], sc, mean_w), sc);       // w_int / w_scale, the STE forward value
         }
 }
 
 // ---- the model ----------------------------------------------------------------------------------------------------------------
-// MH: most 32-row tiles of any layer.  NORM 0 RMS / 1 Lin.  PEROUT: per-output clipping scalars (a second multiplication per output).
-// NG: 8-row landing groups in flight per wave.  WPS: waves per SIMD the register budget is compiled for.
-template <int MH, int NORM, bool PEROUT, int NG, int WPS>
+// MH: most 32-row tiles of any layer.  NORM 0 RMS / 1 Lin.  PEROUT: per-output clipping scalars (a multiplication per output more).
+// HID: the hidden activations are written.  NG: 8-row landing groups in flight per wave.  WPS: waves per SIMD the register budget is
+// compiled for.
+//
+// The arithmetic per layer, in the units the kernel keeps.  The integer sums of a row are acc_o; the layer's outputs are
+//     y_o = acc_o * a * [winv_o],     a = 1 / (factor x_scale [w_scale])  > 0        (winv_o = 1 / w_scale_o: PEROUT only)
+// ReLU, Normalize and activation_quant commute with the positive row constant a, so with u_o = relu(acc_o [* winv_o]):
+//     x_int(next) = rne(u_o * 127 / max u),     x_scale(next) = 127 sqrt(mean u^2) / max u       ('Lin': mean u)
+// and a is needed only where y itself leaves the kernel (the logits, the optional hidden activations).
+template <int MH, int NORM, bool PEROUT, bool HID, int NG, int WPS>
 __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float *__restrict__ x, uint64_t n,
                                                                      const i32x4 *__restrict__ image, QatModelDesc d,
                                                                      float *__restrict__ logits, float *__restrict__ hidden,
@@ -220,9 +228,8 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
     const uint32_t lane16 = 16u * (uint32_t)lane;
     const uint32_t rd_off = tile_off + (uint32_t)j * 256u + 16u * ((uint32_t)h ^ ((uint32_t)j & 15u));
     const uint32_t wr_off = tile_off + 4u * (uint32_t)lane;
-    // which of a group's eight rows this lane's reduced statistics belong to (see group_stats) and whether it is the lane that reports them
+    // which of a group's eight rows this lane's reduced statistics belong to (see the fold comment below); lanes with (lane & 7) == 0 report them
     const uint32_t my_row = (((uint32_t)lane >> 5) & 1u) | ((((uint32_t)lane >> 4) & 1u) << 1) | ((((uint32_t)lane >> 3) & 1u) << 2);
-    const bool reporter = (lane & 7) == 0;
     float *const xs = (float *)(smem + d.image_bytes + nwaves * 8192u) + wave * 32u;      // layer-1 activation scales of the tile's rows
 
     const uint32_t n_units = (uint32_t)((n + 31ull) >> 5);
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
     // words, wave w takes from word w mod 8; zeroed by the prep kernel).  The loop runs one unit ahead because `next`'s loads start
     // inside the current iteration; the take that decides next's successor is issued at the top and retired behind the quantisation.
     constexpr uint32_t batch = QM_BATCH;
-    const uint32_t my_word = wave_id & 7u, first_dyn = total_waves >> 3;
+    const uint32_t my_word = wave_id & 7u, first_dyn = (total_waves + 7u) >> 3;
     uint32_t taken = 0;
     auto batch_first = [&](uint32_t t) { return (((first_dyn + t) << 3) + my_word) * batch; };
     uint32_t unit = wave_id * batch, next = unit + 1u, next_left = batch - 2u;
@@ -267,8 +274,13 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const f32x4 &v = land[slot][r];
-                if constexpr (NORM == 0) sum[r] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
-                else sum[r] = (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
+                if constexpr (NORM == 0) {
+                    const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+                    const f32x2 sq = __builtin_elementwise_fma(hi, hi, lo * lo);
+                    sum[r] = sq[0] + sq[1];
+                } else {
+                    sum[r] = (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
+                }
                 mx[r] = absmax4_bits(v);
             }
             // fold32 pairs rows (0,1) (2,3) (4,5) (6,7); fold16 pairs the results; the select puts the second quadruple into the upper
@@ -279,17 +291,16 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
             const uint32_t f0 = rowmax16u(fold16_max(c0, c1)), f1 = rowmax16u(fold16_max(c2, c3));
             const float row_sum = (lane & 8) ? e1 : e0;
             const float row_max = __uint_as_float((lane & 8) ? f1 : f0);
-            float inv_den, scale;
-            row_scales<NORM>(row_sum, row_max, 256.0f, inv_den, scale);
-            if (reporter) xs[8 * g + (int)my_row] = scale;
+            float cq, scale;
+            row_scalars<NORM>(row_sum, row_max, 1.0f / 256.0f, cq, scale);
+            if ((lane & 7) == 0) xs[8 * g + (int)my_row] = scale;
             constexpr int kLane[8] = {0, 32, 16, 48, 8, 40, 24, 56};
             uint32_t q[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const float id = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_den), kLane[r]));
-                const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scale), kLane[r]));
+                const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cq), kLane[r]));
                 const f32x4 &v = land[slot][r];
-                q[r] = norm_quantise4(v[0], v[1], v[2], v[3], id, sc);
+                q[r] = quantise4_pk(f32x2{v[0], v[1]}, f32x2{v[2], v[3]}, c);
             }
             if constexpr (g + NG < 4) load_group(unit, g + NG, land[slot]);
             else if (next < n_units) load_group(next, g + NG - 4, land[slot]);
@@ -308,27 +319,64 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
 
         // ---- the layers -----------------------------------------------------------------------------------------------------
         const uint64_t row = (uint64_t)unit * 32ull + (uint64_t)j;
-        float y[MH][16];
-        i32x4 act[MH];
+        float u[MH][16];          // relu(acc [* winv]) of the layer in hand
+        i32x4 act[MH];            // its quantised form: the next layer's B operands
         float x_scale = xs[j];
-        // y = sum / factor / x_scale / w_scale as one multiplication (PEROUT: the per-output reciprocal follows)
+        // a of layer l (see the comment above the kernel)
         auto out_scale = [&](uint32_t l) {
-            float a = __fdiv_rn(d.inv_factor[l], x_scale);
-            if constexpr (!PEROUT) a = __fmul_rn(a, *(const float *)(smem + d.winv_off[l]));
+            float a = d.inv_factor[l] * __builtin_amdgcn_rcpf(x_scale);
+            if constexpr (!PEROUT) a *= *(const float *)(smem + d.winv_off[l]);
             return a;
         };
-        auto scale_tile = [&](uint32_t l, int m, const i32x16 &acc, float a, float(&out)[16]) {
-            if constexpr (PEROUT) {
+        // the D fragment of tile m of layer l as floats (PEROUT: times the outputs' reciprocal weight scales)
+        auto to_float = [&](uint32_t l, int m, const i32x16 &acc, float(&out)[16]) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const f32x4 wi = *(const f32x4 *)(smem + d.winv_off[l] + 4u * (32u * (uint32_t)m + 8u * (uint32_t)q + 4u * (uint32_t)h));
+            for (int q = 0; q < 4; q++) {
+                f32x4 wi = {1.0f, 1.0f, 1.0f, 1.0f};
+                if constexpr (PEROUT) wi = *(const f32x4 *)(smem + d.winv_off[l] + 4u * (32u * (uint32_t)m + 8u * (uint32_t)q + 4u * (uint32_t)h));
 #pragma unroll
-                    for (int b = 0; b < 4; b++) out[4 * q + b] = __fmul_rn(__fmul_rn((float)acc[4 * q + b], a), wi[b]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; r++) out[r] = __fmul_rn((float)acc[r], a);
+                for (int b = 0; b < 4; b++) out[4 * q + b] = PEROUT ? (float)acc[4 * q + b] * wi[b] : (float)acc[4 * q + b];
             }
+        };
+        // ReLU + Normalize + activation_quant of layer l's outputs (held in u as acc [* winv]) -> the next layer's B operands; `a` only
+        // where the activations are written out
+        auto relu_norm_quant = [&](uint32_t l, float a) {
+            f32x2 sum2 = {0.0f, 0.0f};
+            float mx = 0.0f;
+#pragma unroll
+            for (int m = 0; m < MH; m++)
+                if ((uint32_t)m < d.M[l]) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 v = {fmaxf(u[m][r], 0.0f), fmaxf(u[m][r + 1], 0.0f)};
+                        u[m][r] = v[0];
+                        u[m][r + 1] = v[1];
+                        if constexpr (NORM == 0) sum2 = __builtin_elementwise_fma(v, v, sum2);
+                        else sum2 += v;
+                        mx = __builtin_fmaxf(__builtin_fmaxf(mx, v[0]), v[1]);      // (v_max3_f32)
+                    }
+                    if constexpr (HID) {
+                        if (row < n) {
+                            float *hp = hidden + row * d.hidden_stride + d.hidden_off[l] + 32u * (uint32_t)m + 4u * (uint32_t)h;
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+#pragma unroll
+                                for (int b = 0; b < 4; b++)
+                                    if (32u * (uint32_t)m + 8u * (uint32_t)q + 4u * (uint32_t)h + (uint32_t)b < d.width[l]) hp[8 * q + b] = u[m][4 * q + b] * a;
+                        }
+                    }
+                }
+            const float sum = halves_sum(sum2[0] + sum2[1]);
+            mx = halves_max(mx);
+            float cq;
+            row_scalars<NORM>(sum, mx, d.inv_width[l], cq, x_scale);
+#pragma unroll
+            for (int m = 0; m < MH; m++)
+                if ((uint32_t)m < d.M[l]) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        act[m][q] = (int)quantise4_pk(f32x2{u[m][4 * q], u[m][4 * q + 1]}, f32x2{u[m][4 * q + 2], u[m][4 * q + 3]}, cq);
+                }
         };
         // layer 0: B operands from the LDS tile (MH = 4: re-read per output tile - 64 registers of outputs leave no room to hold them)
         {
@@ -337,7 +385,6 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
 #pragma unroll
                 for (int s = 0; s < 8; s++) b0[s] = *(const i32x4 *)(smem + (rd_off ^ (32u * (uint32_t)s)));
             }
-            const float a = out_scale(0);
 #pragma unroll
             for (int m = 0; m < MH; m++)
                 if ((uint32_t)m < d.M[0]) {
@@ -348,45 +395,10 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
                         if constexpr (MH <= 2) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const i32x4 *)(fp + 1024 * s), b0[s], acc, 0, 0, 0);
                         else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const i32x4 *)(fp + 1024 * s), *(const i32x4 *)(smem + (rd_off ^ (32u * (uint32_t)s))), acc, 0, 0, 0);
                     }
-                    scale_tile(0, m, acc, a, y[m]);
+                    to_float(0, m, acc, u[m]);
                 }
         }
-        // ReLU + Normalize + activation_quant of a layer's outputs -> the next layer's B operands
-        auto relu_norm_quant = [&](uint32_t l) {
-            float sum = 0.0f, mx = 0.0f;
-#pragma unroll
-            for (int m = 0; m < MH; m++)
-                if ((uint32_t)m < d.M[l]) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const float v = fmaxf(y[m][r], 0.0f);
-                        y[m][r] = v;
-                        if constexpr (NORM == 0) sum = fmaf(v, v, sum);
-                        else sum += v;
-                        mx = fmaxf(mx, v);
-                    }
-                    if (hidden && row < n) {
-                        float *hp = hidden + row * d.hidden_stride + d.hidden_off[l] + 32u * (uint32_t)m + 4u * (uint32_t)h;
-#pragma unroll
-                        for (int q = 0; q < 4; q++)
-#pragma unroll
-                            for (int b = 0; b < 4; b++)
-                                if (32u * (uint32_t)m + 8u * (uint32_t)q + 4u * (uint32_t)h + (uint32_t)b < d.width[l]) hp[8 * q + b] = y[m][4 * q + b];
-                    }
-                }
-            sum = halves_sum(sum);
-            mx = halves_max(mx);
-            float inv_den;
-            row_scales<NORM>(sum, mx, (float)d.width[l], inv_den, x_scale);
-#pragma unroll
-            for (int m = 0; m < MH; m++)
-                if ((uint32_t)m < d.M[l]) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) act[m][q] = (int)norm_quantise4(y[m][4 * q], y[m][4 * q + 1], y[m][4 * q + 2], y[m][4 * q + 3], inv_den, x_scale);
-                }
-        };
         auto layer = [&](uint32_t l) {
-            const float a = out_scale(l);
             const uint32_t ks = d.KS[l];
 #pragma unroll
             for (int m = 0; m < MH; m++)
@@ -396,14 +408,16 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
 #pragma unroll
                     for (int s = 0; s < MH; s++)
                         if ((uint32_t)s < ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*(const i32x4 *)(fp + 1024 * s), act[s], acc, 0, 0, 0);
-                    scale_tile(l, m, acc, a, y[m]);
+                    to_float(l, m, acc, u[m]);
                 }
         };
-        relu_norm_quant(0);
+        relu_norm_quant(0, HID ? out_scale(0) : 0.0f);
         for (uint32_t l = 1; l + 1u < d.n_layers; l++) {
+            const float a = HID ? out_scale(l) : 0.0f;      // (x_scale is the layer's INPUT scale here)
             layer(l);
-            relu_norm_quant(l);
+            relu_norm_quant(l, a);
         }
+        const float a_last = out_scale(d.n_layers - 1u);
         layer(d.n_layers - 1u);
         // ---- logits: 32 x n_classes consecutive floats, staged through the wave's tile ------------------------------------------
         {
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const uint32_t c = 32u * (uint32_t)m + (uint32_t)(r & 3) + 8u * (uint32_t)(r >> 2) + 4u * (uint32_t)h;
-                        if (c < n_classes) stage[(uint32_t)j * n_classes + c] = y[m][r];
+                        if (c < n_classes) stage[(uint32_t)j * n_classes + c] = u[m][r] * a_last;
                     }
                 }
             const uint64_t first = (uint64_t)unit * 32ull;
@@ -451,6 +465,7 @@ bool qat_model_plan(uint32_t n_layers, const uint32_t *widths, QatModelPlan &p) 
         if (w == 0 || w > 128u) return false;
         if (l + 1 == n_layers && w > 64u) return false;
         d.width[l] = w;
+        d.inv_width[l] = 1.0f / (float)w;
         d.M[l] = (w + 31u) / 32u;
         d.KS[l] = l == 0 ? 8u : d.M[l - 1];
         d.frag_off[l] = off;
@@ -472,11 +487,10 @@ bool qat_model_plan(uint32_t n_layers, const uint32_t *widths, QatModelPlan &p) 
     return true;
 }
 
-template <int MH, int NORM, bool PEROUT>
-hipError_t qat_model_launch(const QatModelDesc &d, const float *x, uint64_t n, const char *image, float *logits, float *hidden,
-                            uint32_t n_classes, uint32_t *counter, hipStream_t st) {
-    constexpr int NG = 2, WPS = 2;
-    auto fn = qat_fc_model_fwd_kernel<MH, NORM, PEROUT, NG, WPS>;
+template <int MH, int NORM, bool PEROUT, bool HID, int NG, int WPS>
+hipError_t qat_model_launch_as(const QatModelDesc &d, const float *x, uint64_t n, const char *image, float *logits, float *hidden,
+                               uint32_t n_classes, uint32_t *counter, hipStream_t st) {
+    auto fn = qat_fc_model_fwd_kernel<MH, NORM, PEROUT, HID, NG, WPS>;
     const unsigned threads = 256 * WPS, nwaves = threads / 64;
     const size_t lds = (size_t)d.image_bytes + (size_t)nwaves * 8192u + (size_t)nwaves * 128u;
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
@@ -488,10 +502,25 @@ hipError_t qat_model_launch(const QatModelDesc &d, const float *x, uint64_t n, c
     const uint64_t units = (n + 31ull) >> 5;
     if (units >= (1ull << 31)) return hipErrorInvalidValue;      // 32-bit tile indices in the kernel
     uint64_t blocks = (units + (uint64_t)nwaves * QM_BATCH - 1) / ((uint64_t)nwaves * QM_BATCH);
-    const uint64_t cus = (uint64_t)bnm_num_cus();
-    if (blocks > cus) blocks = cus;
+    const uint64_t cus = (uint64_t)bnm_num_cus() * (WPS == 1 ? 2u : 1u);      // (one wave per SIMD: two workgroups of four waves per CU)
+    if (blocks > cus) blocks = WPS == 1 ? (cus & ~1ull) : cus;      // capped grids: waves a multiple of 8 (the counter's eight words)
     fn<<<dim3((unsigned)blocks), dim3(threads), lds, st>>>(x, n, (const i32x4 *)image, d, logits, hidden, n_classes, counter);
     return hipGetLastError();
+}
+
+template <int MH, int NORM, bool PEROUT, bool HID>
+hipError_t qat_model_launch(const QatModelDesc &d, const float *x, uint64_t n, const char *image, float *logits, float *hidden,
+                            uint32_t n_classes, uint32_t *counter, hipStream_t st) {
+#ifdef BNM_QAT_MODEL_TUNE
+    // measurement builds only: BNM_QAT_TUNE=<ng><wps> picks another landing depth / occupancy for the flagship instantiation
+    if constexpr (MH == 2 && NORM == 0 && !PEROUT && !HID) {
+        const char *t = getenv("BNM_QAT_TUNE");
+        if (t && !strcmp(t, "42")) return qat_model_launch_as<MH, NORM, PEROUT, HID, 4, 2>(d, x, n, image, logits, hidden, n_classes, counter, st);
+        if (t && !strcmp(t, "41")) return qat_model_launch_as<MH, NORM, PEROUT, HID, 4, 1>(d, x, n, image, logits, hidden, n_classes, counter, st);
+        if (t && !strcmp(t, "21")) return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, 1>(d, x, n, image, logits, hidden, n_classes, counter, st);
+    }
+#endif
+    return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, 2>(d, x, n, image, logits, hidden, n_classes, counter, st);
 }
 
 }  // namespace
@@ -528,12 +557,14 @@ hipError_t bnmk_qat_model_forward(const float *x, uint64_t n, uint32_t n_layers,
     }
     char *image = (char *)workspace;
     uint32_t *counter = (uint32_t *)(image + p.d.image_bytes);
-    qat_model_prep_kernel<<<dim3(n_layers), dim3(1024), 0, st>>>(a, p.d, image, counter);
+    qat_model_prep_kernel<<<dim3(n_layers, QM_PREP_SPLIT), dim3(1024), 0, st>>>(a, p.d, image, counter);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
     const uint32_t nc = widths[n_layers];
     const int nt = norm_type == BNM_QAT_NORM_RMS ? 0 : 1;
-#define QM_GO(MH, NORM, PO) return qat_model_launch<MH, NORM, PO>(p.d, x, n, image, logits, hidden, nc, counter, st)
+#define QM_GO(MH, NORM, PO)                                                                                   \
+    return hidden ? qat_model_launch<MH, NORM, PO, true>(p.d, x, n, image, logits, hidden, nc, counter, st) \
+                  : qat_model_launch<MH, NORM, PO, false>(p.d, x, n, image, logits, hidden, nc, counter, st)
     if (p.mh == 2) {
         if (nt == 0) { if (perout) QM_GO(2, 0, true); else QM_GO(2, 0, false); }
         else { if (perout) QM_GO(2, 1, true); else QM_GO(2, 1, false); }

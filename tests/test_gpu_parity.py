@@ -876,6 +876,9 @@ def test_bench_json_contract(gpu_ok, tmp_path):
     # the CNN is one launch per call; its row says what binds it in the kernel's own terms
     assert ex["cnn_64"]["launched"] in ("cnn_li_fused_pipe_kernel", "cnn_front_mfma_kernel+fused_fc_kernel")
     assert "int8_ops_algorithmic" in ex["cnn_64"]["roofline"] and ex["cnn_64"]["roofline"]["int8_ops_algorithmic"]["per_image"] == 2 * 236416
+    # the whole-model QAT forward has a row of its own (HBM roofline on 1,024 + 40 bytes per row)
+    qf = ex["qat_fc_forward"]
+    assert qf["verified_vs_oracle"] is True and qf["rows"] == 300000 and qf["roofline"]["algorithmic_bytes_per_row"] == 1064 and 0 < qf["roofline"]["frac"] <= 1
     # the CNN row's MFMA count is the kernel's own (bnm_ctx_cnn_planes): 14 + 24 + 2 x 2 per channel and tile x 64 channels / 32 + the tail's 5
     assert ex["cnn_64"]["roofline"]["mfma"]["per_channel_tile"] == 42 and ex["cnn_64"]["roofline"]["mfma"]["per_image"] == 85.0
     assert ex["cnn_64"]["steps"] >= 10 and ex["cnn_64"]["warmup"] >= 2
