@@ -772,7 +772,10 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
         ws = [torch.randn(widths[l + 1], widths[l], device=dev) * 0.08 for l in range(4)]
         ss = [w.abs().mean().reshape(1) / 0.25 for w in ws]          # update_clipping_scalar(..., 'prop', 0.25), BitNetMCU.py:107-110
         qts = ["4bitsym"] * 4
-        xq = b.synth.float_images_device(images[:rows])
+        # float rows with a continuous distribution (the int8 synthetic images x 1/127 put half of the rows on EXACT rounding ties
+        # - 64 x 127/128 = 63.5 whenever a row holds -128 -, which no two float evaluation orders resolve alike)
+        gen = torch.Generator(device=dev).manual_seed(20240324)
+        xq = torch.randn(rows, 256, device=dev, generator=gen) * (torch.rand(rows, 1, device=dev, generator=gen) * 2 + 0.05)
         torch.cuda.synchronize()
         out = [None]
         def step():

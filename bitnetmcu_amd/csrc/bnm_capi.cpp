@@ -1,69 +1,12 @@
-// C ABI of libbitnetmcu_hip.so / Bitnet_inf.dll (declared in include/bitnetmcu_hip.h): error state, version, the model
-// objects, and the small device utilities.  The rest of the ABI lives beside this file: bnm_capi_ctx.cpp (contexts, kernel
+// C ABI of libbitnetmcu_hip.so / Bitnet_inf.dll (declared in include/bitnetmcu_hip.h): the small device utilities.  The rest of
+// the ABI lives beside this file: bnm_capi_model.cpp (error state, version, the model objects: no HIP), bnm_capi_ctx.cpp (contexts, kernel
 // selection, per-stream scratch), bnm_capi_infer.cpp (device-pointer inference), bnm_capi_host.cpp (host-pointer inference),
 // bnm_capi_float.cpp (float inputs), bnm_capi_qat.cpp, bnm_capi_multigpu.cpp, bnm_capi_symbols.cpp (the reference's own symbols).
 #include "bnm_capi_internal.hpp"
 
-namespace bnm_internal {
-thread_local std::string g_err;
-}
 using namespace bnm_internal;
 
 extern "C" {
-
-const char *bnm_last_error(void) { return g_err.c_str(); }
-const char *bnm_version(void) { return "bitnetmcu_hip 0.1 (gfx950)"; }
-
-int bnm_model_from_header_text(const char *text, size_t len, bnm_model **out) {
-    if (!text || !out) return fail(BNM_EINVAL, "null argument");
-    bnm_model *m = new bnm_model();
-    std::string err;
-    if (!bnm_parse_header_text(text, len, *m, err)) {
-        delete m;
-        return fail(err.find("support") != std::string::npos ? BNM_EUNSUPPORTED : BNM_EPARSE, err);
-    }
-    *out = m;
-    return BNM_OK;
-}
-
-int bnm_model_from_blob(const void *blob, size_t len, bnm_model **out) {
-    if (!blob || !out) return fail(BNM_EINVAL, "null argument");
-    bnm_model *m = new bnm_model();
-    std::string err;
-    if (!bnm_deserialize(blob, len, *m, err)) {
-        delete m;
-        return fail(BNM_EPARSE, err);
-    }
-    *out = m;
-    return BNM_OK;
-}
-
-size_t bnm_model_blob_size(const bnm_model *m) { return m ? bnm_serialize(*m).size() : 0; }
-
-int bnm_model_to_blob(const bnm_model *m, void *dst, size_t cap) {
-    if (!m || !dst) return fail(BNM_EINVAL, "null argument");
-    std::vector<uint8_t> b = bnm_serialize(*m);
-    if (cap < b.size()) return fail(BNM_EINVAL, "destination too small");
-    std::memcpy(dst, b.data(), b.size());
-    return BNM_OK;
-}
-
-void bnm_model_free(bnm_model *m) { delete m; }
-uint32_t bnm_model_kind(const bnm_model *m) { return m ? m->kind : 0; }
-uint32_t bnm_model_num_layers(const bnm_model *m) { return m ? (uint32_t)m->layers.size() : 0; }
-uint32_t bnm_model_num_classes(const bnm_model *m) { return m ? m->num_classes() : 0; }
-uint32_t bnm_model_input_bytes(const bnm_model *) { return 256; }
-
-int bnm_model_layer(const bnm_model *m, uint32_t i, bnm_layer_info *info) {
-    if (!m || !info || i >= m->layers.size()) return fail(BNM_EINVAL, "layer index out of range");
-    *info = m->layers[i].info;
-    return BNM_OK;
-}
-
-const void *bnm_model_layer_weights(const bnm_model *m, uint32_t i) {
-    if (!m || i >= m->layers.size()) return nullptr;
-    return m->layers[i].weights.data();
-}
 
 int bnm_device_count(void) {
     int n = 0;

@@ -17,18 +17,12 @@
 #include "bnm_device.hpp"
 #include "bnm_kernels.h"
 #include "bnm_model.hpp"
+#include "bnm_capi_error.hpp"
 #ifdef BNM_DIAG
 #include "bnm_diag.h"
 #endif
 
 namespace bnm_internal {
-
-extern thread_local std::string g_err;      // bnm_last_error() of the calling thread (bnm_capi.cpp)
-
-inline int fail(int code, const std::string &msg) {
-    g_err = msg;
-    return code;
-}
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
