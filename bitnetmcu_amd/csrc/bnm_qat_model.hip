@@ -129,8 +129,11 @@ BNM_DEVICE void row_scalars(float sum, float mx, float inv_width, float &c, floa
 
 // rne(v c) of four values as four int8 in one dword (byte b = value b): v c + 1.5 * 2^23 as two v_pk_fma_f32 (the sum's ulp is 1, so
 // the fma rounds the exact product to the nearest integer, ties to even), the four low bytes gathered by v_perm_b32
-BNM_DEVICE uint32_t quantise4_pk(f32x2 lo, f32x2 hi, float c) {
-    const f32x2 cc = {c, c}, magic = {12582912.0f, 12582912.0f};
+// (magic = {1.5 * 2^23, 1.5 * 2^23} in a VGPR pair of the caller: as a scalar-register pair the compiler places its undefined high half on
+// the register an outstanding work-counter take returns into - harmless, but profiles/check_inflight_sgprs.py rightly refuses to reason
+// about that)
+BNM_DEVICE uint32_t quantise4_pk(f32x2 lo, f32x2 hi, float c, f32x2 magic) {
+    const f32x2 cc = {c, c};
     const f32x2 a = __builtin_elementwise_fma(lo, cc, magic), b = __builtin_elementwise_fma(hi, cc, magic);
     const uint32_t p = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x0c0c0400u);
     const uint32_t q = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x04000c0cu);
@@ -236,6 +239,8 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
     const float *const xl = x + 4u * (uint32_t)lane;
     const uint32_t total_waves = gridDim.x * nwaves, wave_id = blockIdx.x * nwaves + wave;
 
+    f32x2 magic = {12582912.0f, 12582912.0f};      // 1.5 * 2^23: the rounding add of quantise4_pk
+    asm volatile("" : "+v"(magic));
     f32x4 land[NG][8];
     auto load_group = [&](uint32_t u, int g, f32x4(&dst)[8]) {
         const uint64_t first = (uint64_t)u * 32ull + (uint64_t)(8 * g);
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
             for (int r = 0; r < 8; r++) {
                 const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cq), kLane[r]));
                 const f32x4 &v = land[slot][r];
-                q[r] = quantise4_pk(f32x2{v[0], v[1]}, f32x2{v[2], v[3]}, c);
+                q[r] = quantise4_pk(f32x2{v[0], v[1]}, f32x2{v[2], v[3]}, c, magic);
             }
             if constexpr (g + NG < 4) load_group(unit, g + NG, land[slot]);
             else if (next < n_units) load_group(next, g + NG - 4, land[slot]);
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
                 if ((uint32_t)m < d.M[l]) {
 #pragma unroll
                     for (int q = 0; q < 4; q++)
-                        act[m][q] = (int)quantise4_pk(f32x2{u[m][4 * q], u[m][4 * q + 1]}, f32x2{u[m][4 * q + 2], u[m][4 * q + 3]}, cq);
+                        act[m][q] = (int)quantise4_pk(f32x2{u[m][4 * q], u[m][4 * q + 1]}, f32x2{u[m][4 * q + 2], u[m][4 * q + 3]}, cq, magic);
                 }
         };
         // layer 0: B operands from the LDS tile (MH = 4: re-read per output tile - 64 registers of outputs leave no room to hold them)
@@ -520,7 +525,8 @@ hipError_t qat_model_launch(const QatModelDesc &d, const float *x, uint64_t n, c
         if (t && !strcmp(t, "21")) return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, 1>(d, x, n, image, logits, hidden, n_classes, counter, st);
     }
 #endif
-    return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, 2>(d, x, n, image, logits, hidden, n_classes, counter, st);
+    // (the four-tile class with the hidden activations written needs more than 256 registers: one wave per SIMD there)
+    return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, (MH == 4 && HID) ? 1 : 2>(d, x, n, image, logits, hidden, n_classes, counter, st);
 }
 
 }  // namespace

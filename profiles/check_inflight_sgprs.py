@@ -23,6 +23,29 @@ def disasm(obj):
 
 
 def sregs(text):
+    """Scalar registers an instruction names.  Packed-math instructions (v_pk_*) read, per lane, the half of a 64-bit source their
+    op_sel / op_sel_hi bits select: a scalar pair with op_sel 0 and op_sel_hi 0 on that source is read in its LOW register only
+    (the compiler broadcasts one scalar that way and leaves the pair's high half undefined - it may sit on a register that is
+    otherwise in use), with both bits 1 in its high register only."""
+    out = set()
+    if text.startswith("v_pk_"):
+        def bits(name, default):
+            m = re.search(name + r":\[([01,]+)\]", text)
+            return [int(v) for v in m.group(1).split(",")] if m else default
+        ops = re.split(r",\s*", text.split(None, 1)[1].split(" op_sel")[0].split(" neg_")[0].split(" clamp")[0])
+        lo_sel, hi_sel = bits("op_sel", [0, 0, 0]), bits("op_sel_hi", [1, 1, 1])
+        for k, op in enumerate(ops[1:]):
+            m = re.fullmatch(r"s\[(\d+):(\d+)\]", op.strip())
+            if m and k < 3 and int(m.group(2)) == int(m.group(1)) + 1:
+                sel = {lo_sel[k] if k < len(lo_sel) else 0, hi_sel[k] if k < len(hi_sel) else 1}
+                out.update(int(m.group(1)) + half for half in sel)
+            else:
+                out |= sregs_plain(op)
+        return out | sregs_plain(ops[0])
+    return sregs_plain(text)
+
+
+def sregs_plain(text):
     out = set()
     for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", text):
         out.update(range(int(a), int(b) + 1))

@@ -27,6 +27,19 @@ def test_ternary_chunk_loads_untouched_in_flight():
     assert " 0 instructions touch a result register in flight" in r.stdout and " 0 scalar work-counter takes" not in r.stdout
 
 
+def test_inflight_checker_reads_packed_math_operand_halves():
+    """Packed fp32 instructions read the half of a scalar pair their op_sel bits select (the whole-model QAT kernel broadcasts one
+    scalar as `s[94:95] op_sel_hi 0`, the pair's undefined high half lying on the take's result register): the checker counts
+    exactly the registers read."""
+    sys.path.insert(0, os.path.join(util.REPO, "profiles"))
+    import check_inflight_sgprs as C
+    assert C.sregs("v_pk_fma_f32 v[58:59], v[110:111], s[94:95], v[142:143] op_sel_hi:[1,0,1]") == {94}
+    assert C.sregs("v_pk_fma_f32 v[58:59], v[110:111], s[94:95], v[142:143]") == {94, 95}
+    assert C.sregs("v_pk_fma_f32 v[58:59], v[110:111], s[94:95], v[142:143] op_sel:[0,1,0] op_sel_hi:[1,1,1]") == {95}
+    assert C.sregs("v_pk_mul_f32 v[6:7], s[94:95], v[58:59] op_sel_hi:[0,1]") == {94}
+    assert C.sregs("v_mov_b64_e32 v[2:3], s[94:95]") == {94, 95} and C.sregs("s_add_i32 s0, s95, s0") == {0, 95}
+
+
 def test_no_instruction_touches_an_mfma_result_in_flight():
     """Inline-asm outputs allocated to the dead rows of an MFMA result are overwritten by its late write-back (hipcc pads nothing
     in front of inline asm): round 4's lane = image CNN kernel lost operand bytes that way, one image in 50,000."""
