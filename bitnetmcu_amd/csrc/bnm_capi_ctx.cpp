@@ -226,6 +226,9 @@ int ctx_build(bnm_ctx *c) {
         HIP_TRY(hipMemset(q, 0, (size_t)16 * 4 * BNM_WORK_DUMMY_WAVES));
         c->idle_words = (uint32_t *)q;
         if (int e = work_blocks_grow(c)) return e;
+        if (int e = dev_alloc(c, &q, 8)) return e;
+        HIP_TRY(hipMemset(q, 0, 8));
+        c->nonfinite = (unsigned long long *)q;
     }
     const uint32_t in_width = width;
     bool all_known = true, any_fp130 = false, all_tern = true;
@@ -536,6 +539,18 @@ int bnm_ctx_float_fused(const bnm_ctx *c) {
     if (c->float_mode == 2 || c->path != BNM_PATH_FUSED_MFMA) return 0;
     if (c->model.kind == BNM_KIND_CNN) return (c->cnn_fused_ok && c->cnn_fuse_tail && c->cnn_variant == 3) ? 1 : 0;
     return c->f32_ok ? 1 : 0;
+}
+
+int bnm_ctx_float_nonfinite(bnm_ctx *c, uint64_t *count) {
+    if (!c || !count) return fail(BNM_EINVAL, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    DeviceGuard dg(c->device);
+    HIP_TRY(dg.err);
+    HIP_TRY(hipDeviceSynchronize());      // (every stream the context was used on: the counter is fed by kernels)
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, c->nonfinite, sizeof v, hipMemcpyDeviceToHost));
+    *count = (uint64_t)v;
+    return BNM_OK;
 }
 
 int bnm_ctx_set_work_batch(bnm_ctx *c, int tiles) {

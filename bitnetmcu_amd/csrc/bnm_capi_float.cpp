@@ -6,11 +6,16 @@ using namespace bnm_internal;
 
 extern "C" {
 
-int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_out, void *stream) {
+int bnm_quantize_input_counted_device(const float *d_x, uint64_t n, int8_t *d_out, uint64_t *d_nonfinite, void *stream) {
     if (n && (!d_x || !d_out)) return fail(BNM_EINVAL, "null pointer");
     if (((uintptr_t)d_x & 15u) || ((uintptr_t)d_out & 3u)) return fail(BNM_EINVAL, "d_x must be 16-byte aligned");
-    HIP_TRY(bnmk_quantize_input(d_x, n, d_out, (hipStream_t)stream));
+    if ((uintptr_t)d_nonfinite & 7u) return fail(BNM_EINVAL, "d_nonfinite must be 8-byte aligned");
+    HIP_TRY(bnmk_quantize_input(d_x, n, d_out, (unsigned long long *)d_nonfinite, (hipStream_t)stream));
     return BNM_OK;
+}
+
+int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_out, void *stream) {
+    return bnm_quantize_input_counted_device(d_x, n, d_out, nullptr, stream);
 }
 
 int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d_cls, int32_t *d_logits, void *stream) {
@@ -28,7 +33,7 @@ int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d
         uint32_t *block = nullptr;
         if (int e = work_block(c, s, &block)) return e;
         HIP_TRY(bnmk_fused_f32(c->gdesc, c->shape.dbl, c->f32_groups, c->grid_blocks, d_x, n, c->gfrags, d_cls, d_logits, block,
-                               c->work_batch, s));
+                               c->work_batch, c->nonfinite, s));
         c->last_kernel = "fused_fc_f32_kernel";
         return BNM_OK;
     }
@@ -37,7 +42,7 @@ int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d
         uint32_t *block = nullptr;
         if (int e = work_block(c, s, &block)) return e;
         HIP_TRY(bnmk_cnn_li_fused(d_x, true, n, c->cnn_li_frags, c->cnn_li_bias, c->channels, c->cnn_li_plane2, c->cnn_li_pipe, c->gfrags, c->gdesc, c->shape.dbl, d_cls, d_logits,
-                                  block, c->cnn_li_grab, s));
+                                  block, c->cnn_li_grab, c->nonfinite, s));
         c->last_kernel = c->cnn_li_pipe ? "cnn_li_fused_pipe_kernel<float>" : "cnn_li_fused_kernel<float>";
         return BNM_OK;
     }
@@ -48,7 +53,7 @@ int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uint32_t *d
     if (int e = q8.ensure((size_t)(n < chunk ? n : chunk) * 256 + 64)) return e;
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t cn = n - off < chunk ? n - off : chunk;
-        HIP_TRY(bnmk_quantize_input(d_x + off * 256, cn, (int8_t *)q8.p, s));
+        HIP_TRY(bnmk_quantize_input(d_x + off * 256, cn, (int8_t *)q8.p, c->nonfinite, s));
         if (int e = infer_device_locked(c, (const int8_t *)q8.p, cn, d_cls + off, d_logits ? d_logits + off * ncls : nullptr, nullptr, 0, s))
             return e;
     }

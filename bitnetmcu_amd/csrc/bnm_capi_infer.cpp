@@ -171,7 +171,7 @@ int infer_device_locked(bnm_ctx *c, const int8_t *d_images, uint64_t n, uint32_t
         uint32_t *block = nullptr;
         if (int e = work_block(c, s, &block)) return e;
         HIP_TRY(bnmk_cnn_li_fused(d_images, false, n, c->cnn_li_frags, c->cnn_li_bias, c->channels, c->cnn_li_plane2, c->cnn_li_pipe, c->gfrags, c->gdesc, c->shape.dbl, d_cls, d_logits,
-                                  block, c->cnn_li_grab, s));
+                                  block, c->cnn_li_grab, nullptr, s));
         c->last_kernel = c->cnn_li_pipe ? "cnn_li_fused_pipe_kernel" : "cnn_li_fused_kernel";
         return BNM_OK;
     }

@@ -188,6 +188,7 @@ struct bnm_ctx {
     // (the graph may be replayed on any stream, next to eager launches on the capturing one).
     std::vector<uint32_t *> work_free;               // blocks not handed out yet (zeroed)
     std::map<hipStream_t, uint32_t *> work_of;       // stream -> its block
+    unsigned long long *nonfinite = nullptr;   // float calls: images that held a NaN or an infinity so far (bnm_ctx_float_nonfinite)
     uint32_t *idle_words = nullptr;   // fused variant 6: one word per resident wave for the loop's zero-adds (never changes value)
     bool tern_dynamic = true;
     uint32_t work_batch = 0;      // tiles / pairs a wave of the fused kernels takes from the work counter at a time (0 = kernel default)

@@ -36,7 +36,7 @@ template <bool DBL, bool FLT, bool P2>
 __global__ __launch_bounds__(64 * (FLT ? LI_WAVES_F32 : LI_WAVES)) void cnn_li_fused_kernel(const int8_t *__restrict__ images, uint32_t n, const i32x4 *__restrict__ frags,
                                                                      const int *__restrict__ bias, uint32_t C, const char *__restrict__ tail_frags,
                                                                      BnmGenericDesc d, uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out,
-                                                                     uint32_t *__restrict__ counter, uint32_t grab) {
+                                                                     uint32_t *__restrict__ counter, uint32_t grab, unsigned long long *__restrict__ nonfinite) {
 #include "bnm_cnn_li_fused_body.inc"
 }
 
@@ -46,7 +46,7 @@ template <bool DBL, bool FLT, bool P2>
 __global__ __launch_bounds__(64 * LI_WAVES_PIPE) void cnn_li_fused_pipe_kernel(const int8_t *__restrict__ images, uint32_t n, const i32x4 *__restrict__ frags,
                                                                      const int *__restrict__ bias, uint32_t C, const char *__restrict__ tail_frags,
                                                                      BnmGenericDesc d, uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out,
-                                                                     uint32_t *__restrict__ counter, uint32_t grab) {
+                                                                     uint32_t *__restrict__ counter, uint32_t grab, unsigned long long *__restrict__ nonfinite) {
 #define LI_TILE_BODY "bnm_cnn_li_tile_body_pipe.inc"
 #include "bnm_cnn_li_fused_body.inc"
 }
@@ -62,14 +62,15 @@ bool bnmk_cnn_li_fused_supported(uint32_t C, const BnmGenericDesc &d) {
 
 hipError_t bnmk_cnn_li_fused(const void *images, bool float_images, uint64_t n, const void *frags, const int *bias, uint32_t C, bool plane2, bool pipe,
                              const void *tail_frags, const BnmGenericDesc &d, bool dbl, uint32_t *cls, int32_t *logits, uint32_t *counter, uint32_t grab,
-                             hipStream_t s) {
+                             unsigned long long *nonfinite, hipStream_t s) {
     if (!n) return hipSuccess;
     uint32_t waves = bnmk_cnn_li_waves(C);
     const uint32_t cap_waves = pipe ? (uint32_t)LI_WAVES_PIPE : float_images ? (uint32_t)LI_WAVES_F32 : (uint32_t)LI_WAVES;
     if (waves > cap_waves) waves = cap_waves;
     if (!bnmk_cnn_li_fused_supported(C, d) || !counter || !cls || n >= (1ull << 31)) return hipErrorInvalidValue;
     if (!grab) grab = 1;
-    typedef void (*fn_t)(const int8_t *, uint32_t, const i32x4 *, const int *, uint32_t, const char *, BnmGenericDesc, uint32_t *, int32_t *, uint32_t *, uint32_t);
+    typedef void (*fn_t)(const int8_t *, uint32_t, const i32x4 *, const int *, uint32_t, const char *, BnmGenericDesc, uint32_t *, int32_t *, uint32_t *, uint32_t,
+                         unsigned long long *);
     static const fn_t table[16] = {cnn_li_fused_kernel<false, false, false>, cnn_li_fused_kernel<true, false, false>, cnn_li_fused_kernel<false, true, false>,
                                    cnn_li_fused_kernel<true, true, false>,   cnn_li_fused_kernel<false, false, true>, cnn_li_fused_kernel<true, false, true>,
                                    cnn_li_fused_kernel<false, true, true>,   cnn_li_fused_kernel<true, true, true>,
@@ -97,6 +98,6 @@ hipError_t bnmk_cnn_li_fused(const void *images, bool float_images, uint64_t n, 
     uint64_t blocks = (tiles + per_block - 1) / per_block;
     if (blocks > cap) blocks = cap;
     fn<<<dim3((unsigned)blocks), dim3(64 * waves_now), waves_now * C * 160u, s>>>((const int8_t *)images, (uint32_t)n, (const i32x4 *)frags, bias, C, (const char *)tail_frags, d,
-                                                                                 cls, logits, counter, grab);
+                                                                                 cls, logits, counter, grab, nonfinite);
     return hipGetLastError();
 }

@@ -5,7 +5,8 @@
 
 #define DECL(NAME)                                                                                                             \
     hipError_t NAME(uint32_t sp, bool dbl, unsigned blocks, unsigned threads, unsigned lds, hipStream_t s, const float *x, uint64_t n, \
-                    const void *frags, const BnmGenericDesc &d, uint32_t *cls, int32_t *logits, uint32_t *counter, uint32_t batch)
+                    const void *frags, const BnmGenericDesc &d, uint32_t *cls, int32_t *logits, uint32_t *counter, uint32_t batch, \
+                    unsigned long long *nonfinite)
 DECL(bnmk_f32_launch_m2_g4);
 DECL(bnmk_f32_launch_m2_g2);
 DECL(bnmk_f32_launch_m4_g2);
@@ -16,7 +17,7 @@ namespace {
 constexpr uint32_t kLdsBytes = 160u * 1024u;
 constexpr uint32_t kWavesPerSimd = 2;      // every instantiation is compiled for two waves per SIMD (256 VGPRs)
 typedef hipError_t (*launch_fn)(uint32_t, bool, unsigned, unsigned, unsigned, hipStream_t, const float *, uint64_t, const void *,
-                                const BnmGenericDesc &, uint32_t *, int32_t *, uint32_t *, uint32_t);
+                                const BnmGenericDesc &, uint32_t *, int32_t *, uint32_t *, uint32_t, unsigned long long *);
 launch_fn launcher_of(uint32_t mmax, int groups) {
     if (mmax == 2) return groups == 2 ? bnmk_f32_launch_m2_g2 : bnmk_f32_launch_m2_g4;
     if (mmax == 4) return (groups == 0 || groups == 2) ? bnmk_f32_launch_m4_g2 : nullptr;
@@ -36,12 +37,12 @@ uint32_t f32_waves(const BnmGenericDesc &d, bool stage) {
 bool bnmk_fused_f32_supported(const BnmGenericDesc &d, bool dbl, int groups) {
     if (d.KT0 != 8 || (d.sp == 2 && dbl) || (d.sp != 1 && d.sp != 2)) return false;
     launch_fn f = launcher_of(d.mmax, groups);
-    if (!f || f(d.sp, dbl, 0, 0, 0, nullptr, nullptr, 0, nullptr, d, nullptr, nullptr, nullptr, 1) != hipSuccess) return false;
+    if (!f || f(d.sp, dbl, 0, 0, 0, nullptr, nullptr, 0, nullptr, d, nullptr, nullptr, nullptr, 1, nullptr) != hipSuccess) return false;
     return f32_waves(d, false) >= 4u;      // below one wave per SIMD the two-kernel path is the faster one
 }
 
 hipError_t bnmk_fused_f32(const BnmGenericDesc &d_in, bool dbl, int groups, int grid_blocks, const float *x, uint64_t n, const void *frags,
-                          uint32_t *cls, int32_t *logits, uint32_t *counter, uint32_t batch, hipStream_t s) {
+                          uint32_t *cls, int32_t *logits, uint32_t *counter, uint32_t batch, unsigned long long *nonfinite, hipStream_t s) {
     if (!bnmk_fused_f32_supported(d_in, dbl, groups)) return hipErrorInvalidValue;
     if (!n) return hipSuccess;
     if (n >= (1ull << 36) || !counter) return hipErrorInvalidValue;      // 32-bit tile indices in the kernel
@@ -58,5 +59,5 @@ hipError_t bnmk_fused_f32(const BnmGenericDesc &d_in, bool dbl, int groups, int 
     const uint64_t blocks = want < cap ? want : cap;
     const uint32_t words = ((blocks * waves) & 7ull) == 0ull ? 8u : 1u;
     return launcher_of(d.mmax, groups)(d.sp, dbl, (unsigned)blocks, 64u * waves, lds, s, x, n, frags, d, cls, logits, counter,
-                                       batch | (words << 16));
+                                       batch | (words << 16), nonfinite);
 }

@@ -22,8 +22,8 @@
 //     hipcc from contracting them into one fma: a single rounding would differ from numpy's two).  |x * scale| <= 127.00001,
 //     so the clip never acts.  Four such bytes are packed with v_perm_b32 and leave as ONE ds_write_b32 per image into the
 //     wave's int8 tile buffer, in the swizzled layout the generic kernel's B-operand reads expect.
-// Non-finite inputs: numpy's result for them is platform-defined; here an image with an infinite value quantises to zeros and
-// NaNs are not propagated.  Out of contract, as in bnm_quantize_input_device.
+// Non-finite inputs (out of contract): an image that holds a NaN or an infinity quantises to all zeros, numpy's result on x86, and is
+// counted (bnm_quantise_f32.hpp; bnm_ctx_float_nonfinite), as in bnm_quantize_input_device.
 #pragma once
 #include "bnm_fused_generic_kernel.hpp"
 #include "bnm_quantise_f32.hpp"
@@ -75,8 +75,10 @@ template <int MMAX, int SP, bool DBL, int NG, int WPS>
 __global__ __launch_bounds__(256 * WPS) void fused_fc_f32_kernel(const float *__restrict__ x, uint64_t n,
                                                                  const i32x4 *__restrict__ frags, BnmGenericDesc d,
                                                                  uint32_t *__restrict__ cls_out, int32_t *__restrict__ logits_out,
-                                                                 uint32_t *__restrict__ counter, uint32_t batch_arg) {
+                                                                 uint32_t *__restrict__ counter, uint32_t batch_arg,
+                                                                 unsigned long long *__restrict__ nonfinite) {
     constexpr int KT0 = 8, T = 1;
+    uint32_t bad_images = 0;
     using G = RowGeom<256>;
     static_assert(NG == 1 || NG == 2 || NG == 4, "a tile's four groups must map to fixed landing slots");
     const uint32_t batch = batch_arg & 0xFFFFu;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_f32_kernel(const float *__
             group_scales(land[slot], scale);
             uint32_t q[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) q[r] = quantise4(land[slot][r], scale[r]);
+            for (int r = 0; r < 8; r++) q[r] = quantise4_image(land[slot][r], scale[r], bad_images);
             // the slot is free: the tile's group g + NG, or group g + NG - 4 of the wave's next unit
             if constexpr (g + NG < 4) load_group(unit, g + NG, land[slot]);
             else if (next < n_units) load_group(next, g + NG - 4, land[slot]);
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_f32_kernel(const float *__
         next = nn;
         next_left = nn_left;
     }
+    report_nonfinite(nonfinite, bad_images);
     work_block_leave_s(counter, total_waves);   // the last wave to leave puts the counter block back to all-zero
 }
 
@@ -230,8 +233,9 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_f32_kernel(const float *__
 #define BNM_F32_LAUNCHER(NAME, MMAX, NG, WPS)                                                                                 \
     hipError_t NAME(uint32_t sp, bool dbl, unsigned blocks, unsigned threads, unsigned lds, hipStream_t s, const float *x,    \
                     uint64_t n, const void *frags, const BnmGenericDesc &d, uint32_t *cls, int32_t *logits, uint32_t *counter, \
-                    uint32_t batch) {                                                                                         \
-        typedef void (*fn_t)(const float *, uint64_t, const i32x4 *, BnmGenericDesc, uint32_t *, int32_t *, uint32_t *, uint32_t); \
+                    uint32_t batch, unsigned long long *nonfinite) {                                                          \
+        typedef void (*fn_t)(const float *, uint64_t, const i32x4 *, BnmGenericDesc, uint32_t *, int32_t *, uint32_t *, uint32_t, \
+                             unsigned long long *);                                                                          \
         fn_t fn = nullptr;                                                                                                    \
         if (sp == 1 && dbl) fn = fused_fc_f32_kernel<MMAX, 1, true, NG, WPS>;                                                 \
         else if (sp == 1) fn = fused_fc_f32_kernel<MMAX, 1, false, NG, WPS>;                                                  \
@@ -239,6 +243,6 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_f32_kernel(const float *__
         if (!fn) return hipErrorInvalidValue;                                                                                 \
         if (!blocks) return hipSuccess;                                                                                       \
         if (hipError_t err = bnm_generic_allow_big_lds((const void *)fn); err != hipSuccess) return err;                      \
-        fn<<<dim3(blocks), dim3(threads), lds, s>>>(x, n, (const i32x4 *)frags, d, cls, logits, counter, batch);              \
+        fn<<<dim3(blocks), dim3(threads), lds, s>>>(x, n, (const i32x4 *)frags, d, cls, logits, counter, batch, nonfinite);   \
         return hipGetLastError();                                                                                             \
     }

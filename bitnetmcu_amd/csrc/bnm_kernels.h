@@ -110,7 +110,7 @@ hipError_t bnmk_fused_generic(const BnmGenericDesc &d, bool dbl, int tiles, int 
 // whose weights leave LDS for at least one wave per SIMD.  groups: 8-image groups in flight per wave (0 = default; 2 or 4).
 bool bnmk_fused_f32_supported(const BnmGenericDesc &d, bool dbl, int groups);
 hipError_t bnmk_fused_f32(const BnmGenericDesc &d, bool dbl, int groups, int grid_blocks, const float *d_x, uint64_t n, const void *d_frags,
-                          uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t batch, hipStream_t s);
+                          uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t batch, unsigned long long *d_nonfinite, hipStream_t s);
 
 // ---- layer-wise ALU kernels (bit-serial unpack + wave-shuffle reduction) ----------------------
 hipError_t bnmk_fc_layer(const int8_t *d_act, uint32_t act_stride, const void *d_packed, int32_t bpw,
@@ -161,7 +161,7 @@ bool bnmk_cnn_li_fused_supported(uint32_t C, const BnmGenericDesc &d);
 hipError_t bnmk_cnn_li_fused(const void *d_images, bool float_images, uint64_t n, const void *d_frags, const int *d_bias, uint32_t C, bool plane2, bool pipe,
                              const void *d_tail_frags,
                              const BnmGenericDesc &d, bool dbl, uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t grab,
-                             hipStream_t s);
+                             unsigned long long *d_nonfinite, hipStream_t s);
 constexpr int BNM_CNN_WTAB_DWORDS = 20;      // per (band, channel); 2 bands x C rounded up to 64 channels
 void bnm_cnn_weight_table(const int8_t *w1, const int8_t *w2, const int8_t *w3, uint32_t C, int *out);
 
@@ -198,7 +198,8 @@ hipError_t bnmk_diag_pipes(int mode, uint64_t tiles_per_wave, uint32_t *d_out, h
 #endif
 
 // ---- input quantisation: float32 [n][256] -> int8 [n][256] (test_inference.py:140-141) --------------
-hipError_t bnmk_quantize_input(const float *d_x, uint64_t n, int8_t *d_out, hipStream_t s);
+// nonfinite (optional): += the images that held a NaN or an infinity (they quantise to all zeros)
+hipError_t bnmk_quantize_input(const float *d_x, uint64_t n, int8_t *d_out, unsigned long long *d_nonfinite, hipStream_t s);
 
 // ---- QAT forward op (bnm_qat.hip) ---------------------------------------
 size_t bnmk_qat_workspace_bytes(uint32_t d, uint32_t k);

@@ -152,24 +152,27 @@ hipError_t bnmk_build_fragments(const int8_t *rows, uint32_t stride, uint32_t n_
 // One wavefront per image (256 floats = one float4 per lane); IEEE float32 divide / multiply and the round-to-nearest-even of a
 // float32 add (bnm_quantise_f32.hpp), so the result is bit-identical to numpy's float32 arithmetic.
 // =================================================================================================
-__global__ __launch_bounds__(256) void quantize_input_kernel(const float *__restrict__ x, uint64_t n, int8_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void quantize_input_kernel(const float *__restrict__ x, uint64_t n, int8_t *__restrict__ out,
+                                                            unsigned long long *__restrict__ nonfinite) {
     const int lane = threadIdx.x & 63;
+    uint32_t bad = 0;
     for (uint64_t img = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); img < n; img += (uint64_t)gridDim.x * 4u) {
         const f32x4 v = __builtin_nontemporal_load((const f32x4 *)(x + img * 256ull + 4u * lane));     // every byte is touched once
         uint32_t m = absmax4_bits(v);      // (non-negative floats order as unsigned integers)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = umax(m, (uint32_t)__shfl_xor((int)m, off));
-        // the same per-value arithmetic as the fused float-input kernels (bnm_quantise_f32.hpp): identical bytes for EVERY input,
-        // non-finite ones included (out of contract: numpy's own result for them is platform-defined)
-        __builtin_nontemporal_store(quantise4(v, quantise_scale(m)), (uint32_t *)(out + img * 256ull + 4u * lane));
+        // the same per-value arithmetic as the fused float-input kernels (bnm_quantise_f32.hpp): identical bytes for EVERY input -
+        // an image with a NaN or an infinity becomes all zeros (numpy's result on x86) and is counted
+        __builtin_nontemporal_store(quantise4_image(v, quantise_scale(m), bad), (uint32_t *)(out + img * 256ull + 4u * lane));
     }
+    report_nonfinite(nonfinite, bad);
 }
 
-hipError_t bnmk_quantize_input(const float *x, uint64_t n, int8_t *out, hipStream_t s) {
+hipError_t bnmk_quantize_input(const float *x, uint64_t n, int8_t *out, unsigned long long *nonfinite, hipStream_t s) {
     if (!n) return hipSuccess;
     uint64_t blocks = (n + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    quantize_input_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, n, out);
+    quantize_input_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(x, n, out, nonfinite);
     return hipGetLastError();
 }
 

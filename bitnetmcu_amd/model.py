@@ -251,6 +251,15 @@ class Context:
         L.check(self._lib, self._lib.bnm_ctx_set_float_mode(self._h, mode, groups), "bnm_ctx_set_float_mode")
 
     @property
+    def float_nonfinite(self):
+        """Images, over all float calls of this context so far, that held a NaN or an infinity: each was classified as the all-zero
+        image (what the reference's numpy quantisation makes of it on x86).  Synchronises the device (bnm_ctx_float_nonfinite)."""
+        import ctypes as C
+        v = C.c_uint64(0)
+        L.check(self._lib, self._lib.bnm_ctx_float_nonfinite(self._h, C.byref(v)), "bnm_ctx_float_nonfinite")
+        return int(v.value)
+
+    @property
     def float_fused(self):
         """True when float calls of this context run the one-kernel path now."""
         return self._lib.bnm_ctx_float_fused(self._h) == 1

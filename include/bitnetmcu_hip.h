@@ -243,10 +243,13 @@ BNM_API int bnm_unpack_layer_host(const void *weights, int32_t bits_per_weight, 
 
 /* Input quantisation on the GPU — the step the reference does in Python before every Inference() call
  * (test_inference.py:140-141; BitNetMCU.py:435-436): scale = 127/max(max|x|,1e-5), round half to even, clip.
- * d_x: float32 [n][256], d_out: int8 [n][256]; bit-identical to the numpy float32 formula for finite inputs (non-finite values are
- * outside the contract - numpy's own result for them is platform-defined; this kernel and the fused float-input kernels give the
- * same bytes for them: an image that holds an infinity quantises to zeros). */
+ * d_x: float32 [n][256], d_out: int8 [n][256]; bit-identical to the numpy float32 formula for finite inputs.  Non-finite values
+ * are outside the reference's contract (numpy's result for them is platform-defined): an image that holds a NaN or an infinity
+ * quantises to ALL ZEROS - what the reference's expression yields on x86 - in this kernel and in the fused float-input kernels alike,
+ * and is COUNTED: the _counted form adds the number of such images to *d_nonfinite (a device uint64 the caller zeroed; NULL = do not
+ * count), contexts keep the count themselves (bnm_ctx_float_nonfinite). */
 BNM_API int bnm_quantize_input_device(const float *d_x, uint64_t n, int8_t *d_out, void *stream);
+BNM_API int bnm_quantize_input_counted_device(const float *d_x, uint64_t n, int8_t *d_out, uint64_t *d_nonfinite, void *stream);
 /* The two steps of the reference's per-image Python flow (test_inference.py:140-150: quantise, then Inference()) for a batch of
  * float images resident on the GPU: d_x float32 [n][256] -> class ids (and the int32 logits if d_logits != NULL), asynchronous on
  * `stream`; the quantised images live in per-stream scratch of the context (allocated on first use: not under stream capture). */
@@ -262,6 +265,10 @@ BNM_API int bnm_infer_float_device(bnm_ctx *c, const float *d_x, uint64_t n, uin
  * groups (FC kernel only): 8-image groups of floats in flight per wave: 0 = default (4 in the 2-tile class, 2 in the 4-tile class, 1 in
  * the 6-tile class), 1, 2 or 4 where instantiated.  Results are identical in every mode. */
 BNM_API int bnm_ctx_set_float_mode(bnm_ctx *c, int mode, int groups);
+/* Float calls say when their input was out of contract: the number of images, over all bnm_infer_float_device calls of this context so
+ * far, that held a NaN or an infinity (each was classified as the all-zero image: see bnm_quantize_input_device).  Synchronises the
+ * device.  0 on a context that only ever saw finite images. */
+BNM_API int bnm_ctx_float_nonfinite(bnm_ctx *c, uint64_t *count);
 BNM_API int bnm_ctx_float_fused(const bnm_ctx *c);      /* 1: float calls of this context run one kernel now (CNN: those that take the one-kernel form); 0: two kernels */
 
 /* ---- QAT forward op ------------------------------------------------------
