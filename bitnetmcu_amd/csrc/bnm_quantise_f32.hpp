@@ -48,21 +48,22 @@ BNM_DEVICE uint32_t quantise4(const f32x4 &v, float scale, uint32_t &worst) {
 }
 
 // the four values of a lane belong to an image that occupies the WHOLE wave (one float4 per lane): its bytes, all zero when any lane
-// met a non-finite value; `count` (wave-uniform) counts such images
+// met a non-finite value; `count` counts such images - a VECTOR register holding the same number in every lane (the fused kernels'
+// scalar registers are spoken for: a scalar counter made hipcc move an outstanding work-counter take out of its register)
 BNM_DEVICE uint32_t quantise4_image(const f32x4 &v, float scale, uint32_t &count) {
     uint32_t worst = 0;
     const uint32_t q = quantise4(v, scale, worst);
-    const bool bad = __builtin_amdgcn_ballot_w64(worst > BNM_QUANT_FINITE_MAX) != 0ull;
-    count += bad ? 1u : 0u;
-    return bad ? 0u : q;
+    const uint32_t keep = __builtin_amdgcn_ballot_w64(worst > BNM_QUANT_FINITE_MAX) != 0ull ? 0u : ~0u;
+    uint32_t c = count;
+    asm("" : "+v"(c));
+    count = c + (1u & ~keep);
+    return q & keep;
 }
 
 // count > 0: one atomic per wave at the end of a kernel (non-finite images are out of contract: the add practically never happens)
 BNM_DEVICE void report_nonfinite(unsigned long long *counter, uint32_t count) {
-    if (counter && count) {
-        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        if (lane == 0) atomicAdd(counter, (unsigned long long)count);
-    }
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (counter && count && lane == 0) atomicAdd(counter, (unsigned long long)count);
 }
 
 }  // namespace
