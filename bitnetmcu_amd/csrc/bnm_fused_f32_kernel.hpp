@@ -163,8 +163,14 @@ __global__ __launch_bounds__(256 * WPS) void fused_fc_f32_kernel(const float *__
             float scale[8];
             group_scales(land[slot], scale);
             uint32_t q[8];
+            uint32_t worst = 0;      // over the group's eight images: two v_max3_u32 per register (bnm_quantise_f32.hpp)
 #pragma unroll
-            for (int r = 0; r < 8; r++) q[r] = quantise4_image(land[slot][r], scale[r], bad_images);
+            for (int r = 0; r < 8; r++) q[r] = quantise4(land[slot][r], scale[r], worst);
+            if (__builtin_amdgcn_ballot_w64(worst > BNM_QUANT_FINITE_MAX) != 0ull) {
+                // out of contract, practically never: some image of the group holds a NaN or an infinity - find which, zero and count it
+#pragma unroll
+                for (int r = 0; r < 8; r++) q[r] = quantise4_image(land[slot][r], scale[r], bad_images, (uint64_t)unit * 32ull + (uint64_t)(8 * g + r) < n);
+            }
             // the slot is free: the tile's group g + NG, or group g + NG - 4 of the wave's next unit
             if constexpr (g + NG < 4) load_group(unit, g + NG, land[slot]);
             else if (next < n_units) load_group(next, g + NG - 4, land[slot]);

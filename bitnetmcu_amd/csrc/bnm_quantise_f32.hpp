@@ -50,13 +50,14 @@ BNM_DEVICE uint32_t quantise4(const f32x4 &v, float scale, uint32_t &worst) {
 // the four values of a lane belong to an image that occupies the WHOLE wave (one float4 per lane): its bytes, all zero when any lane
 // met a non-finite value; `count` counts such images - a VECTOR register holding the same number in every lane (the fused kernels'
 // scalar registers are spoken for: a scalar counter made hipcc move an outstanding work-counter take out of its register)
-BNM_DEVICE uint32_t quantise4_image(const f32x4 &v, float scale, uint32_t &count) {
+// `counted`: the image is one of the call's (rows past the end of a ragged tile re-read the last image: zeroed alike, not counted)
+BNM_DEVICE uint32_t quantise4_image(const f32x4 &v, float scale, uint32_t &count, bool counted = true) {
     uint32_t worst = 0;
     const uint32_t q = quantise4(v, scale, worst);
     const uint32_t keep = __builtin_amdgcn_ballot_w64(worst > BNM_QUANT_FINITE_MAX) != 0ull ? 0u : ~0u;
     uint32_t c = count;
     asm("" : "+v"(c));
-    count = c + (1u & ~keep);
+    count = c + (counted ? 1u & ~keep : 0u);
     return q & keep;
 }
 
