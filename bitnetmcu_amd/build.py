@@ -45,6 +45,26 @@ SOURCES = (("bnm_fused_fc.hip", True), ("bnm_fused_regw.hip", True, ("-mllvm", "
 DIAG_SOURCES = (("bnm_diag.hip", True),)      # diagnostic library only (--diag / --diag-timing)
 
 
+_TOOL = None
+
+
+def tool_version():
+    """`hipcc --version`, once: a compiler upgrade must rebuild everything."""
+    global _TOOL
+    if _TOOL is None:
+        try:
+            _TOOL = subprocess.run([HIPCC, "--version"], capture_output=True, text=True, timeout=120).stdout
+        except Exception as e:      # no compiler: the compile step will say so
+            _TOOL = f"unknown ({e})"
+    return _TOOL
+
+
+def command_stamp(cmd):
+    """What an object was built WITH: the full compile command (flags, per-file flags, architecture, paths) + the compiler's version."""
+    import hashlib
+    return hashlib.sha1(("\x00".join(cmd) + "\x00" + tool_version()).encode()).hexdigest()
+
+
 def deps_of(obj):
     """Prerequisites recorded by the compiler (-MD) beside an object, or None when there is no record."""
     d = os.path.splitext(obj)[0] + ".d"
@@ -53,12 +73,16 @@ def deps_of(obj):
     text = open(d).read().replace("\\\n", " ")
     if ":" not in text:
         return None
-    return [t for t in text.split(":", 1)[1].split() if not t.startswith("/opt/rocm") and not t.startswith("/usr/")]
+    # make syntax: prerequisites separated by unescaped blanks, a blank inside a path written as "\ "
+    import re
+    deps = [t.replace("\\ ", " ") for t in re.split(r"(?<!\\)\s+", text.split(":", 1)[1].strip()) if t]
+    return [t for t in deps if not t.startswith("/opt/rocm") and not t.startswith("/usr/")]
 
 
 def objects(force=False, extra_flags=(), obj_dir=None, sources=SOURCES):
     """Compile what is out of date - a translation unit is rebuilt when one of the files IT includes (the compiler's -MD record)
-    is newer than its object; prints one 'build: compiled|reused <object>' line per translation unit so that a build log
+    is newer than its object, or when the object was built by ANOTHER COMMAND (flags, architecture, compiler version: the stamp
+    beside it, <object>.cmd); prints one 'build: compiled|reused <object>' line per translation unit so that a build log
     shows whether the compiler actually ran (BNM_FORCE_BUILD=1 or --force recompiles everything)."""
     obj_dir = obj_dir or OBJ
     force = force or os.environ.get("BNM_FORCE_BUILD") == "1"
@@ -69,23 +93,32 @@ def objects(force=False, extra_flags=(), obj_dir=None, sources=SOURCES):
         s = os.path.join(CSRC, src)
         o = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         deps = deps_of(o)
-        if force or deps is None or any(not os.path.exists(d) for d in deps) or newer([s] + deps, o):
-            if os.path.exists(o):
-                os.remove(o)          # a failed compile must not leave an older object behind for the link step
-            cmd = [HIPCC, f"--offload-arch={ARCH}"] + CXXFLAGS + list(extra_flags) + list(file_flags) + \
-                  ["-MD", "-MF", os.path.splitext(o)[0] + ".d", "-c", s, "-o", o]
-            if not is_hip:
-                cmd.insert(1, "-x")
-                cmd.insert(2, "hip")
-            jobs.append(cmd)
+        cmd = [HIPCC, f"--offload-arch={ARCH}"] + CXXFLAGS + list(extra_flags) + list(file_flags) + \
+              ["-MD", "-MF", os.path.splitext(o)[0] + ".d", "-c", s, "-o", o]
+        if not is_hip:
+            cmd.insert(1, "-x")
+            cmd.insert(2, "hip")
+        stamp_file, stamp = o + ".cmd", command_stamp(cmd)
+        same_command = os.path.exists(stamp_file) and open(stamp_file).read().strip() == stamp
+        if force or deps is None or not same_command or any(not os.path.exists(d) for d in deps) or newer([s] + deps, o):
+            for stale in (o, stamp_file):
+                if os.path.exists(stale):
+                    os.remove(stale)          # a failed compile must not leave an older object behind for the link step
+            jobs.append((cmd, stamp_file, stamp))
             print("build: compiled", os.path.relpath(o, HERE), flush=True)
         else:
             print("build: reused  ", os.path.relpath(o, HERE), flush=True)
         out.append(o)
+    def compile_one(job):
+        cmd, stamp_file, stamp = job
+        run(cmd)
+        with open(stamp_file, "w") as f:      # (written only after the compiler succeeded)
+            f.write(stamp + "\n")
+
     if jobs:   # translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
-            list(ex.map(run, jobs))
+            list(ex.map(compile_one, jobs))
     return out
 
 

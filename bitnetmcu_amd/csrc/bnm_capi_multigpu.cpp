@@ -6,7 +6,8 @@
 // library is bound with dlopen at run time, so neither its import library nor its headers are a build requirement.
 extern "C" {
 typedef struct ncclComm *ncclComm_t;
-typedef enum { ncclSuccess = 0 } ncclResult_t;      // (any other value is a failure: ncclGetErrorString says which)
+typedef int ncclResult_t;      // (an int, not an enum of one enumerator: every failure code must be a value the type can hold)
+enum { ncclSuccess = 0 };      // (any other value is a failure: ncclGetErrorString says which)
 typedef enum { ncclUint8 = 1, ncclUint64 = 5 } ncclDataType_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
 }
@@ -26,7 +27,8 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    bool ok() const { return CommInitAll && CommDestroy && Broadcast && AllReduce && GetErrorString; }
+    // (ncclCommAbort is part of the contract: the failure path must be able to leave a half-entered collective - without it the host transport runs)
+    bool ok() const { return CommInitAll && CommDestroy && CommAbort && Broadcast && AllReduce && GetErrorString; }
 };
 static const Rccl &rccl() {
     static Rccl r = [] {

@@ -5,9 +5,11 @@
 #   strong scaling: 10^8 images IN TOTAL, split into contiguous shards
 # and the single-process C entry point (one host thread + one RCCL communicator per GPU, bnm_run_synth_multi_gpu).
 # Output: one bench.py JSON line per run in gpurun_out/scale/{weak,strong}_N.json and a table on stdout; per-rank times are in
-# every line (per_rank_ms_per_step), so a straggler GPU shows.  usage: profiles/run_scale.sh [steps] [warmup]
+# every line (per_rank_ms_per_step), so a straggler GPU shows.  usage: profiles/run_scale.sh [steps] [warmup] [gpus needed]
+# Exit status: 0 = every run printed its line; 4 = fewer GPUs visible than the curve needs (default 2: a one-GPU box measures no
+# scaling - one line on stderr says so, nothing runs); 3 = some run gave up (its watchdog's one-line reason is repeated on stderr).
 set -u
-STEPS=${1:-20}; WARM=${2:-3}
+STEPS=${1:-20}; WARM=${2:-3}; NEED=${3:-2}
 REPO=$(cd "$(dirname "$0")/.." && pwd); OUT=$REPO/gpurun_out/scale; mkdir -p "$OUT"; cd "$REPO"
 NGPU=$(python - <<'PY'
 import torch
@@ -15,7 +17,12 @@ print(torch.cuda.device_count())
 PY
 )
 echo "GPUs visible: $NGPU"
+if [ "$NGPU" -lt "$NEED" ]; then
+  echo "run_scale: a scaling curve over $NEED or more GPUs was asked for and $NGPU device(s) are visible on this node - nothing measured" >&2
+  exit 4
+fi
 PORT=29517
+FAILED=0
 for N in 1 2 4 8; do
   [ "$N" -le "$NGPU" ] || continue
   for MODE in weak strong; do
@@ -25,6 +32,11 @@ for N in 1 2 4 8; do
       python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $PORT bench.py \
         --gpus "$N" --steps "$STEPS" --warmup "$WARM" --scaling $MODE > "$OUT/${MODE}_$N.json" 2> "$OUT/${MODE}_$N.err"
       PORT=$((PORT + 1))
+    fi
+    if ! grep -q '^{' "$OUT/${MODE}_$N.json"; then      # no JSON line: the run gave up - say why in one line (bitnetmcu_amd/dist.py's watchdog, or the last stderr line)
+      FAILED=3
+      REASON=$(grep -m1 '^bitnetmcu_amd.dist:' "$OUT/${MODE}_$N.err" || tail -n 1 "$OUT/${MODE}_$N.err")
+      echo "run_scale: $MODE scaling on $N GPU(s) printed no line: $REASON" >&2
     fi
   done
 done
@@ -68,3 +80,4 @@ used = L.bnm_run_synth_multi_gpu(m._h, 100_000_000, 0, 0, b.SEED_DIST_U, out, 10
 print(f"bnm_run_synth_multi_gpu: {used} GPU(s), transport {L.bnm_multi_gpu_transport().decode()}, 1e8 images in {secs.value * 1e3:.3f} ms "
       f"= {1e8 / secs.value:.4g} inferences/s, digest {hex(out[0])} (oracle: 0x81b56c9fafee6636)")
 PY
+exit $FAILED

@@ -137,3 +137,28 @@ def test_bench_line_is_short_enough_for_the_driver():
         big["extra_configs"][f"row_with_a_long_name_{i}"] = v
     with pytest.raises(AssertionError, match="bench line is"):
         bench.compact_line(big)
+
+
+def test_build_rebuilds_when_the_command_changes(tmp_path, capsys):
+    """an object is reused only when the files it includes are older than it AND it was built by the same command
+    (flags, architecture, compiler version - the stamp beside it); a changed flag or a foreign stamp recompiles."""
+    from bitnetmcu_amd import build
+    src = (("bnm_capi_model.cpp", False),)
+    d = str(tmp_path)
+
+    def status(**kw):
+        build.objects(obj_dir=d, sources=src, **kw)
+        out = capsys.readouterr().out
+        return "compiled" if "build: compiled" in out else "reused"
+    assert status() == "compiled" and status() == "reused"
+    assert status(extra_flags=("-DBNM_SOME_FLAG=1",)) == "compiled" and status(extra_flags=("-DBNM_SOME_FLAG=1",)) == "reused"
+    assert status() == "compiled"                                       # back to the first command: another object again
+    stamp = os.path.join(d, "bnm_capi_model.o.cmd")
+    open(stamp, "w").write("an object built by another compiler\n")
+    assert status() == "compiled" and status() == "reused"
+    os.remove(stamp)                                                    # no stamp: nothing is known about the object
+    assert status() == "compiled"
+    # the compiler's -MD record with an escaped blank in a path
+    with open(os.path.join(d, "x.d"), "w") as f:
+        f.write("x.o: /tmp/a\\ dir/one.h \\\n  /tmp/two.h /opt/rocm/include/hip/hip_runtime.h\n")
+    assert build.deps_of(os.path.join(d, "x.o")) == ["/tmp/a dir/one.h", "/tmp/two.h"]
