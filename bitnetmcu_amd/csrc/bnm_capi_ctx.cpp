@@ -426,6 +426,7 @@ int bnm_ctx_create(const bnm_model *m, int device, bnm_ctx **out) {
 void bnm_ctx_destroy(bnm_ctx *c) {
     if (!c) return;
     DeviceGuard dg(c->device);
+    persist_release(c);      // (a resident one-image kernel reads c->gfrags: it leaves before anything is freed)
     for (void *p : c->owned) (void)hipFree(p);
     for (auto &kv : c->scratch)
         for (DevBuf *b : {&kv.second.act_a, &kv.second.act_b, &kv.second.out32, &kv.second.cnn_feat, &kv.second.q8}) b->release(true);
@@ -583,6 +584,22 @@ int bnm_ctx_set_host_tuning(bnm_ctx *c, int mode, int copy_threads, int spin) {
     if ((unsigned)copy_threads != c->host_threads) { delete c->copier; c->copier = nullptr; }
     c->host_threads = (unsigned)copy_threads;
     c->lat_spin = spin != 0;
+    return BNM_OK;
+}
+
+int bnm_ctx_set_persistent(bnm_ctx *c, int mode, uint32_t idle_us) {
+    if (!c || mode < 0 || mode > 1 || (idle_us && (idle_us < 100u || idle_us > 10000000u))) return fail(BNM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    DeviceGuard dg(c->device);
+    HIP_TRY(dg.err);
+    if (mode == 1 && !(c->model.kind == BNM_KIND_FC && c->generic_ok && bnmk_persistent_supported(c->gdesc, c->shape.dbl)))
+        return fail(BNM_EUNSUPPORTED, "the resident one-image kernel serves FC models with 256-byte inputs whose layers are at most 192 wide");
+    if (idle_us && idle_us != c->persist_idle_us) {
+        persist_stop(c);      // (a running kernel carries the old limit)
+        c->persist_idle_us = idle_us;
+    }
+    if (mode == 0) persist_stop(c);
+    c->persist_mode = mode;
     return BNM_OK;
 }
 

@@ -32,6 +32,8 @@ namespace bnm_internal {
     } while (0)
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1u) / m * m; }
+void persist_stop(::bnm_ctx *c);         // bnm_capi_host.cpp: the resident one-image kernel leaves (and has left on return)
+void persist_release(::bnm_ctx *c);      // ... and its stream and mailbox are given back
 
 struct DevBuf {
     void *p = nullptr;
@@ -230,6 +232,13 @@ struct bnm_ctx {
     PinBuf lat_in, lat_cls, lat_logits;
     hipStream_t lat_stream = nullptr;
     bool lat_spin = true;            // poll the page-locked result words instead of waiting for the stream (bnm_ctx_set_host_tuning)
+    // the resident single-wave kernel of the one-image path (opt-in: BNM_PERSISTENT=1 or bnm_ctx_set_persistent; bnm_persist_kernel.hpp)
+    int persist_mode = -1;           // -1: not decided yet (the environment is read at the first one-image call), 0 off, 1 on
+    uint32_t persist_idle_us = 5000; // the kernel leaves by itself after this long without a call
+    PinBuf persist_box;              // its mailbox
+    hipStream_t persist_stream = nullptr;
+    bool persist_running = false;    // a kernel has been started and was not seen finished yet
+    uint32_t persist_seq = 0;        // sequence number of the last call
     unsigned host_threads = 0;       // staging-copy threads of the pipelined path (0 = default)
     int host_mode = 0;               // 0 pipelined page-locked staging, 1 the HIP runtime's own pageable copies (synchronous)
     struct HostSlot {

@@ -12,6 +12,13 @@ DECL(bnmk_f32_launch_m2_g2);
 DECL(bnmk_f32_launch_m4_g2);
 DECL(bnmk_f32_launch_m6_g1);
 #undef DECL
+#define DECLP(NAME)                                                                                                          \
+    hipError_t NAME(uint32_t sp, bool dbl, bool launch, unsigned lds, hipStream_t s, const void *frags, const BnmGenericDesc &d, \
+                    uint32_t *box, uint32_t seq0, uint64_t idle_ticks)
+DECLP(bnmk_persist_launch_m2);
+DECLP(bnmk_persist_launch_m4);
+DECLP(bnmk_persist_launch_m6);
+#undef DECLP
 
 namespace {
 constexpr uint32_t kLdsBytes = 160u * 1024u;
@@ -60,4 +67,24 @@ hipError_t bnmk_fused_f32(const BnmGenericDesc &d_in, bool dbl, int groups, int 
     const uint32_t words = ((blocks * waves) & 7ull) == 0ull ? 8u : 1u;
     return launcher_of(d.mmax, groups)(d.sp, dbl, (unsigned)blocks, 64u * waves, lds, s, x, n, frags, d, cls, logits, counter,
                                        batch | (words << 16), nonfinite);
+}
+
+// ---- the resident single-wave kernel behind Inference() (bnm_persist_kernel.hpp): the models the float-input kernel serves --------
+namespace {
+typedef hipError_t (*persist_fn)(uint32_t, bool, bool, unsigned, hipStream_t, const void *, const BnmGenericDesc &, uint32_t *, uint32_t, uint64_t);
+persist_fn persist_of(uint32_t mmax) {
+    return mmax == 2 ? bnmk_persist_launch_m2 : mmax == 4 ? bnmk_persist_launch_m4 : mmax == 6 ? bnmk_persist_launch_m6 : nullptr;
+}
+}  // namespace
+
+bool bnmk_persistent_supported(const BnmGenericDesc &d, bool dbl) {
+    if (d.KT0 != 8 || (d.sp == 2 && dbl) || (d.sp != 1 && d.sp != 2) || d.n_classes > 256u || d.w_bytes + 8192u > kLdsBytes) return false;
+    persist_fn f = persist_of(d.mmax);
+    return f && f(d.sp, dbl, false, 0, nullptr, nullptr, d, nullptr, 0, 0) == hipSuccess;
+}
+
+hipError_t bnmk_persistent_launch(const BnmGenericDesc &d, bool dbl, const void *frags, uint32_t *box, uint32_t seq0, uint64_t idle_ticks,
+                                  hipStream_t s) {
+    if (!bnmk_persistent_supported(d, dbl) || !box) return hipErrorInvalidValue;
+    return persist_of(d.mmax)(d.sp, dbl, true, d.w_bytes + 8192u, s, frags, d, box, seq0, idle_ticks);
 }

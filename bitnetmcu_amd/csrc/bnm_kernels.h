@@ -112,6 +112,12 @@ bool bnmk_fused_f32_supported(const BnmGenericDesc &d, bool dbl, int groups);
 hipError_t bnmk_fused_f32(const BnmGenericDesc &d, bool dbl, int groups, int grid_blocks, const float *d_x, uint64_t n, const void *d_frags,
                           uint32_t *d_cls, int32_t *d_logits, uint32_t *d_counter, uint32_t batch, unsigned long long *d_nonfinite, hipStream_t s);
 
+// the resident single-wave kernel behind Inference() (bnm_persist_kernel.hpp; opt-in): box = the device address of a page-locked
+// mailbox of 128 dwords, seq0 = the last sequence number already answered, idle_ticks of the 100 MHz wall clock without a call end it
+bool bnmk_persistent_supported(const BnmGenericDesc &d, bool dbl);
+hipError_t bnmk_persistent_launch(const BnmGenericDesc &d, bool dbl, const void *d_frags, uint32_t *box, uint32_t seq0, uint64_t idle_ticks,
+                                  hipStream_t s);
+
 // ---- layer-wise ALU kernels (bit-serial unpack + wave-shuffle reduction) ----------------------
 hipError_t bnmk_fc_layer(const int8_t *d_act, uint32_t act_stride, const void *d_packed, int32_t bpw,
                          uint32_t n_input, uint32_t n_output, int32_t *d_out, uint64_t batch,

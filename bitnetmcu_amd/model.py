@@ -187,6 +187,11 @@ class Context:
         """Drop the scratch buffers and the counter block the context keeps for `stream` (a torch.cuda.Stream); synchronises it."""
         L.check(self._lib, self._lib.bnm_ctx_release_stream(self._h, stream.cuda_stream), "bnm_ctx_release_stream")
 
+    def set_persistent(self, on=True, idle_us=0):
+        """One-image host calls (infer_host with n = 1: what Inference() runs) through a resident single-wave kernel and a page-locked
+        mailbox instead of a launch per call (bnm_ctx_set_persistent); the kernel leaves by itself after idle_us without a call."""
+        L.check(self._lib, self._lib.bnm_ctx_set_persistent(self._h, 1 if on else 0, idle_us), "bnm_ctx_set_persistent")
+
     def set_host_tuning(self, mode=0, copy_threads=0, spin=True):
         L.check(self._lib, self._lib.bnm_ctx_set_host_tuning(self._h, mode, copy_threads, 1 if spin else 0), "bnm_ctx_set_host_tuning")
 

@@ -169,6 +169,14 @@ BNM_API int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uin
                              int32_t *d_logits, void *stream);
 /* Drop what the context keeps for `stream` (scratch buffers, counter block) - call it before destroying a stream the context
  * was used on.  Synchronises the stream. */
+/* One-image calls (bnm_infer_host with n = 1 and no logits: what the drop-in Inference() symbol runs) through a RESIDENT single-wave
+ * kernel instead of a launch per call: the image and the class id travel through a page-locked mailbox, a call costs a PCIe round trip
+ * and the model's arithmetic, not a kernel launch.  mode 1 on / 0 off (a running kernel leaves before the call returns); default: off
+ * unless the environment says BNM_PERSISTENT=1 when the context meets its first one-image call.  The kernel leaves by itself after
+ * idle_us microseconds without a call (0 = keep: default 5000, or BNM_PERSISTENT_IDLE_US) - a hipDeviceSynchronize() anywhere in the
+ * process waits at most that long - and the next call starts another one.  Same results as every other path.  BNM_EUNSUPPORTED for
+ * models it does not serve (CNNs, inputs other than 256 bytes, layers wider than 192): their one-image calls stay launches. */
+BNM_API int bnm_ctx_set_persistent(bnm_ctx *c, int mode, uint32_t idle_us);
 BNM_API int bnm_ctx_release_stream(bnm_ctx *c, void *stream);
 /* Same with HOST pointers; synchronous.  Up to 64 images: zero-copy (page-locked buffers the GPU addresses directly, one launch,
  * results polled in place) — the path behind Inference().  Larger batches: two page-locked staging slots on two streams,

@@ -1,0 +1,121 @@
+"""the reference's own per-image loop (test_inference.py:136-168: one lib.Inference call per image) through a
+RESIDENT single-wave kernel and a page-locked mailbox instead of a kernel launch per call (opt-in: BNM_PERSISTENT=1 /
+bnm_ctx_set_persistent; csrc/bnm_persist_kernel.hpp).  Same class ids as the oracle; the kernel leaves by itself when idle, is
+restarted by the next call, never blocks a device synchronisation for longer than its idle limit, and is gone when its context is."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import bitnetmcu_amd as b
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["fc_4bitsym_64", "mcu_1k", "tern_96", "mcu_12k", "mcu_12k_fp130", "doc12k_binary", "doc12k_8bit"])
+def test_one_image_calls_through_the_resident_kernel_equal_the_oracle(name, gpu_ok, orc):
+    """Every tile class (2, 4, 6), both weight-plane counts (FP1.3.0's +128), 3- and 4-layer models; real-image-like and uniform data."""
+    model = util.load_golden_model(name)
+    ctx = b.Context(model)
+    ctx.set_persistent(True)
+    om = util.OracleModel(model, orc)
+    for dist in (b.DIST_U, b.DIST_M):
+        x = b.synth.images(1000, 1500, dist)
+        want = om.infer(x)
+        got = np.array([int(ctx.infer(x[i:i + 1])[0]) for i in range(len(x))], dtype=np.uint32)
+        assert ctx.last_kernel == "persistent_inference_kernel"
+        assert np.array_equal(got, want), (name, dist, int((got != want).sum()))
+    # a batch in between goes through a launch and the resident kernel carries on
+    xb = b.synth.images(0, 3000, b.DIST_U)
+    assert np.array_equal(ctx.infer(xb), om.infer(xb)) and ctx.last_kernel != "persistent_inference_kernel"
+    assert int(ctx.infer(xb[7:8])[0]) == int(om.infer(xb[7:8])[0]) and ctx.last_kernel == "persistent_inference_kernel"
+    ctx.close()
+
+
+def test_the_resident_kernel_leaves_when_idle_and_comes_back(gpu_ok, orc):
+    model = util.load_golden_model("fc_4bitsym_64")
+    om = util.OracleModel(model, orc)
+    ctx = b.Context(model)
+    ctx.set_persistent(True, idle_us=300)
+    x = b.synth.images(5, 64, b.DIST_U)
+    want = om.infer(x)
+    for rounds in range(6):
+        for i in range(8):
+            k = (8 * rounds + i) % 64
+            assert int(ctx.infer(x[k:k + 1])[0]) == int(want[k])
+        time.sleep(0.01)                       # > 30 idle limits: the kernel has left
+        t0 = time.perf_counter()
+        torch.cuda.synchronize()               # nothing resident: returns at once
+        assert time.perf_counter() - t0 < 0.05
+    # a long limit: a device synchronisation waits for the kernel, and no longer than the limit
+    ctx.set_persistent(True, idle_us=200_000)
+    assert int(ctx.infer(x[:1])[0]) == int(want[0])
+    t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    waited = time.perf_counter() - t0
+    assert 0.05 < waited < 1.0, waited
+    # switched off: the kernel leaves before the call returns; one-image calls are launches again
+    assert int(ctx.infer(x[1:2])[0]) == int(want[1])
+    t0 = time.perf_counter()
+    ctx.set_persistent(False)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.05
+    assert int(ctx.infer(x[2:3])[0]) == int(want[2]) and ctx.last_kernel != "persistent_inference_kernel"
+    # a context destroyed with its kernel resident
+    ctx.set_persistent(True, idle_us=5_000_000)
+    assert int(ctx.infer(x[3:4])[0]) == int(want[3])
+    t0 = time.perf_counter()
+    ctx.close()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.5
+
+
+def test_models_the_resident_kernel_does_not_serve_stay_launches(gpu_ok, orc):
+    model = util.load_golden_model("cnn_64")
+    ctx = b.Context(model)
+    with pytest.raises(b.BnmError):
+        ctx.set_persistent(True)
+    x = b.synth.images(0, 4, b.DIST_U)
+    assert np.array_equal(np.array([int(ctx.infer(x[i:i + 1])[0]) for i in range(4)], dtype=np.uint32), util.OracleModel(model, orc).infer(x))
+    ctx.close()
+
+
+DRIVER = r"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import bitnetmcu_amd as b
+lib = b.harness.load_inference_dll({dll!r})
+x = b.synth.images(0, 10000, b.DIST_M)
+b.harness.run_inference_loop(lib, x[:300])
+t0 = time.perf_counter()
+out = b.harness.run_inference_loop(lib, x)
+t1 = time.perf_counter()
+print(json.dumps({{"us_per_call": (t1 - t0) / len(x) * 1e6, "cls": out.tolist()}}))
+"""
+
+
+def test_the_drop_in_dll_with_the_flag_on_in_a_process_of_its_own(gpu_ok, orc):
+    """BNM_PERSISTENT=1 in the environment of a fresh process that only ever calls lib.Inference (the harness's loop, 10,000 images):
+    same class ids as without the flag and as the oracle, and the process EXITS cleanly with the kernel still resident."""
+    dll = os.path.join(util.REPO, "bitnetmcu_amd", "dlls", "fc_4bitsym_64", "Bitnet_inf.dll")
+    if not os.path.isfile(dll):
+        pytest.fail("bitnetmcu_amd/dlls/fc_4bitsym_64/Bitnet_inf.dll is missing: run __graft_entry__.build()")
+    import json
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, BNM_PERSISTENT=flag)
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, "-c", DRIVER.format(repo=util.REPO, dll=dll)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = json.loads(r.stdout.strip().splitlines()[-1])
+        res[flag]["process_s"] = time.perf_counter() - t0
+    want = util.OracleModel(util.load_golden_model("fc_4bitsym_64"), orc).infer(b.synth.images(0, 10000, b.DIST_M))
+    assert res["0"]["cls"] == want.tolist() and res["1"]["cls"] == want.tolist()
+    print({k: (round(v["us_per_call"], 2), round(v["process_s"], 1)) for k, v in res.items()})
+    assert res["1"]["us_per_call"] < res["0"]["us_per_call"]
