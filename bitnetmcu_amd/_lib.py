@@ -78,6 +78,7 @@ PROTOTYPES = {
     "bnm_ctx_float_fused": (C.c_int, [_vp]),
     "bnm_ctx_float_nonfinite": (C.c_int, [_vp, _u64p]),
     "bnm_ctx_set_persistent": (C.c_int, [_vp, C.c_int, C.c_uint32]),
+    "bnm_ctx_persistent_last_call": (C.c_int, [_vp, _u32p, _u32p]),
     "bnm_quantize_input_counted_device": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp]),
     "bnm_qat_workspace_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32]),
     "bnm_qat_bitconv2d_forward_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32,

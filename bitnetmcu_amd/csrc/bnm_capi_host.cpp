@@ -130,6 +130,16 @@ static int infer_host_persistent(bnm_ctx *c, const int8_t *image, uint32_t *cls)
     }
 }
 
+extern "C" int bnm_ctx_persistent_last_call(bnm_ctx *c, uint32_t *wall_10ns, uint32_t *shader_clocks) {
+    if (!c || !wall_10ns || !shader_clocks) return fail(BNM_EINVAL, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->persist_box.host) return fail(BNM_EINVAL, "no resident kernel has run on this context");
+    volatile uint32_t *box = (volatile uint32_t *)c->persist_box.host;
+    *wall_10ns = box[112];
+    *shader_clocks = box[113];
+    return BNM_OK;
+}
+
 static int infer_host_small(bnm_ctx *c, const int8_t *images, uint64_t n, uint32_t *cls, int32_t *logits) {
     const uint32_t ncls = c->model.num_classes();
     if (n == 1 && cls && !logits && persist_wanted(c)) {

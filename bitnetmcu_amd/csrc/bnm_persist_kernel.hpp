@@ -22,6 +22,7 @@
 constexpr uint32_t BNM_BOX_LINES = 5;         // request: dwords 16 L + k, k < 15 = image dword 15 L + k; dword 16 L + 15 = the tag
 constexpr uint32_t BNM_BOX_QUIT = 80;         // nonzero: leave
 constexpr uint32_t BNM_BOX_RESPONSE = 96;     // (sequence number << 8) | class id
+constexpr uint32_t BNM_BOX_STAMPS = 112;      // after the answer: what the call took inside the wave, tags seen -> answer stored: [100 MHz wall-clock ticks, shader clocks]
 constexpr uint32_t BNM_BOX_DWORDS = 128;
 
 template <int MMAX, int SP, bool DBL>
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(64) void persistent_inference_kernel(const i32x4 *_
             __builtin_amdgcn_s_sleep(1);
             continue;
         }
+        const uint64_t w0 = wall_clock64(), c0 = clock64();
         if (payload_a) *(uint32_t *)(smem + dst_a) = a;
         if (payload_b) *(uint32_t *)(smem + dst_b) = b;
         // ---- the FC stack on the tile (the generic kernel's code; image 0 is the call's, rows 1..31 are zero) -----------------------
@@ -102,6 +104,10 @@ __global__ __launch_bounds__(64) void persistent_inference_kernel(const i32x4 *_
         if (lane == 0) __hip_atomic_store(box + BNM_BOX_RESPONSE, (want << 8) | (cls[0] & 0xFFu), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         last = want;
         t0 = wall_clock64();
+        if (lane == 0) {      // (behind the answer: the host is already on its way)
+            box[BNM_BOX_STAMPS] = (uint32_t)(t0 - w0);
+            box[BNM_BOX_STAMPS + 1] = (uint32_t)(clock64() - c0);
+        }
     }
 }
 

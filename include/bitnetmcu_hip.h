@@ -177,6 +177,9 @@ BNM_API int bnm_infer_device(bnm_ctx *c, const int8_t *d_images, uint64_t n, uin
  * process waits at most that long - and the next call starts another one.  Same results as every other path.  BNM_EUNSUPPORTED for
  * models it does not serve (CNNs, inputs other than 256 bytes, layers wider than 192): their one-image calls stay launches. */
 BNM_API int bnm_ctx_set_persistent(bnm_ctx *c, int mode, uint32_t idle_us);
+/* What the resident kernel's last call took INSIDE the wave, request seen -> answer stored: ticks of the 100 MHz wall clock and shader
+ * clocks (their ratio is the shader clock the wave ran at: a single resident wave does not bring an idle GPU out of its low clocks). */
+BNM_API int bnm_ctx_persistent_last_call(bnm_ctx *c, uint32_t *wall_10ns, uint32_t *shader_clocks);
 BNM_API int bnm_ctx_release_stream(bnm_ctx *c, void *stream);
 /* Same with HOST pointers; synchronous.  Up to 64 images: zero-copy (page-locked buffers the GPU addresses directly, one launch,
  * results polled in place) — the path behind Inference().  Larger batches: two page-locked staging slots on two streams,

@@ -45,6 +45,19 @@ for spin in (True, False):
     for _ in range(3000):
         ctx.infer(one)
     res[f"bnm_infer_host_1_image_us_{'poll' if spin else 'stream_wait'}"] = (time.perf_counter() - t0) / 3000 * 1e6
+# ... and through the resident kernel (opt-in): the same call as a mailbox message; what the wave itself spent on it
+import ctypes as C
+ctx.set_persistent(True)
+for _ in range(500):
+    ctx.infer(one)
+t0 = time.perf_counter()
+for _ in range(3000):
+    ctx.infer(one)
+res["bnm_infer_host_1_image_us_resident_kernel"] = (time.perf_counter() - t0) / 3000 * 1e6
+w, sc = C.c_uint32(), C.c_uint32()
+b.load().bnm_ctx_persistent_last_call(ctx._h, C.byref(w), C.byref(sc))
+res["resident_kernel_inside_the_wave"] = {"us": w.value / 100.0, "shader_clocks": sc.value, "shader_MHz": sc.value / max(w.value, 1) * 100.0}
+ctx.set_persistent(False)
 dll = os.path.join(REPO, "bitnetmcu_amd", "dlls", "fc_4bitsym_64", "Bitnet_inf.dll")
 if os.path.isfile(dll):
     lib = b.harness.load_inference_dll(dll)
