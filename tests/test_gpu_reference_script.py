@@ -54,3 +54,34 @@ def test_the_unmodified_reference_script_drives_the_product_dll(gpu_ok):
     assert _c_side(out_product) == _c_side(expected), "C-side lines differ from the run recorded in the build container"
     assert len(_c_side(out_product)[3]) > 0       # (the two engines do disagree on some images: those lines carry the DLL's answers)
     print(out_product[-400:])
+
+
+SUBPROCESS_DRIVER = r"""
+import json, os, sys, time
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "oracle"))
+import refscript
+images, labels = refscript.synthetic_mnist()
+stage = refscript.STAGE
+t0 = time.perf_counter()
+out = refscript.run_script(os.path.join(stage, "test_inference.py"), os.path.join(stage, {kind!r}), stage, images, labels)
+print(json.dumps({{"seconds": time.perf_counter() - t0, "out": out}}))
+"""
+
+
+def test_the_unmodified_reference_script_with_the_resident_kernel(gpu_ok):
+    """the same unmodified script, in a process of its own whose environment says BNM_PERSISTENT=1 - every
+    lib.Inference call of its 10,000-image loop is a mailbox message to the resident kernel instead of a launch.  What it prints
+    must equal what it prints without the flag and against the reference's own DLL, and the process must exit cleanly."""
+    import subprocess
+    stage = refscript.STAGE
+    runs = {}
+    subprocess.run([sys.executable, "-c", "import torch, numpy"], timeout=600)      # (a fresh box pages the interpreter's libraries in once)
+    for tag, kind, flag in (("launch_per_call", "product", "0"), ("resident_kernel", "product", "1"), ("reference_dll", "ref", "0")):
+        r = subprocess.run([sys.executable, "-c", SUBPROCESS_DRIVER.format(repo=util.REPO, kind=kind)], capture_output=True, text=True,
+                           timeout=900, env=dict(os.environ, BNM_PERSISTENT=flag))
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        runs[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert runs["resident_kernel"]["out"] == runs["launch_per_call"]["out"] == runs["reference_dll"]["out"]
+    expected = open(os.path.join(stage, "expected_stdout.txt")).read()
+    assert _c_side(runs["resident_kernel"]["out"]) == _c_side(expected)
+    print({k: round(v["seconds"], 2) for k, v in runs.items()}, "seconds for the whole script (10,000 images: the reference's Python engine runs beside every call)")
