@@ -206,3 +206,39 @@ def test_fcmnist_module_forward_backward(gpu_ok):
     # a configuration the fused op does not serve runs layer by layer through BitLinear's op - same module, same result shape
     m2 = qat.FCMNIST(64, 64, 64, QuantType="4bitsym", NormType="BatchNorm").cuda()
     assert not m2.fused(xk) and m2(xk.detach()).shape == (x.shape[0] - 1, 10)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_random_model_shapes(seed, gpu_ok):
+    """Random stacks the kernel serves - 3 or 4 layers, hidden widths 1..128 (any, not only multiples of 32), 1..64 classes, every
+    int8-level QuantType, both norms, per-tensor and per-output clipping scalars, ragged batch sizes - against the restated reference
+    formula on torch's own fp32 kernels (pinned bit for bit to the reference module on CPU by tests/test_qat_cpu.py): logits and
+    hidden activations, the end-to-end tolerances of this file."""
+    rng = np.random.default_rng(1000 + seed)
+    n_hidden = int(rng.integers(2, 4))
+    hidden_w = [int(rng.integers(1, 129)) for _ in range(n_hidden)]
+    if seed % 5 == 0:
+        hidden_w = [int(rng.choice([32, 64, 96, 128])) for _ in range(n_hidden)]
+    widths = [256] + hidden_w + [int(rng.integers(1, 65))]
+    qt = ["Binary", "BinarySym", "Ternary", "2bitsym", "4bitsym", "5bitsym", "8bit"][seed % 7]
+    nt = "RMS" if seed % 3 else "Lin"
+    perout = seed % 4 == 1
+    n = int(rng.choice([1, 7, 32, 33, 257, 1000, 4097]))
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ws = [torch.randn(widths[l + 1], widths[l], device="cuda", generator=g) * 0.1 for l in range(len(widths) - 1)]
+    if perout:
+        ss = [w.abs().max(dim=-1).values.clamp(min=1e-5) / 0.25 * (0.5 + torch.rand(w.shape[0], device="cuda", generator=g)) for w in ws]
+    else:
+        ss = [(w.abs().mean() / 0.25).reshape(1) for w in ws]
+    x = torch.randn(n, 256, device="cuda", generator=g) * (torch.rand(n, 1, device="cuda", generator=g) * 3 + 0.02)
+    qts = [qt] * len(ws)
+    assert qat.fc_model_supported(widths, qts, nt), (widths, qt, nt)
+    logits, hidden = qat.fc_model_forward(x, ws, ss, qts, nt, return_hidden=True)
+    want_l, want_h = qat.fc_model_reference(x, ws, [s if perout else s[0] for s in ss], qts, nt)
+    for got, want, what in ((logits, want_l, "logits"), (hidden, want_h, "hidden")):
+        ok = ~torch.isnan(want).any(dim=1)          # (a row whose hidden layer came out all zero: NaN in both)
+        assert torch.equal(torch.isnan(got).any(dim=1), ~ok), (seed, what)
+        if ok.any():
+            scale = want[ok].abs().max(dim=1).values.clamp(min=1e-30)
+            err = (got[ok] - want[ok]).abs().max(dim=1).values / scale
+            assert (err <= 5e-4).float().mean() >= 0.9 and err.max() <= 6e-2, (seed, what, widths, qt, nt, perout, n, float(err.max()), float((err <= 5e-4).float().mean()))
