@@ -33,6 +33,9 @@
 #include "bnm_quantise_f32.hpp"
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace {
 
@@ -218,7 +221,7 @@ template <int MH, int NORM, bool PEROUT, bool HID, int NG, int WPS>
 __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float *__restrict__ x, uint64_t n,
                                                                      const i32x4 *__restrict__ image, QatModelDesc d,
                                                                      float *__restrict__ logits, float *__restrict__ hidden,
-                                                                     uint32_t n_classes, uint32_t *__restrict__ counter) {
+                                                                     uint32_t n_classes, uint32_t *__restrict__ counter, uint32_t batch) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -258,14 +261,23 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
         }
     };
 
-    // units in batches of QM_BATCH consecutive ones: a wave's first batch is static, later ones come from a device-wide counter (eight
-    // words, wave w takes from word w mod 8; zeroed by the prep kernel).  The loop runs one unit ahead because `next`'s loads start
+    // units in batches of `batch` consecutive ones (1 .. QM_BATCH: the launcher picks it so that a wave takes at least ~8 times - a call
+    // of 10^6 rows is 15 tiles per wave, and whole batches of four leave a quarter of the waves idle at the end): a wave's first batch
+    // is static, later ones come from a device-wide counter (eight words, wave w takes from word w mod 8; zeroed by the prep kernel).  The loop runs one unit ahead because `next`'s loads start
     // inside the current iteration; the take that decides next's successor is issued at the top and retired behind the quantisation.
-    constexpr uint32_t batch = QM_BATCH;
     const uint32_t my_word = wave_id & 7u, first_dyn = (total_waves + 7u) >> 3;
     uint32_t taken = 0;
     auto batch_first = [&](uint32_t t) { return (((first_dyn + t) << 3) + my_word) * batch; };
-    uint32_t unit = wave_id * batch, next = unit + 1u, next_left = batch - 2u;
+    uint32_t unit = wave_id * batch, next, next_left;
+    if (batch > 1u) {
+        next = unit + 1u;
+        next_left = batch - 2u;
+    } else {
+        work_take_issue(taken, counter + 16u * my_word, 1u);
+        work_take_wait(taken);
+        next = batch_first(taken);
+        next_left = 0u;
+    }
     if (unit < n_units) static_for<0, NG>([&](auto GI) { load_group(unit, decltype(GI)::value, land[decltype(GI)::value]); });
 
     while (unit < n_units) {
@@ -492,6 +504,19 @@ bool qat_model_plan(uint32_t n_layers, const uint32_t *widths, QatModelPlan &p) 
     return true;
 }
 
+// dynamic LDS beyond 64 KiB must be allowed per kernel and device, once (any host thread may be the first)
+hipError_t qat_allow_big_lds(const void *fn) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({fn, dev})) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert({fn, dev});
+    return e;
+}
+
 template <int MH, int NORM, bool PEROUT, bool HID, int NG, int WPS>
 hipError_t qat_model_launch_as(const QatModelDesc &d, const float *x, uint64_t n, const char *image, float *logits, float *hidden,
                                uint32_t n_classes, uint32_t *counter, hipStream_t st) {
@@ -499,17 +524,17 @@ hipError_t qat_model_launch_as(const QatModelDesc &d, const float *x, uint64_t n
     const unsigned threads = 256 * WPS, nwaves = threads / 64;
     const size_t lds = (size_t)d.image_bytes + (size_t)nwaves * 8192u + (size_t)nwaves * 128u;
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
-    static bool allowed = false;
-    if (!allowed) {
-        if (hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
-        allowed = true;
-    }
+    if (hipError_t e = qat_allow_big_lds((const void *)fn); e != hipSuccess) return e;
     const uint64_t units = (n + 31ull) >> 5;
     if (units >= (1ull << 31)) return hipErrorInvalidValue;      // 32-bit tile indices in the kernel
-    uint64_t blocks = (units + (uint64_t)nwaves * QM_BATCH - 1) / ((uint64_t)nwaves * QM_BATCH);
-    const uint64_t cus = (uint64_t)bnm_num_cus() * (WPS == 1 ? 2u : 1u);      // (one wave per SIMD: two workgroups of four waves per CU)
-    if (blocks > cus) blocks = WPS == 1 ? (cus & ~1ull) : cus;      // capped grids: waves a multiple of 8 (the counter's eight words)
-    fn<<<dim3((unsigned)blocks), dim3(threads), lds, st>>>(x, n, (const i32x4 *)image, d, logits, hidden, n_classes, counter);
+    // resident workgroups per CU: one of eight waves, or (one wave per SIMD) two of four where the LDS holds two
+    const uint64_t per_cu = (WPS == 1 && 2u * lds <= 160u * 1024u) ? 2u : 1u;
+    const uint64_t cap = (uint64_t)bnm_num_cus() * per_cu;
+    uint64_t batch = units / (cap * nwaves * 8u);      // tiles per take: at least ~8 takes per wave
+    batch = batch < 1u ? 1u : batch > QM_BATCH ? QM_BATCH : batch;
+    uint64_t blocks = (units + (uint64_t)nwaves * batch - 1) / ((uint64_t)nwaves * batch);
+    if (blocks > cap) blocks = (nwaves & 7u) ? (cap & ~1ull) : cap;      // capped grids: waves a multiple of 8 (the counter's eight words)
+    fn<<<dim3((unsigned)blocks), dim3(threads), lds, st>>>(x, n, (const i32x4 *)image, d, logits, hidden, n_classes, counter, (uint32_t)batch);
     return hipGetLastError();
 }
 
