@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--layerwise", action="store_true", help="also time the layer-by-layer path")
+    ap.add_argument("--hidden", action="store_true", help="also time the training form: hidden activations + w_int / w_scale written")
     a = ap.parse_args()
     torch.manual_seed(0)
     widths = [256] + [w for w in a.widths if w] + [a.classes]
@@ -49,6 +50,12 @@ def main():
     out = {"rows": a.rows, "widths": widths, "quant": a.quant, "norm": a.norm, "ms_median": float(np.median(ms)), "ms_min": float(np.min(ms)),
            "rows_per_s": a.rows / (np.median(ms) * 1e-3), "bytes_per_row": bpr, "GB/s": a.rows * bpr / (np.median(ms) * 1e-3) / 1e9,
            "hbm_frac": a.rows * bpr / (np.median(ms) * 1e-3) / 8e12}
+    if a.hidden:
+        ms3 = timed(lambda: qat.fc_model_forward(x, ws, ss, qts, a.norm, return_hidden=True, return_w_deq=True), a.steps, a.warmup)
+        hb = 4 * sum(widths[1:-1])
+        out["hidden_ms_median"] = float(np.median(ms3))
+        out["hidden_bytes_per_row"] = bpr + hb
+        out["hidden_hbm_frac"] = a.rows * (bpr + hb) / (np.median(ms3) * 1e-3) / 8e12
     if a.layerwise:
         def lw():
             h = x
