@@ -2,7 +2,7 @@
 // the FC stack behind CNNMNIST's Flatten, :120-135) - per layer BitLinear.forward (BitNetMCU.py:214-235: Normalize ->
 // activation_quant -> weight_quant -> F.linear) with ReLU between the layers - in ONE kernel per batch: float32 rows of 256 values
 // in, float32 logits out, nothing in between goes through HBM (optionally the hidden activations, which are what a backward pass
-// needs, are written once).  gfx950 only.  Floating point: parity with the reference module is within the tolerances
+// needs, are written once, as whole rows staged through LDS).  gfx950 only.  Floating point: parity with the reference module is within the tolerances
 // tests/test_gpu_qat_model.py states, not bit-exact.
 //
 //   qat_model_prep_kernel     16 workgroups per layer, once per call: weight_quant of the layer's float weights (the level of every
@@ -372,17 +372,48 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
                         else sum2 += v;
                         mx = __builtin_fmaxf(__builtin_fmaxf(mx, v[0]), v[1]);      // (v_max3_f32)
                     }
-                    if constexpr (HID) {
-                        if (row < n) {
-                            float *hp = hidden + row * d.hidden_stride + d.hidden_off[l] + 32u * (uint32_t)m + 4u * (uint32_t)h;
+                }
+            if constexpr (HID) {
+                // the layer's outputs y = u a leave as whole rows: two tiles (64 outputs: 256 bytes per row) at a time through the wave's
+                // LDS tile - free here: its int8 rows were consumed by layer 0's operand reads - in the int8 tile's own geometry
+                // (32 rows x sixteen 16-byte slots, slot s of row r stored at s ^ (r & 15): conflict-free both ways), then 16 lanes
+                // write a row's 256 consecutive bytes, four rows per instruction
+                const uint64_t first_row = (uint64_t)unit * 32ull;
+                const uint32_t width = d.width[l], hoff = d.hidden_off[l], hstride = d.hidden_stride;
+                const bool aligned = ((hoff | hstride) & 3u) == 0u && (((uintptr_t)hidden) & 15u) == 0u;
 #pragma unroll
-                            for (int q = 0; q < 4; q++)
+                for (int mp = 0; mp < (MH + 1) / 2; mp++)
+                    if ((uint32_t)(2 * mp) < d.M[l]) {
 #pragma unroll
-                                for (int b = 0; b < 4; b++)
-                                    if (32u * (uint32_t)m + 8u * (uint32_t)q + 4u * (uint32_t)h + (uint32_t)b < d.width[l]) hp[8 * q + b] = u[m][4 * q + b] * a;
+                        for (int mm = 0; mm < 2; mm++) {
+                            const int m = 2 * mp + mm;
+                            if (m < MH && (uint32_t)m < d.M[l]) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    const uint32_t slot = 8u * (uint32_t)mm + 2u * (uint32_t)q + (uint32_t)h;
+                                    const f32x4 v = {u[m][4 * q] * a, u[m][4 * q + 1] * a, u[m][4 * q + 2] * a, u[m][4 * q + 3] * a};
+                                    *(f32x4 *)(smem + tile_off + 256u * (uint32_t)j + 16u * (slot ^ ((uint32_t)j & 15u))) = v;
+                                }
+                            }
+                        }
+                        const uint32_t col = 64u * (uint32_t)mp + 4u * ((uint32_t)lane & 15u);      // this lane's four outputs of the layer
+#pragma unroll
+                        for (int it = 0; it < 8; it++) {
+                            const uint32_t r = 4u * (uint32_t)it + ((uint32_t)lane >> 4);
+                            const f32x4 v = *(const f32x4 *)(smem + tile_off + 256u * r + 16u * (((uint32_t)lane & 15u) ^ (r & 15u)));
+                            if (first_row + r < n && col < width) {
+                                float *hp = hidden + (first_row + r) * hstride + hoff + col;
+                                if (aligned && col + 4u <= width) {
+                                    *(f32x4 *)hp = v;
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; e++)
+                                        if (col + (uint32_t)e < width) hp[e] = v[e];
+                                }
+                            }
                         }
                     }
-                }
+            }
             const float sum = halves_sum(sum2[0] + sum2[1]);
             mx = halves_max(mx);
             float cq;
