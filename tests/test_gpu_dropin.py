@@ -79,11 +79,11 @@ np.save(sys.argv[4], out)
 """
 
 
-@pytest.mark.parametrize("name", ["fc_4bitsym_64", "cnn_64"])
-def test_dll_cold_start_from_eight_threads(name, gpu_ok, orc, tmp_path):
+@pytest.mark.parametrize("name,persistent", [("fc_4bitsym_64", "0"), ("cnn_64", "0"), ("fc_4bitsym_64", "1"), ("cnn_64", "1")])
+def test_dll_cold_start_from_eight_threads(name, persistent, gpu_ok, orc, tmp_path):
     """SURVEY 8(b) threading: the reference DLL is stateless and re-entrant; ours creates its GPU context on the first call.  Eight
     host threads make their FIRST Inference() call at the same time in a fresh process (ctypes releases the GIL) and go on
-    calling concurrently: every class id equals the oracle's."""
+    calling concurrently: every class id equals the oracle's - with a launch per call and with the resident kernels (round 6)."""
     import subprocess
     import sys
     dll = os.path.join(REPO, "bitnetmcu_amd", "dlls", name, "Bitnet_inf.dll")
@@ -94,7 +94,10 @@ def test_dll_cold_start_from_eight_threads(name, gpu_ok, orc, tmp_path):
     np.save(tmp_path / "x.npy", x)
     script = tmp_path / "cold.py"
     script.write_text(_COLD_START_SCRIPT)
-    subprocess.check_call([sys.executable, str(script), REPO, dll, str(tmp_path / "x.npy"), str(tmp_path / "out.npy")], timeout=300)
+    # persistent "1": BNM_PERSISTENT=1 in the process's environment - every thread's leased context starts its own resident
+    # one-image kernel (the FC model; the CNN model is not served by it and keeps its launches), the process exits with them resident
+    subprocess.check_call([sys.executable, str(script), REPO, dll, str(tmp_path / "x.npy"), str(tmp_path / "out.npy")], timeout=300,
+                          env=dict(os.environ, BNM_PERSISTENT=persistent))
     assert np.array_equal(np.load(tmp_path / "out.npy"), util.OracleModel(model, orc).infer(x))
 
 
