@@ -335,7 +335,6 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
         }
 
         // ---- the layers -----------------------------------------------------------------------------------------------------
-        const uint64_t row = (uint64_t)unit * 32ull + (uint64_t)j;
         float u[MH][16];          // relu(acc [* winv]) of the layer in hand
         i32x4 act[MH];            // its quantised form: the next layer's B operands
         float x_scale = xs[j];
