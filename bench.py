@@ -801,6 +801,11 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
                      "roofline": {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_row": bpr,
                                   "definition": "(1,024 B of float32 read + 4 B x classes written) x rows / the median time of a whole call (both launches)"}}
+        c = cj.get("qat_fc_model_fwd_kernel")
+        if c:      # a counter pass of the same kernel binary (code hash checked by load_counters), replayed
+            res[name]["roofline"].update({"traffic_bytes_per_row": c.get("hbm_bytes_per_image"), "valu_per_row": c.get("valu_per_image"),
+                                          "mfma_per_row": c.get("mfma_per_image"), "valu_busy_frac": c.get("valu_busy_frac"),
+                                          "counters_source": f"replayed from profiles/pmc_counters.json (pass {c.get('source')}, 1e7 rows per call; not measured by this run)"})
         del xq
         torch.cuda.empty_cache()
     if a.model == "fc_4bitsym_64" and n >= 1000:
