@@ -519,3 +519,58 @@ class FCMNIST(nn.Module):
             return self.classifier(self.model(x))
         ls = self.bitlinear_layers()
         return _FCModelFn.apply(x, ls[0].NormType, [m.QuantType for m in ls], len(ls), *[m.weight for m in ls], *[m.s for m in ls])
+
+
+class CNNMNIST(nn.Module):
+    """Stand-in for the reference's CNNMNIST (models.py:93-139; the model trainingparameters.yaml names): same constructor, same
+    module / parameter names (`model.0`, `model.2`, `model.5` the convolutions, `model.9`, `model.11`, `model.fc3`, `classifier`).
+    The depthwise-separable front runs layer by layer through `BitConv2d`'s fused op; the FC stack behind Flatten - 64 channels x 4
+    = 256 inputs - runs as ONE kernel (`fc_model_forward`: per-layer QuantTypes: 2bitsym first, then `QuantType`) where the fused op
+    serves the configuration, else layer by layer."""
+
+    def __init__(self, network_width1=64, network_width2=64, network_width3=64, cnn_width=64, QuantType="Binary", WScale="PerTensor",
+                 NormType="RMS", num_classes: int = 10):
+        super().__init__()
+        self.network_width1, self.network_width2, self.network_width3, self.cnn_width = network_width1, network_width2, network_width3, cnn_width
+        self.model = nn.Sequential(
+            BitConv2d(1, cnn_width, kernel_size=3, stride=1, padding=(0, 0), groups=1, QuantType="8bit", NormType="None", WScale=WScale),
+            nn.ReLU(),
+            BitConv2d(cnn_width, cnn_width, kernel_size=3, stride=1, padding=(0, 0), groups=cnn_width, QuantType="8bit", NormType="None", WScale=WScale),
+            nn.ReLU(),
+            nn.MaxPool2d(kernel_size=2, stride=2),
+            BitConv2d(cnn_width, cnn_width, kernel_size=3, stride=1, padding=(0, 0), groups=cnn_width, QuantType="8bit", NormType="None", WScale=WScale),
+            nn.ReLU(),
+            nn.MaxPool2d(kernel_size=2, stride=2),
+            nn.Flatten(),
+            BitLinear(cnn_width * 4, network_width1, QuantType="2bitsym", NormType=NormType, WScale=WScale),
+            nn.ReLU(),
+            BitLinear(network_width1, network_width2, QuantType=QuantType, NormType=NormType, WScale=WScale),
+            nn.ReLU())
+        if network_width3 > 0:
+            self.model.add_module("fc3", BitLinear(network_width2, network_width3, QuantType=QuantType, NormType=NormType, WScale=WScale))
+            self.model.add_module("relu_fc2", nn.ReLU())
+        last_width = network_width3 if network_width3 > 0 else network_width2
+        self.classifier = BitLinear(last_width, num_classes, QuantType=QuantType, NormType=NormType, WScale=WScale)
+
+    def front(self, x):
+        """the convolution front up to and including Flatten (models.py:109-119)"""
+        for m in list(self.model)[:9]:
+            x = m(x)
+        return x
+
+    def bitlinear_layers(self):
+        return [m for m in list(self.model)[9:] if isinstance(m, BitLinear)] + [self.classifier]
+
+    def fused(self, x):
+        """True when forward(x) runs the FC stack as the one-kernel op."""
+        ls = self.bitlinear_layers()
+        return x.is_cuda and fc_model_supported([ls[0].in_features] + [m.out_features for m in ls], [m.QuantType for m in ls], ls[0].NormType)
+
+    def forward(self, x):
+        f = self.front(x)
+        ls = self.bitlinear_layers()
+        if not self.fused(x):
+            for m in list(self.model)[9:]:
+                f = m(f)
+            return self.classifier(f)
+        return _FCModelFn.apply(f, ls[0].NormType, [m.QuantType for m in ls], len(ls), *[m.weight for m in ls], *[m.s for m in ls])

@@ -80,6 +80,27 @@ def main():
             out[f"{tag}/gx"] = grads[0].numpy()
             for l, g in enumerate(grads[1:]):
                 out[f"{tag}/gw{l}"] = g.numpy()
+    # ---- CNNMNIST (models.py:93-139; the model trainingparameters.yaml names), its widths: 96-64-0, 64 channels, 4bitsym / RMS ----
+    torch.manual_seed(20240419)
+    gen = torch.Generator().manual_seed(419)
+    cnn = ref.CNNMNIST(96, 64, 0, cnn_width=64, QuantType="4bitsym", WScale="PerTensor", NormType="RMS", num_classes=10)
+    qlayers = [m for m in list(cnn.model) + [cnn.classifier] if hasattr(m, "weight_quant")]
+    for m in qlayers:
+        m.update_clipping_scalar(m.weight.data, "octav", 0.25)
+    n = 45
+    x = images(n, gen)
+    x[ZERO_ROW] = x[ZERO_ROW + 1]                      # (no all-zero image here: its NaNs would poison the gradients)
+    xr = x.reshape(n, 1, 16, 16).clone().requires_grad_(True)
+    feats = []
+    hook = cnn.model[8].register_forward_hook(lambda mod, i, o: feats.append(o.detach().numpy().copy()))
+    logits = cnn(xr)
+    hook.remove()
+    gy = torch.randn(n, 10, generator=gen)
+    grads = torch.autograd.grad((logits * gy).sum(), [xr] + [m.weight for m in qlayers])
+    out["cnn/x"], out["cnn/logits"], out["cnn/features"], out["cnn/gy"], out["cnn/gx"] = x.numpy(), logits.detach().numpy(), feats[0], gy.numpy(), grads[0].numpy()
+    for l, (m, g) in enumerate(zip(qlayers, grads[1:])):
+        out[f"cnn/w{l}"], out[f"cnn/s{l}"], out[f"cnn/gw{l}"] = m.weight.detach().numpy(), m.s.detach().numpy().reshape(-1).astype(np.float32), g.numpy()
+    out["cnn/state_keys"] = np.array(sorted(cnn.state_dict().keys()))
     path = os.path.join(HERE, "qat_fc_model.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes;", {t: (out[f"{t}/logits"].shape, bool(np.isnan(out[f"{t}/logits"][ZERO_ROW]).all())) for t in CONFIGS})

@@ -201,3 +201,18 @@ def test_fcmnist_module_mirrors_the_reference_module():
         m(torch.randn(3, 1, 16, 16))
     with pytest.raises(RuntimeError, match="GPU op"):
         qat.fc_model_forward(torch.randn(3, 256), [torch.randn(8, 256), torch.randn(4, 8)], [torch.ones(1)] * 2, ["8bit"] * 2, "RMS")
+
+
+def test_cnnmnist_module_mirrors_the_reference_module():
+    """qat.CNNMNIST: the constructor and parameter names of models.py's CNNMNIST (the model trainingparameters.yaml names): a reference
+    checkpoint's state_dict loads; the fixture's weights go in by those names."""
+    m = qat.CNNMNIST(96, 64, 0, cnn_width=64, QuantType="4bitsym", WScale="PerTensor", NormType="RMS", num_classes=10)
+    assert sorted(m.state_dict()) == list(GM["cnn/state_keys"])
+    layers = [x for x in list(m.model) + [m.classifier] if hasattr(x, "weight_quant")]
+    assert [tuple(x.weight.shape) for x in layers] == [tuple(GM[f"cnn/w{l}"].shape) for l in range(6)]
+    assert [x.QuantType for x in layers] == ["8bit", "8bit", "8bit", "2bitsym", "4bitsym", "4bitsym"]
+    assert [x.out_features for x in m.bitlinear_layers()] == [96, 64, 10] and m.bitlinear_layers()[0].in_features == 256
+    m4 = qat.CNNMNIST(64, 64, 64, cnn_width=32)
+    assert "model.fc3.weight" in m4.state_dict() and m4.bitlinear_layers()[0].in_features == 128
+    with pytest.raises(RuntimeError, match="GPU op"):
+        m(torch.randn(2, 1, 16, 16))
