@@ -263,8 +263,9 @@ def test_cnnmnist_module_forward_backward(gpu_ok):
     """qat.CNNMNIST (the reference module's mirror; the model trainingparameters.yaml names) with the reference's weights: the
     convolution front layer by layer through BitConv2d's op, the FC stack behind Flatten (256-96-64-10, 2bitsym then 4bitsym) as the
     ONE-kernel op.  Against the reference module's own features, logits and autograd gradients (fixture), floating point: a conv
-    activation that flips one quantisation step moves its image row's outputs a little, so the bulk of the rows agree to 1e-3 of the
-    row's largest value and all to 0.1; gradients: median error 5e-3 of the largest entry, all within 0.25."""
+    activation that flips one quantisation step moves its image row's outputs a little: features - 85 % of the rows within 1e-4 of the
+    row's largest value, all within 5e-3; logits - the FC model's tolerances (90 % within 5e-4, all within 6e-2); gradients - median
+    error 2e-3 of the largest entry, all within 5e-2."""
     m = qat.CNNMNIST(96, 64, 0, cnn_width=64, QuantType="4bitsym", WScale="PerTensor", NormType="RMS", num_classes=10).cuda()
     layers = [x for x in list(m.model) + [m.classifier] if hasattr(x, "weight_quant")]
     with torch.no_grad():
@@ -273,22 +274,24 @@ def test_cnnmnist_module_forward_backward(gpu_ok):
             layer.s = torch.nn.Parameter(torch.from_numpy(GM[f"cnn/s{l}"]).reshape(()).cuda(), requires_grad=False)
     x = torch.from_numpy(GM["cnn/x"]).cuda().reshape(-1, 1, 16, 16).requires_grad_(True)
     assert m.fused(x)
-    feats = m.front(x.detach())
+    with torch.no_grad():
+        feats = m.front(x.detach())
     ref_f = GM["cnn/features"]
     ef = np.abs(feats.cpu().numpy() - ref_f).max(axis=1) / np.abs(ref_f).max(axis=1)
-    assert (ef <= 1e-3).mean() >= 0.8 and ef.max() <= 0.1, ((ef <= 1e-3).mean(), ef.max())
+    assert (ef <= 1e-4).mean() >= 0.85 and ef.max() <= 5e-3, ((ef <= 1e-4).mean(), ef.max())      # (measured: 96 % within 1e-5, max 6e-4)
     y = m(x)
     ref = GM["cnn/logits"]
     err = np.abs(y.detach().cpu().numpy() - ref).max(axis=1) / np.abs(ref).max(axis=1)
-    assert (err <= 2e-3).mean() >= 0.7 and err.max() <= 0.15, ((err <= 2e-3).mean(), err.max())
+    assert (err <= 5e-4).mean() >= 0.9 and err.max() <= 6e-2, ((err <= 5e-4).mean(), err.max())      # (measured: 98 %, max 9e-3)
     (y * torch.from_numpy(GM["cnn/gy"]).cuda()).sum().backward()
 
     def grad_close(got, want, what):
         e = np.abs(got - want) / np.abs(want).max()
-        assert np.median(e) <= 5e-3 and e.max() <= 0.25, (what, np.median(e), e.max())
+        assert np.median(e) <= 2e-3 and e.max() <= 5e-2, (what, np.median(e), e.max())      # (measured: medians <= 2.5e-4, max 1e-2)
     grad_close(x.grad.reshape(-1, 256).cpu().numpy(), GM["cnn/gx"].reshape(-1, 256), "gx")
     for l, layer in enumerate(layers):
         grad_close(layer.weight.grad.cpu().numpy(), GM[f"cnn/gw{l}"], f"gw{l}")
     # other channel counts: the FC stack's input is not 256 wide - layer by layer, same module
     m32 = qat.CNNMNIST(64, 64, 0, cnn_width=32, QuantType="4bitsym").cuda()
-    assert not m32.fused(x) and m32(x.detach()).shape == (x.shape[0], 10)
+    with torch.no_grad():
+        assert not m32.fused(x) and m32(x.detach()).shape == (x.shape[0], 10)
