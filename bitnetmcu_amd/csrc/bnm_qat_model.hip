@@ -29,6 +29,9 @@
 // squares are added in another order; the integer GEMM is exact where F.linear rounds.  A value that lands within ~1e-5 of a
 // rounding tie can therefore quantise one step away from the reference's.
 // A row whose layer input is all zero has den = 0: the reference divides 0 / 0 and the row's logits are NaN; so are they here.
+// NormType 'LayerNorm' (NORM 2): the row's mean first (one more merged reduction; hidden layers: one more pass over the lane's values,
+// the last tile's padding columns masked out), then everything above on d = x - mean; its epsilon is absolute, so the row constant
+// `a` enters the denominator (row_scalars_layernorm) - and keeps every row finite.  Compiled for one wave per SIMD.
 #include "bnm_qat_math.hpp"
 #include "bnm_quantise_f32.hpp"
 #include <cstdlib>
@@ -130,6 +133,17 @@ BNM_DEVICE void row_scalars(float sum, float mx, float inv_width, float &c, floa
     scale = c * den;
 }
 
+// NormType 'LayerNorm' (BitNetMCU.py:253-257): x_norm = (x - mean) / sqrt(var + 1e-5).  Called with the sum of squares and the maximum of
+// d = x - mean IN UNITS OF 1 / a (layer 1: a = 1; a hidden layer's outputs are y = a u): den = sqrt(a^2 sumsq / width + 1e-5) - the
+// epsilon is absolute, so a does not cancel here -, scale = 127 / max(a max|d| / den, 1e-5) and x_int = rne(d c) with c = a scale / den.
+// A constant row (d = 0) is not NaN: scale = 127 / 1e-5, every x_int 0.
+BNM_DEVICE void row_scalars_layernorm(float sumsq, float mx, float inv_width, float a, float &c, float &scale) {
+    const float den = __builtin_amdgcn_sqrtf(a * a * sumsq * inv_width + 1e-5f);
+    const float inv_den = __builtin_amdgcn_rcpf(den);
+    scale = 127.0f * __builtin_amdgcn_rcpf(fmaxf(a * mx * inv_den, 1e-5f));
+    c = a * scale * inv_den;
+}
+
 // rne(v c) of four values as four int8 in one dword (byte b = value b): v c + 1.5 * 2^23 as two v_pk_fma_f32 (the sum's ulp is 1, so
 // the fma rounds the exact product to the nearest integer, ties to even), the four low bytes gathered by v_perm_b32
 // (magic = {1.5 * 2^23, 1.5 * 2^23} in a VGPR pair of the caller: as a scalar-register pair the compiler places its undefined high half on
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(1024) void qat_model_prep_kernel(QatPrepArgs a, Qat
 }
 
 // ---- the model ----------------------------------------------------------------------------------------------------------------
-// MH: most 32-row tiles of any layer.  NORM 0 RMS / 1 Lin.  PEROUT: per-output clipping scalars (a multiplication per output more).
+// MH: most 32-row tiles of any layer.  NORM 0 RMS / 1 Lin / 2 LayerNorm.  PEROUT: per-output clipping scalars (a multiplication per output more).
 // HID: the hidden activations are written.  NG: 8-row landing groups in flight per wave.  WPS: waves per SIMD the register budget is
 // compiled for.
 //
@@ -286,12 +300,30 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
         // ---- layer 1's Normalize + activation_quant: four groups of 8 rows, registers -> int8 rows of the LDS tile ------------
         static_for<0, 4>([&](auto GI) {
             constexpr int g = decltype(GI)::value, slot = g % NG;
+            constexpr int kLane[8] = {0, 32, 16, 48, 8, 40, 24, 56};
             float sum[8];
             uint32_t mx[8];
+            if constexpr (NORM == 2) {
+                // LayerNorm: the rows' means first (the same merged reduction on plain sums), subtracted in place: land holds d = x - mean
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const f32x4 &v = land[slot][r];
+                    sum[r] = (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                const float t0 = fold32_add(sum[0], sum[1]), t1 = fold32_add(sum[2], sum[3]), t2 = fold32_add(sum[4], sum[5]), t3 = fold32_add(sum[6], sum[7]);
+                const float g0 = rowsum16(fold16_add(t0, t1)), g1 = rowsum16(fold16_add(t2, t3));
+                const float mean = ((lane & 8) ? g1 : g0) * (1.0f / 256.0f);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const float mr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), kLane[r]));
+                    f32x4 &v = land[slot][r];
+                    v[0] -= mr; v[1] -= mr; v[2] -= mr; v[3] -= mr;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const f32x4 &v = land[slot][r];
-                if constexpr (NORM == 0) {
+                if constexpr (NORM == 0 || NORM == 2) {
                     const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
                     const f32x2 sq = __builtin_elementwise_fma(hi, hi, lo * lo);
                     sum[r] = sq[0] + sq[1];
@@ -309,9 +341,9 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
             const float row_sum = (lane & 8) ? e1 : e0;
             const float row_max = __uint_as_float((lane & 8) ? f1 : f0);
             float cq, scale;
-            row_scalars<NORM>(row_sum, row_max, 1.0f / 256.0f, cq, scale);
+            if constexpr (NORM == 2) row_scalars_layernorm(row_sum, row_max, 1.0f / 256.0f, 1.0f, cq, scale);
+            else row_scalars<NORM>(row_sum, row_max, 1.0f / 256.0f, cq, scale);
             if ((lane & 7) == 0) xs[8 * g + (int)my_row] = scale;
-            constexpr int kLane[8] = {0, 32, 16, 48, 8, 40, 24, 56};
             uint32_t q[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -413,10 +445,35 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
                         }
                     }
             }
-            const float sum = halves_sum(sum2[0] + sum2[1]);
-            mx = halves_max(mx);
+            float sum = halves_sum(sum2[0] + sum2[1]);
             float cq;
-            row_scalars<NORM>(sum, mx, d.inv_width[l], cq, x_scale);
+            if constexpr (NORM == 2) {
+                // LayerNorm: d = u - mean over the layer's REAL outputs (the padding columns of the last tile hold u = 0, not d = 0:
+                // masked out), then the sum of squares and the maximum of d
+                const float mean = sum * d.inv_width[l];
+                const uint32_t width = d.width[l];
+                f32x2 sq2 = {0.0f, 0.0f};
+                mx = 0.0f;
+#pragma unroll
+                for (int m = 0; m < MH; m++)
+                    if ((uint32_t)m < d.M[l]) {
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const uint32_t col = 32u * (uint32_t)m + (uint32_t)(r & 3) + 8u * (uint32_t)(r >> 2) + 4u * (uint32_t)h;      // (r even: col + 1 is r + 1's)
+                            const f32x2 v = {col < width ? u[m][r] - mean : 0.0f, col + 1u < width ? u[m][r + 1] - mean : 0.0f};
+                            u[m][r] = v[0];
+                            u[m][r + 1] = v[1];
+                            sq2 = __builtin_elementwise_fma(v, v, sq2);
+                            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+                        }
+                    }
+                sum = halves_sum(sq2[0] + sq2[1]);
+                mx = halves_max(mx);
+                row_scalars_layernorm(sum, mx, d.inv_width[l], a, cq, x_scale);
+            } else {
+                mx = halves_max(mx);
+                row_scalars<NORM>(sum, mx, d.inv_width[l], cq, x_scale);
+            }
 #pragma unroll
             for (int m = 0; m < MH; m++)
                 if ((uint32_t)m < d.M[l]) {
@@ -458,9 +515,9 @@ __global__ __launch_bounds__(256 * WPS) void qat_fc_model_fwd_kernel(const float
                     to_float(l, m, acc, u[m]);
                 }
         };
-        relu_norm_quant(0, HID ? out_scale(0) : 0.0f);
+        relu_norm_quant(0, (HID || NORM == 2) ? out_scale(0) : 0.0f);
         for (uint32_t l = 1; l + 1u < d.n_layers; l++) {
-            const float a = HID ? out_scale(l) : 0.0f;      // (x_scale is the layer's INPUT scale here)
+            const float a = (HID || NORM == 2) ? out_scale(l) : 0.0f;      // (x_scale is the layer's INPUT scale here)
             layer(l);
             relu_norm_quant(l, a);
         }
@@ -580,8 +637,9 @@ hipError_t qat_model_launch(const QatModelDesc &d, const float *x, uint64_t n, c
         if (t && !strcmp(t, "21")) return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, 1>(d, x, n, image, logits, hidden, n_classes, counter, st);
     }
 #endif
-    // (the four-tile class with the hidden activations written needs more than 256 registers: one wave per SIMD there)
-    return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, (MH == 4 && HID) ? 1 : 2>(d, x, n, image, logits, hidden, n_classes, counter, st);
+    // (the four-tile class with the hidden activations written, and LayerNorm's second pass over the values, need more than 256
+    // registers: one wave per SIMD there)
+    return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, ((MH == 4 && HID) || NORM == 2) ? 1 : 2>(d, x, n, image, logits, hidden, n_classes, counter, st);
 }
 
 }  // namespace
@@ -596,7 +654,7 @@ bool bnmk_qat_model_supported(uint32_t n_layers, const uint32_t *widths, const i
     if (!qat_model_plan(n_layers, widths, p)) return false;
     for (uint32_t l = 0; l < n_layers; l++)
         if (!qat_i8_factor(quant_types[l])) return false;
-    return norm_type == BNM_QAT_NORM_RMS || norm_type == BNM_QAT_NORM_LIN;
+    return norm_type == BNM_QAT_NORM_RMS || norm_type == BNM_QAT_NORM_LIN || norm_type == BNM_QAT_NORM_LAYERNORM;
 }
 
 hipError_t bnmk_qat_model_forward(const float *x, uint64_t n, uint32_t n_layers, const uint32_t *widths, const float *const *w,
@@ -622,16 +680,18 @@ hipError_t bnmk_qat_model_forward(const float *x, uint64_t n, uint32_t n_layers,
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
     const uint32_t nc = widths[n_layers];
-    const int nt = norm_type == BNM_QAT_NORM_RMS ? 0 : 1;
+    const int nt = norm_type == BNM_QAT_NORM_RMS ? 0 : norm_type == BNM_QAT_NORM_LIN ? 1 : 2;
 #define QM_GO(MH, NORM, PO)                                                                                   \
     return hidden ? qat_model_launch<MH, NORM, PO, true>(p.d, x, n, image, logits, hidden, nc, counter, st) \
                   : qat_model_launch<MH, NORM, PO, false>(p.d, x, n, image, logits, hidden, nc, counter, st)
     if (p.mh == 2) {
         if (nt == 0) { if (perout) QM_GO(2, 0, true); else QM_GO(2, 0, false); }
-        else { if (perout) QM_GO(2, 1, true); else QM_GO(2, 1, false); }
+        else if (nt == 1) { if (perout) QM_GO(2, 1, true); else QM_GO(2, 1, false); }
+        else { if (perout) QM_GO(2, 2, true); else QM_GO(2, 2, false); }
     } else {
         if (nt == 0) { if (perout) QM_GO(4, 0, true); else QM_GO(4, 0, false); }
-        else { if (perout) QM_GO(4, 1, true); else QM_GO(4, 1, false); }
+        else if (nt == 1) { if (perout) QM_GO(4, 1, true); else QM_GO(4, 1, false); }
+        else { if (perout) QM_GO(4, 2, true); else QM_GO(4, 2, false); }
     }
 #undef QM_GO
 }

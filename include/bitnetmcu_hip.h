@@ -333,14 +333,14 @@ BNM_API int bnm_qat_bitconv2d_forward_device(const float *d_x, uint64_t n, uint3
  *   (PerOutput), quant_types[l] the layer's QuantType - d_w / d_s / s_count / quant_types / widths are HOST arrays (of device
  *   pointers where they hold pointers).
  *   quant_types: those whose levels (x 2 for the half-integer types) are int8 - Binary, BinarySym, Ternary, 2bitsym, 4bitsym,
- *   5bitsym, 8bit; norm_type: BNM_QAT_NORM_RMS or BNM_QAT_NORM_LIN (BatchNorm needs the whole batch per layer).  Anything else:
+ *   5bitsym, 8bit; norm_type: BNM_QAT_NORM_RMS, BNM_QAT_NORM_LIN or BNM_QAT_NORM_LAYERNORM (BatchNorm needs the whole batch per layer).  Anything else:
  *   BNM_EUNSUPPORTED (bnm_qat_model_supported tells beforehand) - run the layers one by one with bnm_qat_bitlinear_forward_device.
  *   d_x [n][256] float32 in, d_logits [n][classes] float32 out (16-byte aligned).  Optional: d_hidden [n][sum of the hidden widths]
  *   - every hidden layer's output after ReLU, i.e. the next layer's input, layer after layer within a row - and d_w_deq[l]
  *   [widths[l+1]][widths[l]] = w_int / w_scale: together with d_x what a straight-through backward pass needs.
  *   workspace: bnm_qat_model_workspace_bytes(n_layers, widths) bytes, 16-byte aligned, owned by the call's stream while it runs.
  * Floating point: within the tolerances of tests/test_gpu_qat_model.py of the reference module, not bit-exact.  A row whose input
- * to some layer is all zero gets NaN logits, as in the reference (0 / 0 in Normalize). */
+ * to some layer is all zero gets NaN logits, as in the reference (0 / 0 in Normalize; not under LayerNorm, whose epsilon keeps it finite). */
 #define BNM_QAT_MODEL_MAX_LAYERS 4
 BNM_API uint64_t bnm_qat_model_workspace_bytes(uint32_t n_layers, const uint32_t *widths);
 BNM_API int bnm_qat_model_supported(uint32_t n_layers, const uint32_t *widths, const int *quant_types, int norm_type);

@@ -26,6 +26,8 @@ CONFIGS = {
     "d": (128, 128, 128, "8bit", "PerTensor", "RMS", 47, 97, "octav"),        # four tiles per layer, two class tiles (EMNIST balanced)
     "e": (80, 40, 72, "2bitsym", "PerOutput", "RMS", 10, 41, "prop"),         # widths off the 32-row tiles, per-output clipping scalars
     "f": (64, 64, 64, "Binary", "PerTensor", "RMS", 10, 33, "octav"),
+    "g": (64, 64, 64, "4bitsym", "PerTensor", "LayerNorm", 10, 90, "octav"),  # LayerNorm: no NaN for the all-zero row (epsilon)
+    "h": (80, 40, 72, "8bit", "PerTensor", "LayerNorm", 47, 50, "octav"),     # ... with widths off the tiles (padding columns masked)
 }
 ZERO_ROW = 5
 
@@ -103,7 +105,7 @@ def main():
     out["cnn/state_keys"] = np.array(sorted(cnn.state_dict().keys()))
     path = os.path.join(HERE, "qat_fc_model.npz")
     np.savez_compressed(path, **out)
-    print(path, os.path.getsize(path), "bytes;", {t: (out[f"{t}/logits"].shape, bool(np.isnan(out[f"{t}/logits"][ZERO_ROW]).all())) for t in CONFIGS})
+    print(path, os.path.getsize(path), "bytes;", {t: (out[f"{t}/logits"].shape, bool(np.isnan(out[f"{t}/logits"][ZERO_ROW]).all()), bool(np.isnan(out[f"{t}/logits"]).any())) for t in CONFIGS})
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@ from util import GOLDEN
 pytestmark = pytest.mark.gpu
 GM = np.load(os.path.join(GOLDEN, "qat_fc_model.npz"))
 CONFIGS = {"a": ("4bitsym", "RMS"), "b": ("4bitsym", "RMS"), "c": ("Ternary", "Lin"), "d": ("8bit", "RMS"), "e": ("2bitsym", "RMS"),
-           "f": ("Binary", "RMS")}
+           "f": ("Binary", "RMS"), "g": ("4bitsym", "LayerNorm"), "h": ("8bit", "LayerNorm")}
 ZERO_ROW = 5
 TIE = 5e-4
 
@@ -48,6 +48,11 @@ def layer_f64(xin, w_q_levels, w_scale, nt):
     x = xin.astype(np.float32)
     if nt == "RMS":
         den = np.sqrt(np.mean(x.astype(np.float64) ** 2, axis=1, keepdims=True)).astype(np.float32)
+    elif nt == "LayerNorm":
+        x64 = x.astype(np.float64)
+        mean = x64.mean(axis=1, keepdims=True)
+        den = np.sqrt(((x64 - mean) ** 2).mean(axis=1, keepdims=True) + 1e-5).astype(np.float32)
+        x = (x64 - mean).astype(np.float32)
     else:
         den = np.mean(np.abs(x.astype(np.float64)), axis=1, keepdims=True).astype(np.float32)
     with np.errstate(all="ignore"):
@@ -74,7 +79,7 @@ def check(tag, n_rows=None):
     assert torch.equal(torch.nan_to_num(plain, nan=-7.0), torch.nan_to_num(logits, nan=-7.0))
     logits, hidden = logits.cpu().numpy(), hidden.cpu().numpy()
     rows = np.ones(n, bool)
-    if n > ZERO_ROW:
+    if n > ZERO_ROW and nt != "LayerNorm":      # (LayerNorm's epsilon keeps the all-zero row finite: it is checked like any other)
         rows[ZERO_ROW] = False
         assert np.isnan(logits[ZERO_ROW]).all(), tag
     assert not np.isnan(logits[rows]).any() and not np.isnan(hidden[rows]).any(), tag
@@ -144,6 +149,7 @@ def test_unsupported_configurations_are_refused_not_emulated(gpu_ok):
     assert not qat.fc_model_supported(widths, ["4bit"] * 4, "RMS")              # levels carry + 0.01: not int8
     assert not qat.fc_model_supported(widths, ["FP130"] * 4, "RMS")             # + 128 does not fit int8
     assert not qat.fc_model_supported(widths, ["4bitsym"] * 4, "BatchNorm")     # needs the whole batch per layer
+    assert qat.fc_model_supported(widths, ["4bitsym"] * 4, "LayerNorm")
     assert not qat.fc_model_supported([256, 200, 64, 64, 10], ["4bitsym"] * 4, "RMS")
     assert not qat.fc_model_supported([128, 64, 64, 64, 10], ["4bitsym"] * 4, "RMS")
     with pytest.raises(NotImplementedError):
@@ -221,7 +227,7 @@ def test_fuzz_random_model_shapes(seed, gpu_ok):
         hidden_w = [int(rng.choice([32, 64, 96, 128])) for _ in range(n_hidden)]
     widths = [256] + hidden_w + [int(rng.integers(1, 65))]
     qt = ["Binary", "BinarySym", "Ternary", "2bitsym", "4bitsym", "5bitsym", "8bit"][seed % 7]
-    nt = "RMS" if seed % 3 else "Lin"
+    nt = ("RMS", "Lin", "LayerNorm")[seed % 3]
     perout = seed % 4 == 1
     n = int(rng.choice([1, 7, 32, 33, 257, 1000, 4097]))
     g = torch.Generator(device="cuda").manual_seed(seed)

@@ -145,7 +145,7 @@ def test_backward_from_quantised_operands_equals_reference_gradients(qt, nt):
 # ---- whole model (models.py:56-90 FCMNIST): fixtures from the reference module itself (tests/golden/make_qat_model_golden.py) ----
 GM = np.load(os.path.join(GOLDEN, "qat_fc_model.npz"))
 MODEL_CONFIGS = {"a": ("4bitsym", "RMS"), "b": ("4bitsym", "RMS"), "c": ("Ternary", "Lin"), "d": ("8bit", "RMS"), "e": ("2bitsym", "RMS"),
-                 "f": ("Binary", "RMS")}
+                 "f": ("Binary", "RMS"), "g": ("4bitsym", "LayerNorm"), "h": ("8bit", "LayerNorm")}
 
 
 def model_case(tag):
@@ -165,7 +165,10 @@ def test_whole_model_formula_equals_the_reference_module(tag):
     x, ws, ss, _ = model_case(tag)
     logits, hidden = qat.fc_model_reference(x, ws, ss, [qt] * len(ws), nt)
     ref_logits, ref_hidden = GM[f"{tag}/logits"], GM[f"{tag}/hidden"]
-    assert np.isnan(ref_logits[5]).all() and not np.isnan(np.delete(ref_logits, 5, axis=0)).any()
+    if nt == "LayerNorm":      # (its epsilon keeps the all-zero row finite)
+        assert not np.isnan(ref_logits).any()
+    else:
+        assert np.isnan(ref_logits[5]).all() and not np.isnan(np.delete(ref_logits, 5, axis=0)).any()
     assert np.array_equal(logits.numpy(), ref_logits, equal_nan=True)
     assert np.array_equal(hidden.numpy(), ref_hidden, equal_nan=True)
     for l, w in enumerate(ws):
