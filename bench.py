@@ -97,8 +97,9 @@ def compact_line(out):
             r["mfma"]["busy_frac"] = sig(rf["mfma"]["busy_frac"], 4)
     if rf.get("counters_dropped"):
         r["counters_dropped"] = len(rf["counters_dropped"])
-    line = {k: sig(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                                     "scaling", "vs_baseline", "dtype", "data")}
+    # (the headline pair at full precision: whoever checks value against ms_per_step must not meet a rounding of the line's own making)
+    line = {k: (out[k] if k in ("value", "ms_per_step") else sig(out[k])) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                                                   "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     line["metric"] = line["metric"].replace(" (BitNetMCU_model_fc.h)", "")
     line["config"] = c
     line["roofline"] = r
