@@ -122,6 +122,7 @@ def test_bench_line_is_short_enough_for_the_driver():
         assert set(c["rows"]) == set(k for k, v in full["extra_configs"].items() if "roofline" in v)
         assert "workload" in c["config"] and "model" not in c["config"]
     # the --gpus N line: per-rank times, no rows
+    full = json.load(open(recs[0]))
     multi = copy.deepcopy(full)
     multi.pop("extra_configs")
     multi.pop("cpu_baseline")
@@ -129,9 +130,11 @@ def test_bench_line_is_short_enough_for_the_driver():
     multi["config"].update(dist_backend="nccl", rccl_ranks=8, parallelism="dp8 image-shard (weak scaling), no data-path collective")
     c = json.loads(bench.compact_line(multi))
     assert c["n_gpus"] == 8 and len(c["per_rank_ms_per_step"]) == 8 and c["config"]["rccl_ranks"] == 8 and "rows" not in c
-    # twice the rows still fit; a record that cannot fit fails loudly instead of printing a line the driver drops
-    big = copy.deepcopy(full)
-    for k, v in list(big["extra_configs"].items()):
+    # half as many rows again still fit (round 6's line: 25 rows, 2.7 KB); a record that cannot fit fails loudly instead of printing
+    # a line the driver drops
+    big = json.load(open(recs[-1]))
+    assert len(big["extra_configs"]) >= 25
+    for k, v in list(big["extra_configs"].items())[:12]:
         big["extra_configs"][k + "_again"] = v
     assert len(bench.compact_line(big)) < 4096
     for i in range(200):
