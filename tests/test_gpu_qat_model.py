@@ -303,3 +303,34 @@ def test_cnnmnist_module_forward_backward(gpu_ok):
     m32 = qat.CNNMNIST(64, 64, 0, cnn_width=32, QuantType="4bitsym").cuda()
     with torch.no_grad():
         assert not m32.fused(x) and m32(x.detach()).shape == (x.shape[0], 10)
+
+
+@pytest.mark.parametrize("tag", ["a", "c", "g"])
+def test_c_host_runs_the_model_forward(tag, tmp_path):
+    """examples/qat_forward.c: a gcc-only host that reads a model and float rows from files and calls the whole-model forward through
+    include/bitnetmcu_hip.h - the logits it prints are the BITS the Python binding returns for the same tensors (same kernel, same
+    launch geometry) and pass the end-to-end tolerance against the reference module's."""
+    import subprocess
+    import util
+    x, ws, ss, widths = case(tag)
+    qt, nt = CONFIGS[tag]
+    nl = len(ws)
+    head = np.array([nl] + widths + [qat.QUANT_TYPES[qt]] * nl + [qat.NORM_TYPES[nt]], dtype=np.int32)
+    with open(tmp_path / "model.f32", "wb") as f:
+        f.write(head.tobytes())
+        for w, s in zip(ws, ss):
+            f.write(s.cpu().numpy().astype(np.float32).reshape(-1)[:1].tobytes())
+            f.write(w.cpu().numpy().astype(np.float32).tobytes())
+    (tmp_path / "rows.f32").write_bytes(x.cpu().numpy().astype(np.float32).tobytes())
+    exe = util.compile_c_host("qat_forward.c", tmp_path)
+    out = subprocess.run([exe, str(tmp_path / "model.f32"), str(tmp_path / "rows.f32")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = np.array([[float(v) for v in line.split()] for line in out.stdout.splitlines()], dtype=np.float32)
+    want = qat.fc_model_forward(x, ws, ss, [qt] * nl, nt).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) or np.array_equal(np.isnan(got), np.isnan(want)) and \
+        np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+    ref = GM[f"{tag}/logits"]
+    rows = [i for i in range(len(ref)) if i != ZERO_ROW]
+    err = np.abs(got[rows] - ref[rows]).max(axis=1) / np.abs(ref[rows]).max(axis=1)
+    assert (err <= 5e-4).mean() >= 0.9 and err.max() <= 6e-2, ((err <= 5e-4).mean(), err.max())
