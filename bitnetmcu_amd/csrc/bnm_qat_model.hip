@@ -566,7 +566,7 @@ bool qat_model_plan(uint32_t n_layers, const uint32_t *widths, QatModelPlan &p) 
     uint32_t off = 0, mh = 1, hoff = 0;
     for (uint32_t l = 0; l < n_layers; l++) {
         const uint32_t w = widths[l + 1];
-        if (w == 0 || w > 128u) return false;
+        if (w == 0 || w > 192u) return false;
         if (l + 1 == n_layers && w > 64u) return false;
         d.width[l] = w;
         d.inv_width[l] = 1.0f / (float)w;
@@ -586,8 +586,11 @@ bool qat_model_plan(uint32_t n_layers, const uint32_t *widths, QatModelPlan &p) 
     }
     d.image_bytes = (off + 1023u) & ~1023u;      // the waves' tiles behind it are addressed with XOR swizzles: 1 KiB aligned
     d.hidden_stride = hoff;
-    p.mh = mh <= 2 ? 2 : 4;
+    p.mh = mh <= 2 ? 2 : mh <= 4 ? 4 : 6;
     p.workspace_bytes = (size_t)d.image_bytes + 1024u;      // + the work counter block
+    // the six-tile class (widths 129 .. 192) runs four waves per workgroup: image + their tiles and scales must fit the CU's LDS
+    // (160-160-160 and 192-192 do; four layers of 192 do not)
+    if (p.mh == 6 && (size_t)d.image_bytes + 4u * (8192u + 128u) > 160u * 1024u) return false;
     return true;
 }
 
@@ -637,9 +640,9 @@ hipError_t qat_model_launch(const QatModelDesc &d, const float *x, uint64_t n, c
         if (t && !strcmp(t, "21")) return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, 1>(d, x, n, image, logits, hidden, n_classes, counter, st);
     }
 #endif
-    // (the four-tile class with the hidden activations written, and LayerNorm's second pass over the values, need more than 256
-    // registers: one wave per SIMD there)
-    return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, ((MH == 4 && HID) || NORM == 2) ? 1 : 2>(d, x, n, image, logits, hidden, n_classes, counter, st);
+    // (the four-tile class with the hidden activations written, LayerNorm's second pass over the values, and the six-tile class
+    // need more than 256 registers: one wave per SIMD there)
+    return qat_model_launch_as<MH, NORM, PEROUT, HID, 2, ((MH == 4 && HID) || NORM == 2 || MH == 6) ? 1 : 2>(d, x, n, image, logits, hidden, n_classes, counter, st);
 }
 
 }  // namespace
@@ -688,10 +691,14 @@ hipError_t bnmk_qat_model_forward(const float *x, uint64_t n, uint32_t n_layers,
         if (nt == 0) { if (perout) QM_GO(2, 0, true); else QM_GO(2, 0, false); }
         else if (nt == 1) { if (perout) QM_GO(2, 1, true); else QM_GO(2, 1, false); }
         else { if (perout) QM_GO(2, 2, true); else QM_GO(2, 2, false); }
-    } else {
+    } else if (p.mh == 4) {
         if (nt == 0) { if (perout) QM_GO(4, 0, true); else QM_GO(4, 0, false); }
         else if (nt == 1) { if (perout) QM_GO(4, 1, true); else QM_GO(4, 1, false); }
         else { if (perout) QM_GO(4, 2, true); else QM_GO(4, 2, false); }
+    } else {
+        if (nt == 0) { if (perout) QM_GO(6, 0, true); else QM_GO(6, 0, false); }
+        else if (nt == 1) { if (perout) QM_GO(6, 1, true); else QM_GO(6, 1, false); }
+        else { if (perout) QM_GO(6, 2, true); else QM_GO(6, 2, false); }
     }
 #undef QM_GO
 }

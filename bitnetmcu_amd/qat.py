@@ -84,7 +84,7 @@ def bitlinear_forward(x, w, s, quant_type, norm_type, return_int=False, return_w
 
 def fc_model_supported(widths, quant_types, norm_type):
     """True when the ONE-kernel whole-model forward serves this stack of BitLinear layers (bnm_qat_model_supported): 256 inputs,
-    hidden widths <= 128, <= 64 classes, QuantTypes whose levels are int8, NormType RMS, Lin or LayerNorm."""
+    hidden widths <= 192, <= 64 classes, QuantTypes whose levels are int8, NormType RMS, Lin or LayerNorm."""
     if any(q not in QUANT_TYPES for q in quant_types) or norm_type not in NORM_TYPES:
         return False
     nl = len(quant_types)

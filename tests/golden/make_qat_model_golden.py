@@ -29,6 +29,13 @@ CONFIGS = {
     "g": (64, 64, 64, "4bitsym", "PerTensor", "LayerNorm", 10, 90, "octav"),  # LayerNorm: no NaN for the all-zero row (epsilon)
     "h": (80, 40, 72, "8bit", "PerTensor", "LayerNorm", 47, 50, "octav"),     # ... with widths off the tiles (padding columns masked)
 }
+# the six-tile class (hidden widths 129 .. 192; the reference's documented 12 KB family ends at binary 160-160-160,
+# docs/documentation.md:169-183) -> tests/golden/qat_fc_model_wide.npz
+CONFIGS_WIDE = {
+    "i": (160, 160, 160, "Binary", "PerTensor", "RMS", 10, 40, "octav"),
+    "j": (192, 144, 0, "4bitsym", "PerOutput", "Lin", 26, 37, "prop"),
+    "k": (136, 192, 160, "8bit", "PerTensor", "LayerNorm", 47, 34, "octav"),
+}
 ZERO_ROW = 5
 
 
@@ -45,8 +52,9 @@ def images(n, gen):
 def main():
     sys.path.insert(0, REF)
     import models as ref          # the reference module, unmodified
-    out = {}
-    for tag, (w1, w2, w3, qt, wscale, nt, ncls, n, algo) in CONFIGS.items():
+    out_main, wide = {}, {}
+    for tag, (w1, w2, w3, qt, wscale, nt, ncls, n, algo) in list(CONFIGS.items()) + list(CONFIGS_WIDE.items()):
+        out = wide if tag in CONFIGS_WIDE else out_main
         torch.manual_seed(20240324 + ord(tag))
         gen = torch.Generator().manual_seed(7 + ord(tag))
         model = ref.FCMNIST(w1, w2, w3, QuantType=qt, WScale=wscale, NormType=nt, num_classes=ncls)
@@ -82,6 +90,7 @@ def main():
             out[f"{tag}/gx"] = grads[0].numpy()
             for l, g in enumerate(grads[1:]):
                 out[f"{tag}/gw{l}"] = g.numpy()
+    out = out_main
     # ---- CNNMNIST (models.py:93-139; the model trainingparameters.yaml names), its widths: 96-64-0, 64 channels, 4bitsym / RMS ----
     torch.manual_seed(20240419)
     gen = torch.Generator().manual_seed(419)
@@ -106,6 +115,9 @@ def main():
     path = os.path.join(HERE, "qat_fc_model.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes;", {t: (out[f"{t}/logits"].shape, bool(np.isnan(out[f"{t}/logits"][ZERO_ROW]).all()), bool(np.isnan(out[f"{t}/logits"]).any())) for t in CONFIGS})
+    path = os.path.join(HERE, "qat_fc_model_wide.npz")
+    np.savez_compressed(path, **wide)
+    print(path, os.path.getsize(path), "bytes;", {t: (wide[f"{t}/logits"].shape, bool(np.isnan(wide[f"{t}/logits"][ZERO_ROW]).all())) for t in CONFIGS_WIDE})
 
 
 if __name__ == "__main__":

@@ -23,12 +23,13 @@ import torch
 
 import bitnetmcu_amd as b
 from bitnetmcu_amd import qat
-from util import GOLDEN
+import util
 
 pytestmark = pytest.mark.gpu
-GM = np.load(os.path.join(GOLDEN, "qat_fc_model.npz"))
+GM = util.qat_model_golden()
 CONFIGS = {"a": ("4bitsym", "RMS"), "b": ("4bitsym", "RMS"), "c": ("Ternary", "Lin"), "d": ("8bit", "RMS"), "e": ("2bitsym", "RMS"),
-           "f": ("Binary", "RMS"), "g": ("4bitsym", "LayerNorm"), "h": ("8bit", "LayerNorm")}
+           "f": ("Binary", "RMS"), "g": ("4bitsym", "LayerNorm"), "h": ("8bit", "LayerNorm"),
+           "i": ("Binary", "RMS"), "j": ("4bitsym", "Lin"), "k": ("8bit", "LayerNorm")}      # i - k: hidden widths 129 .. 192 (six tiles)
 ZERO_ROW = 5
 TIE = 5e-4
 
@@ -151,6 +152,8 @@ def test_unsupported_configurations_are_refused_not_emulated(gpu_ok):
     assert not qat.fc_model_supported(widths, ["4bitsym"] * 4, "BatchNorm")     # needs the whole batch per layer
     assert qat.fc_model_supported(widths, ["4bitsym"] * 4, "LayerNorm")
     assert not qat.fc_model_supported([256, 200, 64, 64, 10], ["4bitsym"] * 4, "RMS")
+    assert qat.fc_model_supported([256, 160, 160, 160, 10], ["Binary"] * 4, "RMS") and qat.fc_model_supported([256, 192, 192, 10], ["8bit"] * 3, "Lin")
+    assert not qat.fc_model_supported([256, 192, 192, 192, 10], ["4bitsym"] * 4, "RMS")      # the weight image + four waves' tiles: past 160 KiB of LDS
     assert not qat.fc_model_supported([128, 64, 64, 64, 10], ["4bitsym"] * 4, "RMS")
     with pytest.raises(NotImplementedError):
         qat.fc_model_forward(x, ws, ss, ["NF4"] * 4, "RMS")
@@ -214,9 +217,9 @@ def test_fcmnist_module_forward_backward(gpu_ok):
     assert not m2.fused(xk) and m2(xk.detach()).shape == (x.shape[0] - 1, 10)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(36))
 def test_fuzz_random_model_shapes(seed, gpu_ok):
-    """Random stacks the kernel serves - 3 or 4 layers, hidden widths 8..128 (any, not only multiples of 32), 1..64 classes, every
+    """Random stacks the kernel serves - 3 or 4 layers, hidden widths 8..128 (seeds 24+: up to 192; any, not only multiples of 32), 1..64 classes, every
     int8-level QuantType, both norms, per-tensor and per-output clipping scalars, ragged batch sizes - against the restated reference
     formula on torch's own fp32 kernels (pinned bit for bit to the reference module on CPU by tests/test_qat_cpu.py): logits and
     hidden activations, the end-to-end tolerances of this file."""
@@ -225,6 +228,9 @@ def test_fuzz_random_model_shapes(seed, gpu_ok):
     hidden_w = [int(rng.integers(8, 129)) for _ in range(n_hidden)]
     if seed % 5 == 0:
         hidden_w = [int(rng.choice([32, 64, 96, 128])) for _ in range(n_hidden)]
+    if seed >= 24:      # the six-tile class: at least one hidden layer of 129 .. 192 units, the others anything up to 176
+        hidden_w = [int(rng.integers(8, 177)) for _ in range(n_hidden)]
+        hidden_w[int(rng.integers(0, n_hidden))] = int(rng.integers(129, 193))
     widths = [256] + hidden_w + [int(rng.integers(1, 65))]
     qt = ["Binary", "BinarySym", "Ternary", "2bitsym", "4bitsym", "5bitsym", "8bit"][seed % 7]
     nt = ("RMS", "Lin", "LayerNorm")[seed % 3]

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from bitnetmcu_amd import qat
+import util
 from util import GOLDEN
 
 G = np.load(os.path.join(GOLDEN, "qat_bitlinear.npz"))
@@ -143,9 +144,10 @@ def test_backward_from_quantised_operands_equals_reference_gradients(qt, nt):
 
 
 # ---- whole model (models.py:56-90 FCMNIST): fixtures from the reference module itself (tests/golden/make_qat_model_golden.py) ----
-GM = np.load(os.path.join(GOLDEN, "qat_fc_model.npz"))
+GM = util.qat_model_golden()
 MODEL_CONFIGS = {"a": ("4bitsym", "RMS"), "b": ("4bitsym", "RMS"), "c": ("Ternary", "Lin"), "d": ("8bit", "RMS"), "e": ("2bitsym", "RMS"),
-                 "f": ("Binary", "RMS"), "g": ("4bitsym", "LayerNorm"), "h": ("8bit", "LayerNorm")}
+                 "f": ("Binary", "RMS"), "g": ("4bitsym", "LayerNorm"), "h": ("8bit", "LayerNorm"),
+                 "i": ("Binary", "RMS"), "j": ("4bitsym", "Lin"), "k": ("8bit", "LayerNorm")}      # i - k: hidden widths 129 .. 192
 
 
 def model_case(tag):

@@ -177,3 +177,14 @@ def compile_c_host(source, include_dir):
                            os.path.join(REPO, "examples", source), "-L", libdir, "-lbitnetmcu_hip", f"-Wl,-rpath,{libdir}",
                            "-o", exe])
     return exe
+
+
+def qat_model_golden():
+    """The whole-model QAT fixtures (tests/golden/make_qat_model_golden.py) as one mapping: qat_fc_model.npz + the six-tile class's
+    qat_fc_model_wide.npz."""
+    import numpy as np
+    out = {}
+    for name in ("qat_fc_model.npz", "qat_fc_model_wide.npz"):
+        with np.load(os.path.join(GOLDEN, name)) as f:
+            out.update({k: f[k] for k in f.files})
+    return out
