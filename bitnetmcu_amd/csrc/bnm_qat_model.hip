@@ -588,9 +588,6 @@ bool qat_model_plan(uint32_t n_layers, const uint32_t *widths, QatModelPlan &p) 
     d.hidden_stride = hoff;
     p.mh = mh <= 2 ? 2 : mh <= 4 ? 4 : 6;
     p.workspace_bytes = (size_t)d.image_bytes + 1024u;      // + the work counter block
-    // the six-tile class (widths 129 .. 192) runs four waves per workgroup: image + their tiles and scales must fit the CU's LDS
-    // (160-160-160 and 192-192 do; four layers of 192 do not)
-    if (p.mh == 6 && (size_t)d.image_bytes + 4u * (8192u + 128u) > 160u * 1024u) return false;
     return true;
 }
 
@@ -611,8 +608,14 @@ template <int MH, int NORM, bool PEROUT, bool HID, int NG, int WPS>
 hipError_t qat_model_launch_as(const QatModelDesc &d, const float *x, uint64_t n, const char *image, float *logits, float *hidden,
                                uint32_t n_classes, uint32_t *counter, hipStream_t st) {
     auto fn = qat_fc_model_fwd_kernel<MH, NORM, PEROUT, HID, NG, WPS>;
-    const unsigned threads = 256 * WPS, nwaves = threads / 64;
-    const size_t lds = (size_t)d.image_bytes + (size_t)nwaves * 8192u + (size_t)nwaves * 128u;
+    // (the widest stacks of the six-tile class - four layers of ~192 - leave room for two waves' tiles beside the weight image, not four)
+    unsigned threads = 256 * WPS, nwaves = threads / 64;
+    size_t lds = (size_t)d.image_bytes + (size_t)nwaves * 8192u + (size_t)nwaves * 128u;
+    if (lds > 160u * 1024u && WPS == 1) {
+        threads = 128;
+        nwaves = 2;
+        lds = (size_t)d.image_bytes + (size_t)nwaves * 8192u + (size_t)nwaves * 128u;
+    }
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
     if (hipError_t e = qat_allow_big_lds((const void *)fn); e != hipSuccess) return e;
     const uint64_t units = (n + 31ull) >> 5;
@@ -623,7 +626,7 @@ hipError_t qat_model_launch_as(const QatModelDesc &d, const float *x, uint64_t n
     uint64_t batch = units / (cap * nwaves * 8u);      // tiles per take: at least ~8 takes per wave
     batch = batch < 1u ? 1u : batch > QM_BATCH ? QM_BATCH : batch;
     uint64_t blocks = (units + (uint64_t)nwaves * batch - 1) / ((uint64_t)nwaves * batch);
-    if (blocks > cap) blocks = (nwaves & 7u) ? (cap & ~1ull) : cap;      // capped grids: waves a multiple of 8 (the counter's eight words)
+    if (blocks > cap) blocks = cap & ~(uint64_t)(8u / nwaves - 1u);      // capped grids: waves a multiple of 8 (the counter's eight words; nwaves 2, 4 or 8)
     fn<<<dim3((unsigned)blocks), dim3(threads), lds, st>>>(x, n, (const i32x4 *)image, d, logits, hidden, n_classes, counter, (uint32_t)batch);
     return hipGetLastError();
 }
