@@ -37,7 +37,7 @@ def newer(src_list, out):
 SOURCES = (("bnm_fused_fc.hip", True), ("bnm_fused_regw.hip", True, ("-mllvm", "-amdgpu-mfma-vgpr-form")), ("bnm_fused_generic.hip", True), ("bnm_fused_generic_m2.hip", True),
            ("bnm_fused_generic_m4.hip", True), ("bnm_fused_generic_m6_k8.hip", True), ("bnm_fused_generic_m8_k2.hip", True), ("bnm_fused_generic_m8_k4.hip", True),
            ("bnm_fused_generic_m8_k8.hip", True), ("bnm_fused_generic_m8_k16.hip", True), ("bnm_fused_generic_m2_t2.hip", True), ("bnm_fused_generic_m4_t2.hip", True), ("bnm_cnn.hip", True, ("-mllvm", "-amdgpu-mfma-vgpr-form")), ("bnm_cnn_li.hip", True), ("bnm_cnn_li_fused.hip", True), ("bnm_ternary.hip", True), ("bnm_ternary_s32.hip", True), ("bnm_ternary_s64.hip", True), ("bnm_ternary_s96.hip", True), ("bnm_ternary_s128.hip", True),
-           ("bnm_layerwise.hip", True), ("bnm_support.hip", True), ("bnm_qat.hip", True), ("bnm_qat_model.hip", True),
+           ("bnm_layerwise.hip", True), ("bnm_support.hip", True), ("bnm_qat.hip", True), ("bnm_qat_model.hip", True), ("bnm_qat_cnn.hip", True),
            ("bnm_fused_f32.hip", True), ("bnm_fused_f32_m2.hip", True), ("bnm_fused_f32_m4.hip", True), ("bnm_fused_f32_m6.hip", True),
            ("bnm_capi.cpp", False), ("bnm_capi_model.cpp", False), ("bnm_capi_ctx.cpp", False), ("bnm_capi_infer.cpp", False), ("bnm_capi_host.cpp", False),
            ("bnm_capi_float.cpp", False), ("bnm_capi_qat.cpp", False), ("bnm_capi_multigpu.cpp", False), ("bnm_capi_symbols.cpp", False),

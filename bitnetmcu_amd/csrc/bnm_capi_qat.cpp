@@ -67,7 +67,7 @@ int bnm_qat_model_forward_device(const float *d_x, uint64_t n, uint32_t n_layers
     }
     if (norm_type < BNM_QAT_NORM_RMS || norm_type > BNM_QAT_NORM_NONE) return fail(BNM_EINVAL, "unknown norm_type");
     if (!bnmk_qat_model_supported(n_layers, widths, quant_types, norm_type))
-        return fail(BNM_EUNSUPPORTED, "the fused model forward serves 256 inputs, hidden widths <= 128, <= 64 classes, int8-level QuantTypes "
+        return fail(BNM_EUNSUPPORTED, "the fused model forward serves 256 inputs, hidden widths <= 192, <= 64 classes, int8-level QuantTypes "
                                       "and NormType RMS / Lin / LayerNorm (bnm_qat_model_supported); run the layers with bnm_qat_bitlinear_forward_device");
     if (workspace_bytes < bnmk_qat_model_workspace_bytes(n_layers, widths)) return fail(BNM_EINVAL, "workspace too small (bnm_qat_model_workspace_bytes)");
     if (((uintptr_t)d_workspace & 15u) || ((uintptr_t)d_logits & 15u) || ((uintptr_t)d_x & 15u))
@@ -75,6 +75,32 @@ int bnm_qat_model_forward_device(const float *d_x, uint64_t n, uint32_t n_layers
     if (n >= (1ull << 36)) return fail(BNM_EINVAL, "n too large for one call");
     HIP_TRY(bnmk_qat_model_forward(d_x, n, n_layers, widths, d_w, d_s, s_count, quant_types, norm_type, d_logits, d_hidden, d_w_deq,
                                    d_workspace, (hipStream_t)stream));
+    return BNM_OK;
+}
+
+int bnm_qat_cnn_front_supported(uint32_t channels, const uint32_t *s_count, const int *quant_types) {
+    if (!s_count || !quant_types) return 0;
+    return bnmk_qat_cnn_front_supported(channels, s_count, quant_types) ? 1 : 0;
+}
+
+uint64_t bnm_qat_cnn_front_workspace_bytes(uint32_t channels) { return bnmk_qat_cnn_front_workspace_bytes(channels); }
+
+int bnm_qat_cnn_front_forward_device(const float *d_x, uint64_t n, uint32_t channels, const float *const *d_w, const float *const *d_s,
+                                     const uint32_t *s_count, const int *quant_types, float *d_features, void *d_workspace,
+                                     uint64_t workspace_bytes, void *stream) {
+    if (!d_w || !d_s || !s_count || !quant_types || !d_workspace || (n && (!d_x || !d_features))) return fail(BNM_EINVAL, "null pointer");
+    for (int l = 0; l < 3; l++) {
+        if (!d_w[l] || !d_s[l]) return fail(BNM_EINVAL, "null weight or clipping-scalar pointer");
+        if (quant_types[l] < BNM_QAT_NONE || quant_types[l] > BNM_QAT_8BIT) return fail(BNM_EINVAL, "unknown quant_type");
+    }
+    if (!bnmk_qat_cnn_front_supported(channels, s_count, quant_types))
+        return fail(BNM_EUNSUPPORTED, "the fused convolution front serves an even number of 16 .. 128 channels with per-tensor clipping scalars and a QuantType other than 'None' "
+                                      "(bnm_qat_cnn_front_supported); run the layers with bnm_qat_bitconv2d_forward_device");
+    if (workspace_bytes < bnmk_qat_cnn_front_workspace_bytes(channels)) return fail(BNM_EINVAL, "workspace too small (bnm_qat_cnn_front_workspace_bytes)");
+    if (((uintptr_t)d_workspace & 15u) || ((uintptr_t)d_features & 15u) || ((uintptr_t)d_x & 15u))
+        return fail(BNM_EINVAL, "d_x, d_features and the workspace must be 16-byte aligned");
+    if (n >= (1ull << 36)) return fail(BNM_EINVAL, "n too large for one call");
+    HIP_TRY(bnmk_qat_cnn_front_forward(d_x, n, channels, d_w, d_s, quant_types, d_features, d_workspace, (hipStream_t)stream));
     return BNM_OK;
 }
 

@@ -220,6 +220,11 @@ bool bnmk_qat_model_supported(uint32_t n_layers, const uint32_t *widths, const i
 hipError_t bnmk_qat_model_forward(const float *d_x, uint64_t n, uint32_t n_layers, const uint32_t *widths, const float *const *d_w,
                                   const float *const *d_s, const uint32_t *s_count, const int *quant_types, int norm_type,
                                   float *d_logits, float *d_hidden, float *const *d_w_deq, void *d_workspace, hipStream_t stream);
+// CNNMNIST's convolution front in one kernel (bnm_qat_cnn.hip): w / s / quant_types are three-element HOST arrays (conv1, conv2, conv3)
+bool bnmk_qat_cnn_front_supported(uint32_t channels, const uint32_t *s_count, const int *quant_types);
+size_t bnmk_qat_cnn_front_workspace_bytes(uint32_t channels);
+hipError_t bnmk_qat_cnn_front_forward(const float *d_x, uint64_t n, uint32_t channels, const float *const *d_w, const float *const *d_s,
+                                      const int *quant_types, float *d_features, void *d_workspace, hipStream_t stream);
 // workspace: bnmk_qat_workspace_bytes((cin / groups) * kh * kw, cout) bytes; dynamic LDS: bnmk_qat_bitconv2d_lds_bytes (<= 160 KiB).
 size_t bnmk_qat_bitconv2d_lds_bytes(uint32_t cin, uint32_t h, uint32_t w, uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad,
                                     uint32_t groups);

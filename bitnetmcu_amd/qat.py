@@ -144,6 +144,57 @@ def fc_model_forward(x, weights, scalars, quant_types, norm_type, return_hidden=
     return out if len(out) > 1 else logits
 
 
+_front_workspaces = {}
+
+
+def cnn_front_supported(channels, scalars, quant_types=("8bit", "8bit", "8bit")):
+    """True when the ONE-kernel convolution front serves CNNMNIST's three BitConv2d layers (bnm_qat_cnn_front_supported): an even
+    number of 16 .. 128 channels, per-tensor clipping scalars, a QuantType other than 'None'."""
+    if len(scalars) != 3 or len(quant_types) != 3 or any(q not in QUANT_TYPES for q in quant_types):
+        return False
+    counts = (C.c_uint32 * 3)(*[int(torch.as_tensor(s).numel()) for s in scalars])
+    qa = (C.c_int * 3)(*[QUANT_TYPES[q] for q in quant_types])
+    return bool(L.load().bnm_qat_cnn_front_supported(int(channels), counts, qa))
+
+
+def cnn_front_forward(x, weights, scalars, quant_types=("8bit", "8bit", "8bit")):
+    """The convolution front of the reference's CNNMNIST (models.py:109-119) - BitConv2d(1 -> C) / ReLU / depthwise BitConv2d / ReLU /
+    MaxPool / depthwise BitConv2d / ReLU / MaxPool / Flatten, NormType 'None' - in ONE kernel (bnm_qat_cnn_front_forward_device,
+    csrc/bnm_qat_cnn.hip).  x [n, 1, 16, 16] (or [n, 256]), weights three [C, 1, 3, 3] tensors, scalars their clipping scalars;
+    float32 CUDA tensors.  Returns the features [n, 4 C]."""
+    if not x.is_cuda:
+        raise RuntimeError("cnn_front_forward is a GPU op: x must be a CUDA tensor (there is no CPU path)")
+    lib = L.load()
+    x2 = x.flatten(1).contiguous().float()
+    n, d = x2.shape
+    if d != 256 or len(weights) != 3 or len(scalars) != 3:
+        raise ValueError("cnn_front_forward: 16x16 images and three convolution layers")
+    ws = [w.contiguous().float() for w in weights]
+    channels = ws[0].shape[0]
+    if any(tuple(w.shape) != (channels, 1, 3, 3) for w in ws):
+        raise ValueError(f"cnn_front_forward: weights must be [C, 1, 3, 3], got {[tuple(w.shape) for w in ws]}")
+    ss = [torch.as_tensor(s, dtype=torch.float32, device=x.device).reshape(-1).contiguous() for s in scalars]
+    if not cnn_front_supported(channels, ss, quant_types):
+        raise NotImplementedError(f"cnn_front_forward: {channels} channels / {[s.numel() for s in ss]} clipping scalars / {list(quant_types)} are not served by the "
+                                  "fused kernel (cnn_front_supported); run the layers with bitconv2d_forward")
+    sc = (C.c_uint32 * 3)(*[s.numel() for s in ss])
+    qa = (C.c_int * 3)(*[QUANT_TYPES[q] for q in quant_types])
+    wp = (C.c_void_p * 3)(*[w.data_ptr() for w in ws])
+    sp = (C.c_void_p * 3)(*[s.data_ptr() for s in ss])
+    features = torch.empty((n, 4 * channels), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        key = (x.device.index, stream, channels)
+        wsp = _front_workspaces.get(key)
+        if wsp is None:
+            wsp = torch.empty((int(lib.bnm_qat_cnn_front_workspace_bytes(channels)) + 3) // 4, dtype=torch.float32, device=x.device)
+            _front_workspaces[key] = wsp
+        L.check(lib, lib.bnm_qat_cnn_front_forward_device(
+            C.c_void_p(x2.data_ptr()), n, channels, wp, sp, sc, qa, C.c_void_p(features.data_ptr()), C.c_void_p(wsp.data_ptr()),
+            wsp.numel() * 4, C.c_void_p(stream)), "bnm_qat_cnn_front_forward_device")
+    return features
+
+
 def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
@@ -524,7 +575,8 @@ class FCMNIST(nn.Module):
 class CNNMNIST(nn.Module):
     """Stand-in for the reference's CNNMNIST (models.py:93-139; the model trainingparameters.yaml names): same constructor, same
     module / parameter names (`model.0`, `model.2`, `model.5` the convolutions, `model.9`, `model.11`, `model.fc3`, `classifier`).
-    The depthwise-separable front runs layer by layer through `BitConv2d`'s fused op; the FC stack behind Flatten - 64 channels x 4
+    The depthwise-separable front runs as ONE kernel (`cnn_front_forward`) where no gradient is asked for (evaluation) and layer by
+    layer through `BitConv2d`'s op in training steps; the FC stack behind Flatten - 64 channels x 4
     = 256 inputs - runs as ONE kernel (`fc_model_forward`: per-layer QuantTypes: 2bitsym first, then `QuantType`) where the fused op
     serves the configuration, else layer by layer."""
 
@@ -552,8 +604,19 @@ class CNNMNIST(nn.Module):
         last_width = network_width3 if network_width3 > 0 else network_width2
         self.classifier = BitLinear(last_width, num_classes, QuantType=QuantType, NormType=NormType, WScale=WScale)
 
+    def front_fused(self, x):
+        """True when front(x) runs as the one-kernel op: a CUDA batch of 16x16 images, nothing that needs a gradient (the backward
+        pass works from the per-layer ops' saved planes: training steps run layer by layer), a configuration the kernel serves."""
+        convs = [m for m in list(self.model)[:9] if isinstance(m, BitConv2d)]
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(c.weight.requires_grad for c in convs))
+        return (x.is_cuda and not needs_grad and tuple(x.shape[1:]) == (1, 16, 16) and all(c.NormType == "None" for c in convs)
+                and cnn_front_supported(self.cnn_width, [c.s for c in convs], [c.QuantType for c in convs]))
+
     def front(self, x):
         """the convolution front up to and including Flatten (models.py:109-119)"""
+        if self.front_fused(x):
+            convs = [m for m in list(self.model)[:9] if isinstance(m, BitConv2d)]
+            return cnn_front_forward(x, [c.weight for c in convs], [c.s for c in convs], [c.QuantType for c in convs])
         for m in list(self.model)[:9]:
             x = m(x)
         return x

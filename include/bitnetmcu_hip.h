@@ -349,6 +349,22 @@ BNM_API int bnm_qat_model_forward_device(const float *d_x, uint64_t n, uint32_t 
                                          const int *quant_types, int norm_type, float *d_logits, float *d_hidden,
                                          float *const *d_w_deq, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
+/* The convolution front of the reference's CNNMNIST (models.py:109-119) in ONE kernel behind a tap-preparation launch:
+ *   BitConv2d(1 -> C, 3x3) -> ReLU -> BitConv2d(C -> C, 3x3, groups = C) -> ReLU -> MaxPool2d(2) -> BitConv2d(C -> C, 3x3, groups = C)
+ *   -> ReLU -> MaxPool2d(2) -> Flatten, every BitConv2d with NormType 'None' and stride 1 / no padding (BitNetMCU.py:285-305).
+ *   d_x [n][256] float32 (16x16 images) in, d_features [n][4 C] float32 out (Flatten's order: channel-major, then 2x2) - the input of
+ *   the model's FC stack (bnm_qat_model_forward_device where 4 C = 256).  d_w[l] [C][9] float32 (the layers' weight tensors
+ *   [C][1][3][3] as they lie), d_s[l] the layer's clipping scalar, s_count[l] = 1, quant_types[l] any BNM_QAT_* but BNM_QAT_NONE (which skips
+ *   activation_quant as well) - d_w / d_s / s_count / quant_types are three-element HOST arrays.  Serves an even C of 16 .. 128
+ *   with per-tensor clipping scalars (bnm_qat_cnn_front_supported); anything else: BNM_EUNSUPPORTED - run the layers with bnm_qat_bitconv2d_forward_device.
+ *   workspace: bnm_qat_cnn_front_workspace_bytes(C) bytes, 16-byte aligned like d_x and d_features.
+ * Floating point: within the tolerances of tests/test_gpu_qat_cnn.py of the reference module, not bit-exact. */
+BNM_API int bnm_qat_cnn_front_supported(uint32_t channels, const uint32_t *s_count, const int *quant_types);
+BNM_API uint64_t bnm_qat_cnn_front_workspace_bytes(uint32_t channels);
+BNM_API int bnm_qat_cnn_front_forward_device(const float *d_x, uint64_t n, uint32_t channels, const float *const *d_w,
+                                             const float *const *d_s, const uint32_t *s_count, const int *quant_types,
+                                             float *d_features, void *d_workspace, uint64_t workspace_bytes, void *stream);
+
 /* ---- synthetic workload + digests ---------------------------------------- */
 #define BNM_DIST_U 0
 #define BNM_DIST_M 1

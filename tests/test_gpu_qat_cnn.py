@@ -1,0 +1,171 @@
+"""The convolution front of the reference's CNNMNIST in one kernel (csrc/bnm_qat_cnn.hip) on the GPU, through
+the C ABI, against fixtures generated from the reference's own module (tests/golden/make_qat_model_golden.py: "cnn/*") and against
+the layer-by-layer path (qat.BitConv2d's op per layer, pinned to the reference's BitConv2d by tests/test_gpu_qat.py).
+
+FLOATING POINT: parity is within tolerance.  The kernel's float32 operations are the reference's one by one up to the order of the
+nine products of a convolution sum, so an output differs from the reference's by a rounding of that sum (~1e-7 relative) - unless
+that rounding moves a value that sits at a tie of the NEXT layer's activation_quant: then one input of nine is a quantisation step
+(1 / 127 of its row's maximum) off.  The tolerances, relative to the image's largest feature:
+  * at least 90 % of the images within 1e-5 (no flipped step anywhere in 14,000 quantised values; measured: 96-100 %);
+  * every image within 1e-2 (measured: 4e-3);
+  * the layer-by-layer path, which sums in yet another order, sits at the same distances from the reference.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bitnetmcu_amd as b
+from bitnetmcu_amd import qat
+import util
+
+pytestmark = pytest.mark.gpu
+GM = util.qat_model_golden()
+
+
+def golden_module():
+    m = qat.CNNMNIST(96, 64, 0, cnn_width=64, QuantType="4bitsym", WScale="PerTensor", NormType="RMS", num_classes=10).cuda()
+    layers = [x for x in list(m.model) + [m.classifier] if hasattr(x, "weight_quant")]
+    with torch.no_grad():
+        for l, layer in enumerate(layers):
+            layer.weight.copy_(torch.from_numpy(GM[f"cnn/w{l}"]))
+            layer.s = torch.nn.Parameter(torch.from_numpy(GM[f"cnn/s{l}"]).reshape(()).cuda(), requires_grad=False)
+    return m
+
+
+def layer_by_layer(m, x):
+    with torch.no_grad():
+        for k in list(m.model)[:9]:
+            x = k(x)
+    return x
+
+
+def distances(got, want):
+    got, want = got.detach().cpu().numpy(), want.detach().cpu().numpy() if torch.is_tensor(want) else want
+    return np.abs(got - want).max(axis=1) / np.maximum(np.abs(want).max(axis=1), 1e-30)
+
+
+def close(got, want, what):
+    e = distances(got, want)
+    n = len(e)
+    assert (e <= 1e-5).sum() >= n - max(2, n // 10) and e.max() <= 1e-2, (what, float((e <= 1e-5).mean()), float(e.max()))
+
+
+def test_front_and_model_against_the_reference_module(gpu_ok):
+    """The reference's own CNNMNIST (96-64, 64 channels): features behind Flatten, then the logits with the FC stack's one-kernel op
+    behind the front's - two launches + two preparation launches for the whole model."""
+    m = golden_module()
+    x = torch.from_numpy(GM["cnn/x"]).cuda().reshape(-1, 1, 16, 16)
+    with torch.no_grad():
+        assert m.front_fused(x) and m.fused(x)
+        f = m.front(x)
+        y = m(x)
+    assert f.shape == (x.shape[0], 256)
+    close(f, GM["cnn/features"], "features")
+    ref = GM["cnn/logits"]
+    err = distances(y, ref)
+    assert (err <= 5e-4).mean() >= 0.9 and err.max() <= 6e-2, ((err <= 5e-4).mean(), err.max())
+    # the per-layer path is the one a training step takes: same answers, same distances
+    close(layer_by_layer(m, x), GM["cnn/features"], "layer by layer")
+    assert not m.front_fused(x.clone().requires_grad_(True))
+
+
+@pytest.mark.parametrize("channels", [16, 18, 32, 48, 64, 100, 128])
+def test_channel_counts_and_batch_sizes_against_the_layer_by_layer_path(channels, gpu_ok):
+    """8 .. 64 channel pairs per image (8, 4, 2 images or one per wave; lanes idle where the pairs do not divide 64), ragged batches,
+    random weights: the features of the per-layer ops within the tolerances above."""
+    torch.manual_seed(channels)
+    m = qat.CNNMNIST(64, 64, 0, cnn_width=channels, QuantType="4bitsym").cuda()
+    for n in (1, 2, 3, 7, 64, 1001):
+        x = torch.randn(n, 1, 16, 16, device="cuda") * (torch.rand(n, 1, 1, 1, device="cuda") * 2 + 0.05)
+        with torch.no_grad():
+            assert m.front_fused(x)
+            got = m.front(x)
+        assert got.shape == (n, 4 * channels)
+        close(got, layer_by_layer(m, x), (channels, n))
+    with torch.no_grad():
+        assert m.front(torch.empty(0, 1, 16, 16, device="cuda")).shape == (0, 4 * channels)
+
+
+@pytest.mark.parametrize("qt", ["8bit", "4bitsym", "4bit", "Ternary", "Binary", "BinarySym", "2bitsym", "5bitsym", "FP130", "NF4"])
+def test_quant_types(qt, gpu_ok):
+    """The taps are w_int / w_scale as floats: every QuantType of the reference's weight_quant ('None', which skips activation_quant
+    as well, is refused)."""
+    torch.manual_seed(5)
+    m = qat.CNNMNIST(64, 64, 0, cnn_width=32).cuda()
+    convs = [c for c in m.model if isinstance(c, qat.BitConv2d)]
+    x = torch.randn(300, 1, 16, 16, device="cuda")
+    ws, ss = [c.weight.detach() for c in convs], [c.s for c in convs]
+    got = qat.cnn_front_forward(x, ws, ss, [qt] * 3)
+    y = x
+    for l, c in enumerate(convs):
+        y = torch.relu(qat.bitconv2d_forward(y, ws[l], ss[l], qt, "None", groups=c.groups))
+        if l:
+            y = torch.nn.functional.max_pool2d(y, 2)
+    close(got, y.flatten(1), qt)
+
+
+def test_rows_do_not_depend_on_the_batch_and_special_images(gpu_ok):
+    """200,000 images (more groups than the launch has waves): every image's features equal the features it gets in a small batch,
+    bit for bit.  An all-zero image and an image with one non-zero pixel: finite features (NormType 'None': no 0 / 0), equal to the
+    per-layer path's; a huge image: scale-invariant up to rounding; a tiny one: as the per-layer path (the 1e-5 clamp acts)."""
+    m = golden_module()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    big = torch.randn(200_000, 1, 16, 16, device="cuda", generator=g) * (torch.rand(200_000, 1, 1, 1, device="cuda", generator=g) * 2 + 0.01)
+    big[7] = 0.0
+    big[8] = 0.0
+    big[8, 0, 5, 9] = 1.5
+    big[9] = big[10] * 1e4
+    big[11] = big[10] * 1e-4
+    with torch.no_grad():
+        full = m.front(big)
+        for first in (0, 100_001, 199_990):
+            assert torch.equal(m.front(big[first:first + 10].clone()), full[first:first + 10]), first
+    assert torch.isfinite(full).all()
+    assert torch.equal(full[7], torch.zeros(256, device="cuda"))
+    close(full[:2000], layer_by_layer(m, big[:2000]), "first 2000")
+    assert torch.allclose(full[9] * 1e-4, full[10], rtol=1e-4, atol=1e-6 * float(full[10].abs().max()))
+    # (the tiny image is NOT a scaled copy: activation_quant's clamp of a row maximum at 1e-5 acts on it - here as in the reference)
+
+
+def test_unsupported_configurations_are_refused_not_emulated(gpu_ok):
+    lib = b.load()
+    one = (C.c_uint32 * 3)(1, 1, 1)
+    q8 = (C.c_int * 3)(10, 10, 10)
+    assert lib.bnm_qat_cnn_front_supported(64, one, q8) == 1 and lib.bnm_qat_cnn_front_supported(16, one, q8) == 1
+    for ch in (0, 8, 14, 17, 63, 130, 256):
+        assert lib.bnm_qat_cnn_front_supported(ch, one, q8) == 0, ch
+    assert lib.bnm_qat_cnn_front_supported(64, (C.c_uint32 * 3)(1, 64, 1), q8) == 0      # per-output clipping scalars
+    assert lib.bnm_qat_cnn_front_supported(64, one, (C.c_int * 3)(10, 0, 10)) == 0          # QuantType 'None': no activation_quant either
+    m = qat.CNNMNIST(64, 64, 0, cnn_width=8).cuda()
+    x = torch.randn(5, 1, 16, 16, device="cuda")
+    with torch.no_grad():
+        assert not m.front_fused(x) and m.front(x).shape == (5, 32)      # layer by layer, same module
+    convs = [c for c in m.model if isinstance(c, qat.BitConv2d)]
+    with pytest.raises(NotImplementedError):
+        qat.cnn_front_forward(x, [c.weight for c in convs], [c.s for c in convs])
+    with pytest.raises(RuntimeError):
+        qat.cnn_front_forward(x.cpu(), [c.weight for c in convs], [c.s for c in convs])
+    # return codes: BNM_OK 0, BNM_EINVAL -1, BNM_EUNSUPPORTED -3
+    m64 = golden_module()
+    convs = [c for c in m64.model if isinstance(c, qat.BitConv2d)]
+    ws = [c.weight.detach().contiguous() for c in convs]
+    ss = [c.s.detach().reshape(1).contiguous() for c in convs]
+    wp = (C.c_void_p * 3)(*[w.data_ptr() for w in ws])
+    sp = (C.c_void_p * 3)(*[s.data_ptr() for s in ss])
+    qa = (C.c_int * 3)(10, 10, 10)
+    x = torch.randn(6, 256, device="cuda")
+    f = torch.empty(6, 256, device="cuda")
+    wsp = torch.empty(4096, device="cuda")
+    args = lambda **k: [C.c_void_p(k.get("x", x.data_ptr())), 6, k.get("ch", 64), wp, sp, k.get("sc", one), k.get("qa", qa), C.c_void_p(f.data_ptr()),
+                        C.c_void_p(wsp.data_ptr()), k.get("wsb", wsp.numel() * 4), None]
+    assert lib.bnm_qat_cnn_front_forward_device(*args()) == 0
+    assert lib.bnm_qat_cnn_front_forward_device(*args(wsb=64)) == -1
+    assert lib.bnm_qat_cnn_front_forward_device(*args(x=x.data_ptr() + 4)) == -1
+    assert lib.bnm_qat_cnn_front_forward_device(*args(qa=(C.c_int * 3)(10, 99, 10))) == -1
+    assert lib.bnm_qat_cnn_front_forward_device(*args(ch=12)) == -3
+    assert lib.bnm_qat_cnn_front_forward_device(*args(qa=(C.c_int * 3)(10, 0, 10))) == -3
+    assert int(lib.bnm_qat_cnn_front_workspace_bytes(64)) == 3 * 64 * 9 * 4
+    torch.cuda.synchronize()
