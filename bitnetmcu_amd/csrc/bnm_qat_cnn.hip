@@ -18,8 +18,8 @@
 //     * rows are produced in order and consumed at once - conv1 row r completes the three-row window of conv2 row r - 2, two of
 //       those make a pooled row, three pooled rows a conv3 row - so a lane holds three rows of each stage, never a plane; the
 //       loops are unrolled completely (every index is a constant: the windows are registers);
-//     * activation_quant of a row is per lane: the row's maximum with v_max3_f32, scale = 127 / max (IEEE division, as the
-//       reference), q = rne(relu(y) scale) as (y scale + 1.5 * 2^23) - 1.5 * 2^23, x_quant = q * (1 / scale);
+//     * activation_quant of a row is per lane: the row's maximum m with v_max3_f32, u = clamp(y / m, 0, 1) (v_pk_mul_f32 with the
+//       clamp modifier: the ReLU costs nothing), q = rne(127 u) as (127 u + 1.5 * 2^23) - 1.5 * 2^23, x_quant = q m / 127;
 //     * a lane's eight features are 32 consecutive bytes of the image's row of 4 C floats.
 // Bound: VALU issue (~5,100 instructions per lane and image, two thirds of them the packed multiply-adds); HBM sees 1 KiB + 16 C
 // bytes per image.
@@ -34,23 +34,31 @@ constexpr float QC_MAGIC = 12582912.0f;      // 1.5 * 2^23
 
 BNM_DEVICE f32x2 splat(float v) { return f32x2{v, v}; }
 
-// ReLU + activation_quant of one row of W pairs (channel a in .x, channel b in .y): in place, y -> x_int / x_scale
+// ReLU + activation_quant of one row of W pairs (channel a in .x, channel b in .y): in place, y -> x_int / x_scale.
+// With m = max(row maximum of relu(y), 1e-5):  x_int = rne(relu(y) 127 / m) = rne(127 u),  u = clamp(y / m, 0, 1)  - the clamp is the
+// ReLU (and free: the multiplication's own output modifier); x_int / x_scale = x_int m / 127.  v_rcp_f32 and two multiplications where
+// the reference divides: a rounding of the scale (see the file header on what that can do).
 template <int W>
 BNM_DEVICE void relu_quant_row(f32x2 (&row)[W]) {
-    float ma = 0.0f, mb = 0.0f;
+    float ma = 1e-5f, mb = 1e-5f;
 #pragma unroll
     for (int c = 0; c + 1 < W; c += 2) {
-        ma = __builtin_fmaxf(__builtin_fmaxf(ma, row[c][0]), row[c + 1][0]);      // (v_max3_f32; starting from 0: the ReLU)
+        ma = __builtin_fmaxf(__builtin_fmaxf(ma, row[c][0]), row[c + 1][0]);      // (v_max3_f32)
         mb = __builtin_fmaxf(__builtin_fmaxf(mb, row[c][1]), row[c + 1][1]);
     }
     static_assert(W % 2 == 0, "even rows");
-    const f32x2 scale = {__fdiv_rn(127.0f, __builtin_fmaxf(ma, 1e-5f)), __fdiv_rn(127.0f, __builtin_fmaxf(mb, 1e-5f))};
-    const f32x2 inv = {__builtin_amdgcn_rcpf(scale[0]), __builtin_amdgcn_rcpf(scale[1])};
-    const f32x2 magic = splat(QC_MAGIC);
+    // (the reciprocals pass through an ordinary multiplication before the hand-written instruction reads them: hipcc does not see into
+    // inline assembly when it places the wait state a transcendental result needs in front of its first VALU reader)
+    f32x2 one = splat(1.0f);
+    asm volatile("" : "+v"(one));
+    const f32x2 rm = f32x2{__builtin_amdgcn_rcpf(ma), __builtin_amdgcn_rcpf(mb)} * one;
+    const f32x2 inv = f32x2{ma, mb} * splat(1.0f / 127.0f);
+    const f32x2 magic = splat(QC_MAGIC), c127 = splat(127.0f);
 #pragma unroll
     for (int c = 0; c < W; c++) {
-        const f32x2 r = {__builtin_fmaxf(row[c][0], 0.0f), __builtin_fmaxf(row[c][1], 0.0f)};
-        const f32x2 t = __builtin_elementwise_fma(r, scale, magic);
+        f32x2 u;
+        asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(u) : "v"(row[c]), "v"(rm));
+        const f32x2 t = __builtin_elementwise_fma(u, c127, magic);
         row[c] = (t - magic) * inv;
     }
 }

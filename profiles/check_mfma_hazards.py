@@ -11,6 +11,11 @@ instruction that names a register of the result before the required count has pa
 hipcc itself pads to; MFMA -> MFMA forwarding is interlocked and not checked).  Straight-line code only: the walk stops at
 branches.
 
+Round 6 added the second hazard hipcc cannot see through inline asm: the result of a TRANSCENDENTAL operation (v_rcp / v_rsq / v_sqrt /
+v_exp / v_log / v_sin / v_cos) needs one wait state before a non-transcendental VALU instruction reads it.  The first version of the
+one-kernel convolution front fed v_rcp_f32 results straight into a hand-written `v_pk_mul_f32 ... clamp` and read stale registers
+(every feature wrong by up to 35 %).
+
 usage: python profiles/check_mfma_hazards.py [object ...]      (default: every object under bitnetmcu_amd/_build)"""
 import os
 import re
@@ -21,6 +26,7 @@ import tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 REQUIRED = {"v_mfma_i32_32x32x32_i8": 12, "v_mfma_f32_32x32x2_f32": 20}
+TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
 REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
 
 
@@ -63,6 +69,9 @@ def check(ins):
     for i, text in enumerate(ins):
         op = text.split()[0]
         need = REQUIRED.get(op)
+        trans = need is None and op.startswith(TRANS)
+        if trans:
+            need = 1
         if need is None:
             continue
         dest = regs(text.split(None, 1)[1].split(",")[0])
@@ -77,6 +86,9 @@ def check(ins):
                 continue
             if o.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc", "s_swappc")):
                 break
+            if trans and (not o.startswith("v_") or o.startswith(TRANS)):      # (only VALU readers; transcendental -> transcendental forwards)
+                states += 1
+                continue
             if not o.startswith(("v_mfma", "v_smfmac")) and not o.startswith("s_") and " " in t:
                 hit = dest & regs(t.split(None, 1)[1])
                 if hit:
@@ -96,11 +108,11 @@ def main():
             continue
         for name, ins in kernels_of(text).items():
             n_k += 1
-            n_m += sum(1 for t in ins if t.split()[0] in REQUIRED)
+            n_m += sum(1 for t in ins if t.split()[0] in REQUIRED or t.split()[0].startswith(TRANS))
             for i, mf, k, t, states in check(ins):
                 n_bad += 1
                 print(f"{os.path.basename(obj)} {name[:60]}: +{k - i} instructions, {states} wait states behind\n    {mf}\n    {t}")
-    print(f"{n_k} kernels, {n_m} MFMAs: {n_bad} instructions touch a result register in flight")
+    print(f"{n_k} kernels, {n_m} MFMAs and transcendental operations: {n_bad} instructions touch a result register in flight")
     return 1 if n_bad else 0
 
 

@@ -52,6 +52,12 @@ def test_no_instruction_touches_an_mfma_result_in_flight():
     assert H.check([mf, "v_mov_b32_e32 v78, v35", "s_nop 10", wr]) == []
     assert H.check([mf, "v_mfma_i32_32x32x32_i8 v[14:29], v[0:3], v[4:7], v[14:29]", "s_nop 11", "v_lshlrev_b32_e32 v79, 8, v14"]) == []
     assert len(H.check([mf, "s_nop 9", "v_lshlrev_b32_e32 v79, 8, v14"])) == 1
+    # ... and round 6's: a transcendental result read by the very next VALU instruction (an inline-asm one: hipcc pads its own)
+    rcp = "v_rcp_f32_e32 v197, v11"
+    assert len(H.check([rcp, "v_pk_mul_f32 v[10:11], v[60:61], v[196:197] clamp"])) == 1
+    assert H.check([rcp, "s_nop 0", "v_pk_mul_f32 v[10:11], v[60:61], v[196:197] clamp"]) == []
+    assert H.check([rcp, "v_mov_b32_e32 v1, v2", "v_pk_mul_f32 v[10:11], v[60:61], v[196:197] clamp"]) == []
+    assert H.check([rcp, "v_sqrt_f32_e32 v3, v197"]) == []
     r = subprocess.run([sys.executable, os.path.join(util.REPO, "profiles", "check_mfma_hazards.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " 0 instructions touch a result register in flight" in r.stdout
