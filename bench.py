@@ -809,7 +809,54 @@ def extra_configs(a, np, torch, b, dev, images, cls, n, counters, stream_read):
                                           "counters_source": f"replayed from profiles/pmc_counters.json (pass {c.get('source')}, 1e7 rows per call; not measured by this run)"})
         del xq
         torch.cuda.empty_cache()
+    # ... and of the model trainingparameters.yaml names, CNNMNIST (models.py:93-139): the convolution front as ONE kernel
+    # (csrc/bnm_qat_cnn.hip), the FC stack behind it as the kernel above - float32 images in, float32 logits out, four launches
+    def qat_cnn_row(name, rows, note):
+        from bitnetmcu_amd import qat
+        torch.manual_seed(20240419)
+        mod = qat.CNNMNIST(96, 64, 0, cnn_width=64, QuantType="4bitsym", WScale="PerTensor", NormType="RMS", num_classes=10).to(dev)
+        gen = torch.Generator(device=dev).manual_seed(20240419)
+        xq = torch.randn(rows, 1, 16, 16, device=dev, generator=gen) * (torch.rand(rows, 1, 1, 1, device=dev, generator=gen) * 2 + 0.05)
+        torch.cuda.synchronize()
+        out = [None]
+        with torch.no_grad():
+            fused = bool(mod.front_fused(xq) and mod.fused(xq))
+            def step():
+                out[0] = mod(xq)
+            _, ms = timed_steps(torch, step, 10, 2)
+            rate = rows / (float(np.median(ms)) * 1e-3)
+            ok = None
+            if not a.no_verify:
+                # floating point: against the layer-by-layer path (qat.BitConv2d's and BitLinear's ops, each pinned to the reference's
+                # layer by tests/test_gpu_qat.py) on a sample, the end-to-end tolerances of tests/test_gpu_qat_model.py
+                m = min(rows, 4096)
+                y = xq[:m]
+                for k in list(mod.model):
+                    y = k(y)
+                want = mod.classifier(y)
+                err = (out[0][:m] - want).abs().max(dim=1).values / want.abs().max(dim=1).values
+                ok = bool(fused and (err <= 5e-4).float().mean() >= 0.9 and err.max() <= 6e-2 and torch.isfinite(out[0]).all())
+        # the front's arithmetic: 64 channels x (196 + 144 + 16) outputs x 9 multiply-adds = 205,056 per image = 1,602 packed
+        # wave64 instructions (v_pk_fma_f32: 128 multiply-adds each)
+        alg = 205056 / 128.0
+        res[name] = {"model": "CNNMNIST 64 channels, FC 256-96-64-10, 8bit convolutions / 2bitsym + 4bitsym FC, RMS (random weights)", "rows": rows,
+                     "steps": 10, "warmup": 2, "value": rate, "unit": "images/s", "median_call_ms": float(np.median(ms)), "min_call_ms": float(np.min(ms)),
+                     "kernel": "qat_cnn_prep_kernel+qat_cnn_front_kernel+qat_model_prep_kernel+qat_fc_model_fwd_kernel", "launches_per_step": 4,
+                     "verified_vs_oracle": ok, "verified_against": "the layer-by-layer ops in fp32 (floating-point op: tolerances, not bit-exact)",
+                     "note": note,
+                     "roofline": {"bound": "valu", "unit": "wave64 VALU instructions/s", "peak": VALU_PEAK_WAVE_INSTR_PER_S, "achieved": rate * alg,
+                                  "frac": rate * alg / VALU_PEAK_WAVE_INSTR_PER_S, "algorithmic_valu_per_image": alg,
+                                  "definition": "the front's 205,056 multiply-adds per image as packed float32 instructions (128 per wave64 instruction) x images / the "
+                                                "median time of a whole call (four launches), against 1,024 SIMDs x 2.4 GHz / 4 clocks"}}
+        c = cj.get("qat_cnn_front_kernel")
+        if c and "valu_per_image" in c:
+            res[name]["roofline"].update({"valu_per_image": c["valu_per_image"], "pipe_utilisation": rate * c["valu_per_image"] / VALU_PEAK_WAVE_INSTR_PER_S,
+                                          "traffic_bytes_per_image": c.get("hbm_bytes_per_image"), "valu_busy_frac": c.get("valu_busy_frac"),
+                                          "counters_source": f"replayed from profiles/pmc_counters.json (pass {c.get('source')}; not measured by this run)"})
+        del xq
+        torch.cuda.empty_cache()
     if a.model == "fc_4bitsym_64" and n >= 1000:
+        qat_cnn_row("qat_cnn_forward", min(n, 1_000_000), "QAT forward of the reference's CNNMNIST, 1e6 images per call (convolution front + FC stack: two kernels)")
         qat_row("qat_fc_forward", min(n, 1_000_000), "QAT forward of the whole FC model, 1e6 rows per call (VERDICT r05 next #4)")
         if n >= 10_000_000:
             qat_row("qat_fc_forward_1e7", 10_000_000, "the same at 1e7 rows per call")

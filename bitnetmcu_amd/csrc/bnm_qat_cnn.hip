@@ -273,10 +273,13 @@ size_t bnmk_qat_cnn_front_workspace_bytes(uint32_t channels) { return (size_t)3u
 template <int IPW>
 static hipError_t qat_cnn_front_launch(const float *x, uint64_t n, const float *taps, uint32_t channels, float *features, hipStream_t st) {
     const uint64_t groups = (n + IPW - 1) / IPW;
-    uint64_t blocks = (groups + 3u) / 4u;
-    const uint64_t cap = (uint64_t)bnm_num_cus() * 2u;
-    if (blocks > cap) blocks = cap;
     const size_t lds = 4u * 2u * IPW * 1024u;
+    // persistent waves: as many workgroups as are resident at once (one per CU at this kernel's ~300 registers; asked, not assumed)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qat_cnn_front_kernel<IPW>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    uint64_t blocks = (groups + 3u) / 4u;
+    const uint64_t cap = (uint64_t)bnm_num_cus() * (uint64_t)per_cu;
+    if (blocks > cap) blocks = cap;
     qat_cnn_front_kernel<IPW><<<dim3((unsigned)blocks), dim3(256), lds, st>>>(x, n, taps, channels, features);
     return hipGetLastError();
 }

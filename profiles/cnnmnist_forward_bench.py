@@ -31,15 +31,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--front-only", action="store_true", help="only the one-kernel convolution front (counter passes)")
     a = ap.parse_args()
     torch.manual_seed(0)
     m = qat.CNNMNIST(96, 64, 0, cnn_width=64, QuantType="4bitsym", WScale="PerTensor", NormType="RMS", num_classes=10).cuda()
     x = torch.randn(a.rows, 1, 16, 16, device="cuda") * (torch.rand(a.rows, 1, 1, 1, device="cuda") * 2 + 0.05)
     out = {"rows": a.rows}
+    if a.front_only:
+        cs = [c for c in m.model if isinstance(c, qat.BitConv2d)]
+        ms = timed(lambda: qat.cnn_front_forward(x, [c.weight for c in cs], [c.s for c in cs]), a.steps, 1)
+        print(json.dumps({"rows": a.rows, "front_fused_ms": ms, "front_fused_images_per_s": a.rows / (ms * 1e-3)}))
+        return
     with torch.no_grad():
         f = m.front(x)
         ms_all = timed(lambda: m(x), a.steps)
         ms_front = timed(lambda: m.front(x), a.steps)
+        def layer_by_layer():
+            y = x
+            for k in list(m.model)[:9]:
+                y = k(y)
+            return y
+        ms_layers = timed(layer_by_layer, 3, 1)
+        out.update({"front_layer_by_layer_ms": ms_layers, "front_layer_by_layer_images_per_s": a.rows / (ms_layers * 1e-3)})
         ls = m.bitlinear_layers()
         ms_fc = timed(lambda: qat.fc_model_forward(f, [l.weight for l in ls], [l.s for l in ls], [l.QuantType for l in ls], "RMS"), a.steps)
         if hasattr(qat, "cnn_front_forward"):
