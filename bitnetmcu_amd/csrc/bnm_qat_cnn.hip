@@ -210,8 +210,11 @@ __global__ __launch_bounds__(256) void qat_cnn_front_kernel(const float *__restr
             for (int k = 0; k < 4; k++) xin[r][k] = *(const f32x4 *)(img + 64 * r + 16 * k);
         static_for<0, 14>([&](auto RI) {
             constexpr int r = decltype(RI)::value;
+            // input row r + 2 is asked for two rows ahead of its first use (a lone wave per SIMD has nobody to hide an LDS round trip
+            // behind; the scheduling barrier keeps hipcc from sinking the reads next to their use, which it otherwise does)
 #pragma unroll
             for (int k = 0; k < 4; k++) xin[(r + 2) % 3][k] = *(const f32x4 *)(img + 64 * (r + 2) + 16 * k);
+            __builtin_amdgcn_sched_barrier(0);
             // ---- conv1 row r: taps are pairs, the input value is a splat ----
             f32x2 (&y1)[14] = q1[r % 3];
 #pragma unroll
@@ -246,6 +249,10 @@ __global__ __launch_bounds__(256) void qat_cnn_front_kernel(const float *__restr
                 }
             }
         });
+        // the next group's images (loaded at the top of this iteration) are quantised BEFORE this group's features are stored: loads
+        // and stores retire through one counter in order, and a wait for the loads behind the stores would sit out the stores' way to HBM
+        if (gn < groups) quantise_group(stage + (cur ^ 1u) * (IPW * 1024u));
+        __builtin_amdgcn_sched_barrier(0);
         // ---- features: channel a's 2 x 2, then channel b's: 32 consecutive bytes of the image's row ----
         const uint64_t image = g * (uint64_t)IPW + (uint64_t)slot;
         if (active && image < n) {
@@ -253,7 +260,6 @@ __global__ __launch_bounds__(256) void qat_cnn_front_kernel(const float *__restr
             __builtin_nontemporal_store(f32x4{out[0][0][0], out[0][1][0], out[1][0][0], out[1][1][0]}, (f32x4 *)f);
             __builtin_nontemporal_store(f32x4{out[0][0][1], out[0][1][1], out[1][0][1], out[1][1][1]}, (f32x4 *)(f + 4));
         }
-        if (gn < groups) quantise_group(stage + (cur ^ 1u) * (IPW * 1024u));
         cur ^= 1u;
     }
 }
