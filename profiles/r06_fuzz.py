@@ -4,7 +4,9 @@
   2. the whole-model QAT forward on random shapes (tests/test_gpu_qat_model.py::test_fuzz_random_model_shapes);
   3. the resident one-image kernel on random FC models (the FC fuzz's generator): every model it serves, 200 one-image calls on
      synthetic + extreme images against the oracle, interleaved with a batched call.
-usage: python profiles/r06_fuzz.py [first_seed] [fc] [cnn] [float] [qat] [resident]"""
+  4. the one-kernel convolution front of the QAT forward on random channel counts / QuantTypes / magnitudes
+     (tests/test_gpu_qat_cnn.py::test_fuzz_random_fronts).
+usage: python profiles/r06_fuzz.py [first_seed] [fc] [cnn] [float] [qat] [resident] [front]"""
 import os
 import sys
 import time
@@ -19,6 +21,7 @@ import util                      # noqa: E402
 import bitnetmcu_amd as b        # noqa: E402
 import test_gpu_parity as t      # noqa: E402
 import test_gpu_qat_model as q   # noqa: E402
+import test_gpu_qat_cnn as qc    # noqa: E402
 
 
 def resident(seed, orc):
@@ -55,10 +58,10 @@ def resident(seed, orc):
 
 
 def main():
-    a = [int(v) for v in sys.argv[1:]] + [None] * 6
+    a = [int(v) for v in sys.argv[1:]] + [None] * 7
     first = a[0] if a[0] is not None else 3000
     counts = [a[1] if a[1] is not None else 100, a[2] if a[2] is not None else 60, a[3] if a[3] is not None else 100,
-              a[4] if a[4] is not None else 300, a[5] if a[5] is not None else 150]
+              a[4] if a[4] is not None else 300, a[5] if a[5] is not None else 150, a[6] if a[6] is not None else 200]
     orc = util.load_oracle()
     served = [0]
 
@@ -67,7 +70,8 @@ def main():
     for name, fn, count in (("FC", t.test_fuzz_random_models_every_available_path, counts[0]), ("CNN", t.test_fuzz_random_cnn_models, counts[1]),
                             ("FC float input", t.test_fuzz_fused_float_input_kernel_on_random_models, counts[2]),
                             ("QAT whole-model forward", lambda s, g, o: q.test_fuzz_random_model_shapes(s, g), counts[3]),
-                            ("resident one-image kernel", res, counts[4])):
+                            ("resident one-image kernel", res, counts[4]),
+                            ("QAT convolution front", lambda s, g, o: qc.test_fuzz_random_fronts(s, g), counts[5])):
         t0, bad = time.time(), []
         for seed in range(first, first + count):
             try:

@@ -107,6 +107,40 @@ def test_quant_types(qt, gpu_ok):
     close(got, y.flatten(1), qt)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_random_fronts(seed, gpu_ok):
+    """Random fronts the kernel serves - an even channel count of 16 .. 128, a QuantType per layer, weights and clipping scalars of
+    random magnitude (weights past the clipping range included), images from a tenth to ten times the usual brightness, ragged
+    batches - against the per-layer ops."""
+    rng = np.random.default_rng(5000 + seed)
+    channels = 2 * int(rng.integers(8, 65))
+    qts = [str(rng.choice(["8bit", "4bitsym", "Ternary", "Binary", "2bitsym", "5bitsym", "FP130", "4bit", "NF4", "BinarySym"])) for _ in range(3)]
+    if seed % 3 == 0:
+        qts = ["8bit"] * 3      # (CNNMNIST's own)
+    n = int(rng.choice([1, 2, 5, 31, 64, 257, 1000, 4099]))
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ws = [torch.randn(channels, 1, 3, 3, device="cuda", generator=g) * float(rng.choice([0.05, 0.3, 1.0])) for _ in range(3)]
+    ss = [(w.abs().mean() / 0.25 * float(rng.choice([0.5, 1.0, 3.0]))).reshape(1) for w in ws]
+    x = torch.randn(n, 1, 16, 16, device="cuda", generator=g) * (torch.rand(n, 1, 1, 1, device="cuda", generator=g) * 2 + 0.05) * float(rng.choice([0.1, 1.0, 10.0]))
+    assert qat.cnn_front_supported(channels, ss, qts), (channels, qts)
+    got = qat.cnn_front_forward(x, ws, ss, qts)
+    y = x
+    for l in range(3):
+        y = torch.relu(qat.bitconv2d_forward(y, ws[l], ss[l], qts[l], "None", groups=1 if l == 0 else channels))
+        if l:
+            y = torch.nn.functional.max_pool2d(y, 2)
+    want = y.flatten(1)
+    # an image whose features are all zero in one path (every conv3 output negative) must be all zero in the other - or carry only what a
+    # flipped step leaves (tiny); elsewhere the file's tolerances
+    e = distances(got, want)
+    dead = (want.abs().max(dim=1).values == 0).cpu().numpy()
+    assert (got[torch.from_numpy(dead).cuda()].abs().max() if dead.any() else torch.zeros(())) <= 1e-2 * float(want.abs().max().clamp(min=1e-30)), (seed, channels, qts)
+    live = ~dead
+    if live.any():
+        el = e[live]
+        assert (el <= 1e-5).sum() >= len(el) - max(2, len(el) // 10) and el.max() <= 2e-2, (seed, channels, qts, n, float((el <= 1e-5).mean()), float(el.max()))
+
+
 def test_rows_do_not_depend_on_the_batch_and_special_images(gpu_ok):
     """200,000 images (more groups than the launch has waves): every image's features equal the features it gets in a small batch,
     bit for bit.  An all-zero image and an image with one non-zero pixel: finite features (NormType 'None': no 0 / 0), equal to the
