@@ -25,6 +25,7 @@
 // bytes per image.
 #include "bnm_qat_math.hpp"
 #include "bnm_quantise_f32.hpp"
+#include <atomic>
 
 namespace {
 
@@ -280,9 +281,16 @@ template <int IPW>
 static hipError_t qat_cnn_front_launch(const float *x, uint64_t n, const float *taps, uint32_t channels, float *features, hipStream_t st) {
     const uint64_t groups = (n + IPW - 1) / IPW;
     const size_t lds = 4u * 2u * IPW * 1024u;
-    // persistent waves: as many workgroups as are resident at once (one per CU at this kernel's ~300 registers; asked, not assumed)
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qat_cnn_front_kernel<IPW>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    // persistent waves: as many workgroups as are resident at once (one per CU at this kernel's ~300 registers; asked once per
+    // device, not assumed)
+    static std::atomic<int> resident[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int per_cu = resident[dev].load(std::memory_order_relaxed);
+    if (per_cu < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qat_cnn_front_kernel<IPW>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        resident[dev].store(per_cu, std::memory_order_relaxed);
+    }
     uint64_t blocks = (groups + 3u) / 4u;
     const uint64_t cap = (uint64_t)bnm_num_cus() * (uint64_t)per_cu;
     if (blocks > cap) blocks = cap;
