@@ -311,6 +311,7 @@ hipError_t bnmk_qat_cnn_front_forward(const float *x, uint64_t n, uint32_t chann
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
     const uint32_t pairs = channels / 2u, fit = 64u / pairs;
+    if (fit >= 8u) return qat_cnn_front_launch<8>(x, n, taps, channels, features, st);
     if (fit >= 4u) return qat_cnn_front_launch<4>(x, n, taps, channels, features, st);
     if (fit >= 2u) return qat_cnn_front_launch<2>(x, n, taps, channels, features, st);
     return qat_cnn_front_launch<1>(x, n, taps, channels, features, st);
