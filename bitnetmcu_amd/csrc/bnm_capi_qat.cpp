@@ -67,7 +67,7 @@ int bnm_qat_model_forward_device(const float *d_x, uint64_t n, uint32_t n_layers
     }
     if (norm_type < BNM_QAT_NORM_RMS || norm_type > BNM_QAT_NORM_NONE) return fail(BNM_EINVAL, "unknown norm_type");
     if (!bnmk_qat_model_supported(n_layers, widths, quant_types, norm_type))
-        return fail(BNM_EUNSUPPORTED, "the fused model forward serves 256 inputs, hidden widths <= 192, <= 64 classes, int8-level QuantTypes "
+        return fail(BNM_EUNSUPPORTED, "the fused model forward serves <= 256 inputs, hidden widths <= 192, <= 64 classes, int8-level QuantTypes "
                                       "and NormType RMS / Lin / LayerNorm (bnm_qat_model_supported); run the layers with bnm_qat_bitlinear_forward_device");
     if (workspace_bytes < bnmk_qat_model_workspace_bytes(n_layers, widths)) return fail(BNM_EINVAL, "workspace too small (bnm_qat_model_workspace_bytes)");
     if (((uintptr_t)d_workspace & 15u) || ((uintptr_t)d_logits & 15u) || ((uintptr_t)d_x & 15u))

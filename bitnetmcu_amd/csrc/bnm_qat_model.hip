@@ -68,6 +68,10 @@ struct QatPrepArgs {
     uint32_t s_count[QM_MAX_LAYERS];
     int qt[QM_MAX_LAYERS];
     uint32_t d_in[QM_MAX_LAYERS];
+    // fewer than 256 inputs (rows zero-padded to 256 floats by the caller): the model kernel's Normalize of layer 1 averages over 256
+    // values, the reference over d - its denominator comes out sqrt(d / 256) ('Lin': d / 256) too small, the layer's outputs that much
+    // too large: folded into layer 1's reciprocal weight scales here (everything behind is the kernel's as it stands)
+    float in_fix;
 };
 
 // lanes < 32: a over {l, l + 32}; lanes >= 32: b
@@ -212,8 +216,9 @@ __global__ __launch_bounds__(1024) void qat_model_prep_kernel(QatPrepArgs a, Qat
         frag[o] = b;
     }
     float *winv = (float *)(image + d.winv_off[l]);
+    const float fix = l == 0 ? a.in_fix : 1.0f;
     for (uint32_t row = tid; row < Mt * 32u; row += stride)
-        winv[row] = row < k ? __fdiv_rn(1.0f, qat_weight_scale(qt, a.s[l][a.s_count[l] > 1 ? row : 0], mean_abs)) : 0.0f;
+        winv[row] = row < k ? __fdiv_rn(1.0f, qat_weight_scale(qt, a.s[l][a.s_count[l] > 1 ? row : 0], mean_abs)) * fix : 0.0f;
     if (a.w_deq[l])
         for (uint64_t i = tid; i < count; i += stride) {
             const float sc = qat_weight_scale(qt, a.s[l][a.s_count[l] > 1 ? (uint32_t)(i / din) : 0], mean_abs);
@@ -559,7 +564,7 @@ struct QatModelPlan {
 };
 
 bool qat_model_plan(uint32_t n_layers, const uint32_t *widths, QatModelPlan &p) {
-    if (n_layers < 2 || n_layers > (uint32_t)QM_MAX_LAYERS || widths[0] != 256u) return false;
+    if (n_layers < 2 || n_layers > (uint32_t)QM_MAX_LAYERS || widths[0] == 0u || widths[0] > 256u) return false;
     QatModelDesc &d = p.d;
     d = QatModelDesc{};
     d.n_layers = n_layers;
@@ -660,7 +665,8 @@ bool bnmk_qat_model_supported(uint32_t n_layers, const uint32_t *widths, const i
     if (!qat_model_plan(n_layers, widths, p)) return false;
     for (uint32_t l = 0; l < n_layers; l++)
         if (!qat_i8_factor(quant_types[l])) return false;
-    return norm_type == BNM_QAT_NORM_RMS || norm_type == BNM_QAT_NORM_LIN || norm_type == BNM_QAT_NORM_LAYERNORM;
+    // (LayerNorm subtracts the row's mean from the padding columns as well: 256 inputs only)
+    return norm_type == BNM_QAT_NORM_RMS || norm_type == BNM_QAT_NORM_LIN || (norm_type == BNM_QAT_NORM_LAYERNORM && widths[0] == 256u);
 }
 
 hipError_t bnmk_qat_model_forward(const float *x, uint64_t n, uint32_t n_layers, const uint32_t *widths, const float *const *w,
@@ -680,6 +686,7 @@ hipError_t bnmk_qat_model_forward(const float *x, uint64_t n, uint32_t n_layers,
         p.d.inv_factor[l] = 1.0f / (float)qat_i8_factor(quant_types[l]);
         perout = perout || s_count[l] > 1;
     }
+    a.in_fix = widths[0] == 256u ? 1.0f : norm_type == BNM_QAT_NORM_LIN ? (float)widths[0] / 256.0f : sqrtf((float)widths[0] / 256.0f);
     char *image = (char *)workspace;
     uint32_t *counter = (uint32_t *)(image + p.d.image_bytes);
     qat_model_prep_kernel<<<dim3(n_layers, QM_PREP_SPLIT), dim3(1024), 0, st>>>(a, p.d, image, counter);

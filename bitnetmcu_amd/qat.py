@@ -83,8 +83,8 @@ def bitlinear_forward(x, w, s, quant_type, norm_type, return_int=False, return_w
 
 
 def fc_model_supported(widths, quant_types, norm_type):
-    """True when the ONE-kernel whole-model forward serves this stack of BitLinear layers (bnm_qat_model_supported): 256 inputs,
-    hidden widths <= 192, <= 64 classes, QuantTypes whose levels are int8, NormType RMS, Lin or LayerNorm."""
+    """True when the ONE-kernel whole-model forward serves this stack of BitLinear layers (bnm_qat_model_supported): at most 256
+    inputs, hidden widths <= 192, <= 64 classes, QuantTypes whose levels are int8, NormType RMS, Lin or (256 inputs) LayerNorm."""
     if any(q not in QUANT_TYPES for q in quant_types) or norm_type not in NORM_TYPES:
         return False
     nl = len(quant_types)
@@ -101,7 +101,8 @@ _model_workspaces = {}
 def fc_model_forward(x, weights, scalars, quant_types, norm_type, return_hidden=False, return_w_deq=False):
     """The forward pass of a stack of BitLinear layers with ReLU between them (models.py:70-90 FCMNIST) in ONE kernel
     (bnm_qat_model_forward_device, csrc/bnm_qat_model.hip) behind a weight-preparation launch.
-    x [n, 256] (or [n, 1, 16, 16]: flattened), weights [w_l [k_l, d_l]], scalars [s_l] (each a scalar tensor or [k_l] / [k_l, 1]),
+    x [n, d <= 256] (or [n, 1, 16, 16]: flattened; d < 256: padded with zeros for the kernel here), weights [w_l [k_l, d_l]], scalars
+    [s_l] (each a scalar tensor or [k_l] / [k_l, 1]),
     quant_types [str] one per layer, all float32 CUDA tensors.  Returns logits [n, classes]; with return_hidden also the hidden
     layers' outputs after ReLU as ONE tensor [n, sum of hidden widths] (layer after layer within a row); with return_w_deq also
     the list of fake-quantised weights w_int / w_scale."""
@@ -111,6 +112,8 @@ def fc_model_forward(x, weights, scalars, quant_types, norm_type, return_hidden=
     nl = len(weights)
     x2 = x.flatten(1).contiguous().float()
     n, d = x2.shape
+    if d < 256:      # (the kernel reads rows of 256 floats; the zero columns meet zero weight fragments)
+        x2 = F.pad(x2, (0, 256 - d))
     ws = [w.contiguous().float() for w in weights]
     ss = [torch.as_tensor(s, dtype=torch.float32, device=x.device).reshape(-1).contiguous() for s in scalars]
     widths = [d] + [w.shape[0] for w in ws]

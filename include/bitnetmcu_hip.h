@@ -327,7 +327,8 @@ BNM_API int bnm_qat_bitconv2d_forward_device(const float *d_x, uint64_t n, uint3
 
 /* Whole-model QAT forward (models.py:56-90 FCMNIST; the FC stack of CNNMNIST, :120-135): n_layers BitLinear layers
  * (BitNetMCU.py:214-235, bias-free) with ReLU between them, ONE kernel per call behind a per-call weight preparation launch:
- *   widths[0] = 256 inputs (the 16x16 image, or CNNMNIST's 64 channels x 4), widths[1 .. n_layers-1] the hidden widths
+ *   widths[0] <= 256 inputs (the 16x16 image, or CNNMNIST's channels x 4; fewer than 256: d_x still holds rows of 256 floats, the
+ *   caller pads them with zeros, and NormType LayerNorm is not served), widths[1 .. n_layers-1] the hidden widths
  *   (each <= 192), widths[n_layers] the classes (<= 64); 2 <= n_layers <= BNM_QAT_MODEL_MAX_LAYERS.
  *   d_w[l] [widths[l+1]][widths[l]] float32, d_s[l] the layer's clipping scalar(s), s_count[l] 1 (PerTensor) or widths[l+1]
  *   (PerOutput), quant_types[l] the layer's QuantType - d_w / d_s / s_count / quant_types / widths are HOST arrays (of device

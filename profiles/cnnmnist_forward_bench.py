@@ -31,12 +31,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--channels", type=int, default=64, help="cnn_width (the FC stack then has 4 x channels inputs)")
     ap.add_argument("--front-only", action="store_true", help="only the one-kernel convolution front (counter passes)")
     a = ap.parse_args()
     torch.manual_seed(0)
-    m = qat.CNNMNIST(96, 64, 0, cnn_width=64, QuantType="4bitsym", WScale="PerTensor", NormType="RMS", num_classes=10).cuda()
+    m = qat.CNNMNIST(96, 64, 0, cnn_width=a.channels, QuantType="4bitsym", WScale="PerTensor", NormType="RMS", num_classes=10).cuda()
     x = torch.randn(a.rows, 1, 16, 16, device="cuda") * (torch.rand(a.rows, 1, 1, 1, device="cuda") * 2 + 0.05)
-    out = {"rows": a.rows}
+    out = {"rows": a.rows, "channels": a.channels}
     if a.front_only:
         cs = [c for c in m.model if isinstance(c, qat.BitConv2d)]
         ms = timed(lambda: qat.cnn_front_forward(x, [c.weight for c in cs], [c.s for c in cs]), a.steps, 1)

@@ -112,6 +112,28 @@ def main():
     for l, (m, g) in enumerate(zip(qlayers, grads[1:])):
         out[f"cnn/w{l}"], out[f"cnn/s{l}"], out[f"cnn/gw{l}"] = m.weight.detach().numpy(), m.s.detach().numpy().reshape(-1).astype(np.float32), g.numpy()
     out["cnn/state_keys"] = np.array(sorted(cnn.state_dict().keys()))
+    # ---- a CNNMNIST whose FC stack has fewer than 256 inputs: 32 channels (128 features), 'Lin' norm; and 48 channels (192), RMS ----
+    for tag, (cw, w1, w2, nt, seed) in {"cnn32": (32, 64, 48, "Lin", 3201), "cnn48": (48, 80, 64, "RMS", 4801)}.items():
+        torch.manual_seed(seed)
+        gen = torch.Generator().manual_seed(seed)
+        cnn = ref.CNNMNIST(w1, w2, 0, cnn_width=cw, QuantType="4bitsym", WScale="PerTensor", NormType=nt, num_classes=10)
+        qlayers = [m for m in list(cnn.model) + [cnn.classifier] if hasattr(m, "weight_quant")]
+        for m in qlayers:
+            m.update_clipping_scalar(m.weight.data, "octav", 0.25)
+        n = 40
+        x = images(n, gen)
+        x[ZERO_ROW] = x[ZERO_ROW + 1]
+        xr = x.reshape(n, 1, 16, 16).clone().requires_grad_(True)
+        feats = []
+        hook = cnn.model[8].register_forward_hook(lambda mod, i, o: feats.append(o.detach().numpy().copy()))
+        logits = cnn(xr)
+        hook.remove()
+        gy = torch.randn(n, 10, generator=gen)
+        grads = torch.autograd.grad((logits * gy).sum(), [xr] + [m.weight for m in qlayers])
+        wide[f"{tag}/cfg"] = np.array([cw, w1, w2, 10], dtype=np.int64)
+        wide[f"{tag}/x"], wide[f"{tag}/logits"], wide[f"{tag}/features"], wide[f"{tag}/gy"], wide[f"{tag}/gx"] = x.numpy(), logits.detach().numpy(), feats[0], gy.numpy(), grads[0].numpy()
+        for l, (m, g) in enumerate(zip(qlayers, grads[1:])):
+            wide[f"{tag}/w{l}"], wide[f"{tag}/s{l}"], wide[f"{tag}/gw{l}"] = m.weight.detach().numpy(), m.s.detach().numpy().reshape(-1).astype(np.float32), g.numpy()
     path = os.path.join(HERE, "qat_fc_model.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes;", {t: (out[f"{t}/logits"].shape, bool(np.isnan(out[f"{t}/logits"][ZERO_ROW]).all()), bool(np.isnan(out[f"{t}/logits"]).any())) for t in CONFIGS})
