@@ -97,12 +97,14 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
                            f"-Wl,-rpath,{libdir}", "-o", str(exe)])
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
-    exe = tmp_path / "qat_forward"      # the whole-model training forward from C (the GPU run: tests/test_gpu_qat_model.py)
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", hdr,
-                           os.path.join(REPO, "examples", "qat_forward.c"), "-L", libdir, "-lbitnetmcu_hip",
-                           f"-Wl,-rpath,{libdir}", "-o", str(exe)])
-    r = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert r.returncode == 2 and "usage" in r.stderr
+    # the training forward from C: the whole FC model, the whole CNNMNIST (the GPU runs: tests/test_gpu_qat_model.py, test_gpu_qat_cnn.py)
+    for name in ("qat_forward", "qat_cnn_forward"):
+        exe = tmp_path / name
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", hdr,
+                               os.path.join(REPO, "examples", name + ".c"), "-L", libdir, "-lbitnetmcu_hip",
+                               f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+        r = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert r.returncode == 2 and "usage" in r.stderr
 
 
 @pytest.mark.parametrize("name", ["fc_4bitsym_64", "mcu_1k", "tern_96", "cnn_64"])

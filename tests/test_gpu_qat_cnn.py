@@ -203,3 +203,32 @@ def test_unsupported_configurations_are_refused_not_emulated(gpu_ok):
     assert lib.bnm_qat_cnn_front_forward_device(*args(qa=(C.c_int * 3)(10, 0, 10))) == -3
     assert int(lib.bnm_qat_cnn_front_workspace_bytes(64)) == 3 * 64 * 9 * 4
     torch.cuda.synchronize()
+
+
+def test_c_host_runs_the_whole_cnnmnist_forward(tmp_path, gpu_ok):
+    """examples/qat_cnn_forward.c: a gcc-only host that chains the two kernels (convolution front, FC stack) on the reference's own
+    CNNMNIST fixture - the logits it prints are the bits the Python module returns under torch.no_grad() and pass the end-to-end
+    tolerance against the reference module's."""
+    import subprocess
+    m = golden_module()
+    convs = [c for c in m.model if isinstance(c, qat.BitConv2d)]
+    fcs = m.bitlinear_layers()
+    head = np.array([64, len(fcs)] + [f.out_features for f in fcs] + [qat.QUANT_TYPES[c.QuantType] for c in convs] +
+                    [qat.QUANT_TYPES[f.QuantType] for f in fcs] + [qat.NORM_TYPES[fcs[0].NormType]], dtype=np.int32)
+    with open(tmp_path / "model.f32", "wb") as f:
+        f.write(head.tobytes())
+        for layer in convs + fcs:
+            f.write(layer.s.detach().cpu().numpy().astype(np.float32).reshape(-1)[:1].tobytes())
+            f.write(layer.weight.detach().cpu().numpy().astype(np.float32).tobytes())
+    x = torch.from_numpy(GM["cnn/x"]).cuda().reshape(-1, 1, 16, 16)
+    (tmp_path / "images.f32").write_bytes(GM["cnn/x"].astype(np.float32).tobytes())
+    exe = util.compile_c_host("qat_cnn_forward.c", tmp_path)
+    out = subprocess.run([exe, str(tmp_path / "model.f32"), str(tmp_path / "images.f32")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = np.array([[float(v) for v in line.split()] for line in out.stdout.splitlines()], dtype=np.float32)
+    with torch.no_grad():
+        want = m(x).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ref = GM["cnn/logits"]
+    err = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    assert (err <= 5e-4).mean() >= 0.9 and err.max() <= 6e-2, ((err <= 5e-4).mean(), err.max())
