@@ -3,7 +3,7 @@
 // BitConv2d(C -> C, 3x3, depthwise) -> ReLU -> MaxPool 2x2 -> BitConv2d(C -> C, 3x3, depthwise) -> ReLU -> MaxPool 2x2, every
 // BitConv2d with NormType 'None' (BitNetMCU.py:285-305: activation_quant per image ROW of each plane - the maximum over the last
 // dimension, :125-127 -, weight_quant, F.conv2d).  Layer by layer (bnm_qat.hip: one workgroup per image and channel, every plane
-// through HBM) the front runs at 3-4 x 10^6 images/s and is 99.9 % of the model's forward pass.  gfx950 only.  Floating point:
+// through HBM) the front runs at 3-7 x 10^6 images/s and is 99.9 % of the model's forward pass.  gfx950 only.  Floating point:
 // parity with the reference module within the tolerances tests/test_gpu_qat_cnn.py states, not bit-exact.
 //
 //   qat_cnn_prep_kernel    one workgroup per layer, once per call: the taps w_int / w_scale (the straight-through forward value) of
@@ -12,7 +12,7 @@
 //                          front for them in registers, both channels side by side in the halves of v_pk_fma_f32:
 //     * the wave's images arrive as one float4 per lane and image (a row of 16 = four lanes: the row maximum is two DPP steps),
 //       are quantised with the reference's own float32 operations (127 / max, round, / scale) and parked in LDS, from where every
-//       lane of the image reads the rows back as broadcasts;
+//       lane of the image reads the rows back as broadcasts, two rows ahead of their use;
 //     * conv1's taps are (w_a, w_b) pairs against a splat of the input value (op_sel picks the half: no extra move), the depthwise
 //       layers' operands are (x_a, x_b) pairs: nine v_pk_fma_f32 per pair of outputs, 3,204 per lane and image;
 //     * rows are produced in order and consumed at once - conv1 row r completes the three-row window of conv2 row r - 2, two of
@@ -21,8 +21,8 @@
 //     * activation_quant of a row is per lane: the row's maximum m with v_max3_f32, u = clamp(y / m, 0, 1) (v_pk_mul_f32 with the
 //       clamp modifier: the ReLU costs nothing), q = rne(127 u) as (127 u + 1.5 * 2^23) - 1.5 * 2^23, x_quant = q m / 127;
 //     * a lane's eight features are 32 consecutive bytes of the image's row of 4 C floats.
-// Bound: VALU issue (~4,900 instructions per lane and image, two thirds of them the packed multiply-adds; measured: 0.84 busy); HBM sees 1 KiB + 16 C
-// bytes per image.
+// Bound: VALU issue (~4,900 instructions per lane and image, two thirds of them the packed multiply-adds; measured: 0.84 busy); HBM
+// sees 1 KiB + 16 C bytes per image.
 #include "bnm_qat_math.hpp"
 #include "bnm_quantise_f32.hpp"
 #include <atomic>
