@@ -331,7 +331,27 @@ def ste_conv_formula(x, w, s, quant_type, norm_type, stride=1, padding=0, groups
     return F.conv2d(x_quant, w_quant, groups=groups, stride=stride, padding=padding, bias=None)
 
 
+def depthwise_conv_backward(gy, x_q, w_q, padding):
+    """Gradients of y = F.conv2d(x_q, w_q, stride 1, padding, groups = channels) for a depthwise layer (one tap set per channel) from
+    library FORWARD passes only: the input gradient is the full correlation of gy with the flipped taps (a depthwise convolution of the
+    padded gy), the weight gradient kh x kw slice-multiply-reduce passes.  (The library's own depthwise convolution_backward runs at
+    66 GFLOP/s on this GPU - 41 ms for 16,384 images of 64 channels x 14 x 14, 20 x its forward - and is all of a CNNMNIST training step:
+    profiles/probes/cnnmnist_backward_parts.py.)"""
+    kh, kw = w_q.shape[2], w_q.shape[3]
+    ph, pw = _pair(padding)
+    gx = F.conv2d(F.pad(gy, (kw - 1 - pw, kw - 1 - pw, kh - 1 - ph, kh - 1 - ph)), w_q.flip(2, 3), groups=w_q.shape[0])
+    xp = F.pad(x_q, (pw, pw, ph, ph)) if ph or pw else x_q
+    ho, wo = gy.shape[2], gy.shape[3]
+    gw = torch.stack([(xp[:, :, dy:dy + ho, dx:dx + wo] * gy).sum(dim=(0, 2, 3)) for dy in range(kh) for dx in range(kw)], dim=1)
+    return gx, gw.reshape(w_q.shape)
+
+
 class _BitConv2dFn(torch.autograd.Function):
+    """Forward: the fused HIP op.  Backward: the straight-through gradients of BitConv2d.forward (BitNetMCU.py:284-305; the detach()
+    terms carry none): dy / dx_norm and dy / dw are the convolution's gradients at the quantised operands x_int / x_scale and
+    w_int / w_scale, which the restated formula recomputes from the saved input; Normalize's own backward through autograd.  Depthwise
+    layers of stride 1 take `depthwise_conv_backward`; everything else the formula under autograd (the library's gradients)."""
+
     @staticmethod
     def forward(ctx, x, w, s, quant_type, norm_type, stride, padding, groups):
         ctx.save_for_backward(x, w, s)
@@ -341,6 +361,25 @@ class _BitConv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, s = ctx.saved_tensors
+        quant_type, norm_type, stride, padding, groups = ctx.cfg
+        depthwise = groups == x.shape[1] == w.shape[0] and w.shape[1] == 1 and _pair(stride) == (1, 1)
+        ph, pw = _pair(padding)
+        if depthwise and ph < w.shape[2] and pw < w.shape[3]:
+            with torch.enable_grad():
+                xr = x.detach().requires_grad_(norm_type != "None")
+                x_norm = xr if norm_type == "None" else xr / torch.sqrt(torch.mean(xr ** 2, dim=(-2, -1), keepdim=True))
+            with torch.no_grad():
+                if quant_type == "None":
+                    x_q, w_q = x_norm, w
+                else:
+                    x_int, x_scale = activation_quant(x_norm)
+                    x_q = x_int / x_scale
+                    w_int, w_scale = weight_quant(w, s, quant_type)
+                    w_q = w_int / w_scale
+                gx, gw = depthwise_conv_backward(gy.contiguous(), x_q, w_q, padding)
+            if norm_type != "None":
+                (gx,) = torch.autograd.grad(x_norm, xr, gx)
+            return gx, gw, None, None, None, None, None, None
         with torch.enable_grad():
             xr = x.detach().requires_grad_(True)
             wr = w.detach().requires_grad_(True)

@@ -221,3 +221,21 @@ def test_cnnmnist_module_mirrors_the_reference_module():
     assert "model.fc3.weight" in m4.state_dict() and m4.bitlinear_layers()[0].in_features == 128
     with pytest.raises(RuntimeError, match="GPU op"):
         m(torch.randn(2, 1, 16, 16))
+
+
+@pytest.mark.parametrize("pad,nt,qt", [(0, "None", "8bit"), (1, "None", "4bitsym"), (0, "RMS", "8bit"), (2, "RMS", "None")])
+def test_depthwise_backward_from_forward_passes_equals_autograd(pad, nt, qt):
+    """qat.depthwise_conv_backward + the straight-through rule (what _BitConv2dFn.backward does for depthwise layers) against autograd
+    through the restated BitConv2d formula, CPU: the same gradients up to float32 summation order."""
+    torch.manual_seed(pad + 7)
+    c, n = 6, 5
+    x = torch.randn(n, c, 9, 7)
+    w = torch.randn(c, 1, 3, 3) * 0.4
+    s = w.abs().mean() / 0.25
+    gy = torch.randn(n, c, 9 + 2 * pad - 2, 7 + 2 * pad - 2)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = torch.autograd.grad(qat.ste_conv_formula(xr, wr, s, qt, nt, padding=pad, groups=c), (xr, wr), gy)
+    ctx = type("Ctx", (), {"saved_tensors": (x, w, s), "cfg": (qt, nt, 1, pad, c)})()
+    gx, gw = qat._BitConv2dFn.backward(ctx, gy)[:2]
+    for a, b_ in ((gx, want[0]), (gw, want[1])):
+        assert a.shape == b_.shape and (a - b_).abs().max() <= 2e-5 * b_.abs().max()
