@@ -93,6 +93,7 @@ PROTOTYPES = {
     "bnm_qat_cnn_front_supported": (C.c_int, [C.c_uint32, _vp, _vp]),
     "bnm_qat_cnn_front_workspace_bytes": (C.c_uint64, [C.c_uint32]),
     "bnm_qat_cnn_front_forward_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
+    "bnm_qat_cnn_front_forward_train_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
     "bnm_synth_fill_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _vp]),
     "bnm_class_digest_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32, _vp]),
     "bnm_stream_read_device": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),

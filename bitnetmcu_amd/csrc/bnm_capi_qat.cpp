@@ -88,7 +88,16 @@ uint64_t bnm_qat_cnn_front_workspace_bytes(uint32_t channels) { return bnmk_qat_
 int bnm_qat_cnn_front_forward_device(const float *d_x, uint64_t n, uint32_t channels, const float *const *d_w, const float *const *d_s,
                                      const uint32_t *s_count, const int *quant_types, float *d_features, void *d_workspace,
                                      uint64_t workspace_bytes, void *stream) {
+    return bnm_qat_cnn_front_forward_train_device(d_x, n, channels, d_w, d_s, s_count, quant_types, d_features, nullptr, nullptr, nullptr,
+                                                  d_workspace, workspace_bytes, stream);
+}
+
+int bnm_qat_cnn_front_forward_train_device(const float *d_x, uint64_t n, uint32_t channels, const float *const *d_w, const float *const *d_s,
+                                           const uint32_t *s_count, const int *quant_types, float *d_features, float *d_y1, float *d_y2,
+                                           float *d_y3, void *d_workspace, uint64_t workspace_bytes, void *stream) {
     if (!d_w || !d_s || !s_count || !quant_types || !d_workspace || (n && (!d_x || !d_features))) return fail(BNM_EINVAL, "null pointer");
+    if ((d_y1 != nullptr) != (d_y2 != nullptr) || (d_y1 != nullptr) != (d_y3 != nullptr)) return fail(BNM_EINVAL, "d_y1, d_y2 and d_y3: all three or none");
+    if (((uintptr_t)d_y1 | (uintptr_t)d_y2 | (uintptr_t)d_y3) & 15u) return fail(BNM_EINVAL, "d_y1, d_y2 and d_y3 must be 16-byte aligned");
     for (int l = 0; l < 3; l++) {
         if (!d_w[l] || !d_s[l]) return fail(BNM_EINVAL, "null weight or clipping-scalar pointer");
         if (quant_types[l] < BNM_QAT_NONE || quant_types[l] > BNM_QAT_8BIT) return fail(BNM_EINVAL, "unknown quant_type");
@@ -100,7 +109,7 @@ int bnm_qat_cnn_front_forward_device(const float *d_x, uint64_t n, uint32_t chan
     if (((uintptr_t)d_workspace & 15u) || ((uintptr_t)d_features & 15u) || ((uintptr_t)d_x & 15u))
         return fail(BNM_EINVAL, "d_x, d_features and the workspace must be 16-byte aligned");
     if (n >= (1ull << 36)) return fail(BNM_EINVAL, "n too large for one call");
-    HIP_TRY(bnmk_qat_cnn_front_forward(d_x, n, channels, d_w, d_s, quant_types, d_features, d_workspace, (hipStream_t)stream));
+    HIP_TRY(bnmk_qat_cnn_front_forward(d_x, n, channels, d_w, d_s, quant_types, d_features, d_y1, d_y2, d_y3, d_workspace, (hipStream_t)stream));
     return BNM_OK;
 }
 

@@ -223,8 +223,10 @@ hipError_t bnmk_qat_model_forward(const float *d_x, uint64_t n, uint32_t n_layer
 // CNNMNIST's convolution front in one kernel (bnm_qat_cnn.hip): w / s / quant_types are three-element HOST arrays (conv1, conv2, conv3)
 bool bnmk_qat_cnn_front_supported(uint32_t channels, const uint32_t *s_count, const int *quant_types);
 size_t bnmk_qat_cnn_front_workspace_bytes(uint32_t channels);
+// d_y1 / d_y2 / d_y3: all null, or the training form's planes, CHANNELS-LAST: [n][14][14][C] / [n][12][12][C] / [n][4][4][C]
 hipError_t bnmk_qat_cnn_front_forward(const float *d_x, uint64_t n, uint32_t channels, const float *const *d_w, const float *const *d_s,
-                                      const int *quant_types, float *d_features, void *d_workspace, hipStream_t stream);
+                                      const int *quant_types, float *d_features, float *d_y1, float *d_y2, float *d_y3, void *d_workspace,
+                                      hipStream_t stream);
 // workspace: bnmk_qat_workspace_bytes((cin / groups) * kh * kw, cout) bytes; dynamic LDS: bnmk_qat_bitconv2d_lds_bytes (<= 160 KiB).
 size_t bnmk_qat_bitconv2d_lds_bytes(uint32_t cin, uint32_t h, uint32_t w, uint32_t cout, uint32_t kh, uint32_t kw, uint32_t pad,
                                     uint32_t groups);

@@ -136,10 +136,22 @@ __global__ __launch_bounds__(1024) void qat_cnn_prep_kernel(QatCnnPrepArgs a, ui
 }
 
 // ---- the front -----------------------------------------------------------------------------------------------------------------------
+// one row of W pairs -> a saved plane in CHANNELS-LAST order ([n][rows][W][C] floats): the pair (channel 2 p, channel 2 p + 1) of one
+// position is 8 consecutive bytes, the C / 2 lanes of an image write 4 C consecutive bytes per position - no repacking, whole lines
+template <int W>
+BNM_DEVICE void store_plane_row(const f32x2 (&row)[W], float *at, uint32_t channels) {
+#pragma unroll
+    for (int c = 0; c < W; c++) __builtin_nontemporal_store(row[c], (f32x2 *)(at + (size_t)c * channels));
+}
+
 // IPW images per wave (a power of two, IPW * C / 2 <= 64 lanes); four waves per workgroup, each with two IPW KiB staging buffers in LDS.
-template <int IPW>
+// SAVE (the training form): the three convolutions' outputs BEFORE their ReLU leave as well, channels-last - y1 [n][14][14][C],
+// y2 [n][12][12][C], y3 [n][4][4][C] (torch.channels_last tensors of shape [n, C, k, k]) -: with x and the weights all a backward pass
+// needs (ReLU masks, pooling arguments and every layer's input are functions of them).  356 C floats per image: bound by those writes.
+template <int IPW, bool SAVE>
 __global__ __launch_bounds__(256) void qat_cnn_front_kernel(const float *__restrict__ x, uint64_t n, const float *__restrict__ taps,
-                                                            uint32_t channels, float *__restrict__ features) {
+                                                            uint32_t channels, float *__restrict__ features, float *__restrict__ y1_out,
+                                                            float *__restrict__ y2_out, float *__restrict__ y3_out) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -201,6 +213,9 @@ __global__ __launch_bounds__(256) void qat_cnn_front_kernel(const float *__restr
         const uint64_t gn = g + total_waves;
         if (gn < groups) load_group(gn);
         const char *img = stage + cur * (IPW * 1024u) + slot * 1024u;
+        const uint64_t image = g * (uint64_t)IPW + (uint64_t)slot;
+        const bool mine = active && image < n;
+        const uint64_t saved = image < n ? image : 0ull;      // (the image's index in the saved planes)
 
         // rolling windows: three input rows, three rows of conv1's quantised outputs, two conv2 rows, three pooled rows, two conv3 rows
         f32x4 xin[3][4];
@@ -228,11 +243,17 @@ __global__ __launch_bounds__(256) void qat_cnn_front_kernel(const float *__restr
 #pragma unroll
                     for (int c = 0; c < 14; c++) y1[c] = __builtin_elementwise_fma(splat(row[(c + dx) >> 2][(c + dx) & 3]), w1[3 * dy + dx], y1[c]);
             }
+            if constexpr (SAVE) {
+                if (mine) store_plane_row<14>(y1, y1_out + ((saved * 14ull + r) * 14ull) * channels + 2u * p, channels);
+            }
             relu_quant_row<14>(y1);
             if constexpr (r >= 2) {
                 // ---- conv2 row r2 = r - 2 ----
                 constexpr int r2 = r - 2;
                 conv_row_pairs<12>(q1[r2 % 3], q1[(r2 + 1) % 3], q1[(r2 + 2) % 3], w2, c2[r2 & 1]);
+                if constexpr (SAVE) {
+                    if (mine) store_plane_row<12>(c2[r2 & 1], y2_out + ((saved * 12ull + r2) * 12ull) * channels + 2u * p, channels);
+                }
                 if constexpr (r2 & 1) {
                     // ---- pooled row k (ReLU inside its quantiser), conv3's activation_quant ----
                     constexpr int k = r2 >> 1;
@@ -241,6 +262,9 @@ __global__ __launch_bounds__(256) void qat_cnn_front_kernel(const float *__restr
                     if constexpr (k >= 2) {
                         constexpr int m = k - 2;
                         conv_row_pairs<4>(q2[m % 3], q2[(m + 1) % 3], q2[(m + 2) % 3], w3, c3[m & 1]);
+                        if constexpr (SAVE) {
+                            if (mine) store_plane_row<4>(c3[m & 1], y3_out + ((saved * 4ull + m) * 4ull) * channels + 2u * p, channels);
+                        }
                         if constexpr (m & 1) {
                             pool_rows<2>(c3[0], c3[1], out[m >> 1]);
 #pragma unroll
@@ -255,8 +279,7 @@ __global__ __launch_bounds__(256) void qat_cnn_front_kernel(const float *__restr
         if (gn < groups) quantise_group(stage + (cur ^ 1u) * (IPW * 1024u));
         __builtin_amdgcn_sched_barrier(0);
         // ---- features: channel a's 2 x 2, then channel b's: 32 consecutive bytes of the image's row ----
-        const uint64_t image = g * (uint64_t)IPW + (uint64_t)slot;
-        if (active && image < n) {
+        if (mine) {
             float *f = features + image * (uint64_t)(4u * channels) + 8u * p;
             __builtin_nontemporal_store(f32x4{out[0][0][0], out[0][1][0], out[1][0][0], out[1][1][0]}, (f32x4 *)f);
             __builtin_nontemporal_store(f32x4{out[0][0][1], out[0][1][1], out[1][0][1], out[1][1][1]}, (f32x4 *)(f + 4));
@@ -277,8 +300,9 @@ bool bnmk_qat_cnn_front_supported(uint32_t channels, const uint32_t *s_count, co
 
 size_t bnmk_qat_cnn_front_workspace_bytes(uint32_t channels) { return (size_t)3u * channels * 9u * sizeof(float); }
 
-template <int IPW>
-static hipError_t qat_cnn_front_launch(const float *x, uint64_t n, const float *taps, uint32_t channels, float *features, hipStream_t st) {
+template <int IPW, bool SAVE>
+static hipError_t qat_cnn_front_launch(const float *x, uint64_t n, const float *taps, uint32_t channels, float *features, float *y1, float *y2,
+                                       float *y3, hipStream_t st) {
     const uint64_t groups = (n + IPW - 1) / IPW;
     const size_t lds = 4u * 2u * IPW * 1024u;
     // persistent waves: as many workgroups as are resident at once (one per CU at this kernel's ~300 registers; asked once per
@@ -288,18 +312,29 @@ static hipError_t qat_cnn_front_launch(const float *x, uint64_t n, const float *
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     int per_cu = resident[dev].load(std::memory_order_relaxed);
     if (per_cu < 1) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qat_cnn_front_kernel<IPW>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qat_cnn_front_kernel<IPW, SAVE>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         resident[dev].store(per_cu, std::memory_order_relaxed);
     }
     uint64_t blocks = (groups + 3u) / 4u;
     const uint64_t cap = (uint64_t)bnm_num_cus() * (uint64_t)per_cu;
     if (blocks > cap) blocks = cap;
-    qat_cnn_front_kernel<IPW><<<dim3((unsigned)blocks), dim3(256), lds, st>>>(x, n, taps, channels, features);
+    qat_cnn_front_kernel<IPW, SAVE><<<dim3((unsigned)blocks), dim3(256), lds, st>>>(x, n, taps, channels, features, y1, y2, y3);
     return hipGetLastError();
 }
 
+template <bool SAVE>
+static hipError_t qat_cnn_front_go(const float *x, uint64_t n, const float *taps, uint32_t channels, float *features, float *y1, float *y2, float *y3,
+                                   hipStream_t st) {
+    const uint32_t pairs = channels / 2u, fit = 64u / pairs;
+    if (fit >= 8u) return qat_cnn_front_launch<8, SAVE>(x, n, taps, channels, features, y1, y2, y3, st);
+    if (fit >= 4u) return qat_cnn_front_launch<4, SAVE>(x, n, taps, channels, features, y1, y2, y3, st);
+    if (fit >= 2u) return qat_cnn_front_launch<2, SAVE>(x, n, taps, channels, features, y1, y2, y3, st);
+    return qat_cnn_front_launch<1, SAVE>(x, n, taps, channels, features, y1, y2, y3, st);
+}
+
 hipError_t bnmk_qat_cnn_front_forward(const float *x, uint64_t n, uint32_t channels, const float *const *w, const float *const *s,
-                                      const int *quant_types, float *features, void *workspace, hipStream_t st) {
+                                      const int *quant_types, float *features, float *y1, float *y2, float *y3, void *workspace,
+                                      hipStream_t st) {
     QatCnnPrepArgs a{};
     for (int l = 0; l < 3; l++) {
         a.w[l] = w[l];
@@ -310,9 +345,7 @@ hipError_t bnmk_qat_cnn_front_forward(const float *x, uint64_t n, uint32_t chann
     qat_cnn_prep_kernel<<<dim3(3), dim3(1024), 0, st>>>(a, channels, taps);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
-    const uint32_t pairs = channels / 2u, fit = 64u / pairs;
-    if (fit >= 8u) return qat_cnn_front_launch<8>(x, n, taps, channels, features, st);
-    if (fit >= 4u) return qat_cnn_front_launch<4>(x, n, taps, channels, features, st);
-    if (fit >= 2u) return qat_cnn_front_launch<2>(x, n, taps, channels, features, st);
-    return qat_cnn_front_launch<1>(x, n, taps, channels, features, st);
+    // the training form: all three planes or none (the C ABI checks)
+    return y1 ? qat_cnn_front_go<true>(x, n, taps, channels, features, y1, y2, y3, st)
+              : qat_cnn_front_go<false>(x, n, taps, channels, features, nullptr, nullptr, nullptr, st);
 }

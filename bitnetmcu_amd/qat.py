@@ -160,11 +160,12 @@ def cnn_front_supported(channels, scalars, quant_types=("8bit", "8bit", "8bit"))
     return bool(L.load().bnm_qat_cnn_front_supported(int(channels), counts, qa))
 
 
-def cnn_front_forward(x, weights, scalars, quant_types=("8bit", "8bit", "8bit")):
+def cnn_front_forward(x, weights, scalars, quant_types=("8bit", "8bit", "8bit"), return_planes=False):
     """The convolution front of the reference's CNNMNIST (models.py:109-119) - BitConv2d(1 -> C) / ReLU / depthwise BitConv2d / ReLU /
     MaxPool / depthwise BitConv2d / ReLU / MaxPool / Flatten, NormType 'None' - in ONE kernel (bnm_qat_cnn_front_forward_device,
     csrc/bnm_qat_cnn.hip).  x [n, 1, 16, 16] (or [n, 256]), weights three [C, 1, 3, 3] tensors, scalars their clipping scalars;
-    float32 CUDA tensors.  Returns the features [n, 4 C]."""
+    float32 CUDA tensors.  Returns the features [n, 4 C]; with return_planes (the training form) also the three convolutions' outputs
+    before their ReLU - y1 [n, C, 14, 14], y2 [n, C, 12, 12], y3 [n, C, 4, 4], torch.channels_last tensors."""
     if not x.is_cuda:
         raise RuntimeError("cnn_front_forward is a GPU op: x must be a CUDA tensor (there is no CPU path)")
     lib = L.load()
@@ -185,6 +186,8 @@ def cnn_front_forward(x, weights, scalars, quant_types=("8bit", "8bit", "8bit"))
     wp = (C.c_void_p * 3)(*[w.data_ptr() for w in ws])
     sp = (C.c_void_p * 3)(*[s.data_ptr() for s in ss])
     features = torch.empty((n, 4 * channels), dtype=torch.float32, device=x.device)
+    planes = [torch.empty((n, channels, k, k), dtype=torch.float32, device=x.device, memory_format=torch.channels_last) for k in (14, 12, 4)] \
+        if return_planes else [None] * 3
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream().cuda_stream
         key = (x.device.index, stream, channels)
@@ -192,10 +195,11 @@ def cnn_front_forward(x, weights, scalars, quant_types=("8bit", "8bit", "8bit"))
         if wsp is None:
             wsp = torch.empty((int(lib.bnm_qat_cnn_front_workspace_bytes(channels)) + 3) // 4, dtype=torch.float32, device=x.device)
             _front_workspaces[key] = wsp
-        L.check(lib, lib.bnm_qat_cnn_front_forward_device(
-            C.c_void_p(x2.data_ptr()), n, channels, wp, sp, sc, qa, C.c_void_p(features.data_ptr()), C.c_void_p(wsp.data_ptr()),
-            wsp.numel() * 4, C.c_void_p(stream)), "bnm_qat_cnn_front_forward_device")
-    return features
+        L.check(lib, lib.bnm_qat_cnn_front_forward_train_device(
+            C.c_void_p(x2.data_ptr()), n, channels, wp, sp, sc, qa, C.c_void_p(features.data_ptr()),
+            *[C.c_void_p(t.data_ptr()) if return_planes else None for t in planes], C.c_void_p(wsp.data_ptr()),
+            wsp.numel() * 4, C.c_void_p(stream)), "bnm_qat_cnn_front_forward_train_device")
+    return (features, *planes) if return_planes else features
 
 
 def _pair(v):
@@ -386,6 +390,65 @@ class _BitConv2dFn(torch.autograd.Function):
             y = ste_conv_formula(xr, wr, s.detach(), *ctx.cfg)
             gx, gw = torch.autograd.grad(y, (xr, wr), gy)
         return gx, gw, None, None, None, None, None, None
+
+
+def cnn_front_backward(x, y1, y2, y3, weights, scalars, quant_types, g_features, need_gx=True):
+    """Gradients of the convolution front from what its training form saved - the input and the three convolutions' outputs before their
+    ReLU.  Pooling and ReLU backward through autograd on those planes; every BitConv2d's straight-through gradients (BitNetMCU.py:284-305)
+    at the quantised operands, which are functions of the plane in front of the layer: the depthwise layers through
+    `depthwise_conv_backward`, conv1 (one input plane shared by all channels) as nine slice-multiply-reduce passes for the taps and -
+    only where the images themselves want a gradient - a library convolution for the input.  Returns (gx or None, [gw1, gw2, gw3])."""
+    n, channels = y1.shape[0], y1.shape[1]
+    g = g_features.reshape(n, channels, 2, 2)
+    gws = [None] * 3
+    with torch.enable_grad():
+        leaf = y3.detach().requires_grad_(True)
+        (g,) = torch.autograd.grad(F.max_pool2d(torch.relu(leaf), 2), leaf, g)
+    for l, plane in ((2, y2), (1, y1)):
+        with torch.enable_grad():
+            leaf = plane.detach().requires_grad_(True)
+            a = torch.relu(leaf)
+            a = F.max_pool2d(a, 2) if l == 2 else a      # the layer's input, as a function of the plane in front of it
+        with torch.no_grad():
+            if quant_types[l] == "None":
+                x_q, w_q = a, weights[l]
+            else:
+                x_int, x_scale = activation_quant(a)
+                x_q = x_int / x_scale
+                w_int, w_scale = weight_quant(weights[l], scalars[l], quant_types[l])
+                w_q = w_int / w_scale
+            ga, gws[l] = depthwise_conv_backward(g.contiguous(memory_format=torch.channels_last), x_q, w_q, 0)
+        (g,) = torch.autograd.grad(a, leaf, ga)
+    with torch.no_grad():
+        x4 = x.detach().reshape(n, 1, 16, 16)
+        if quant_types[0] == "None":
+            x_q, w_q = x4, weights[0]
+        else:
+            x_int, x_scale = activation_quant(x4)
+            x_q = x_int / x_scale
+            w_int, w_scale = weight_quant(weights[0], scalars[0], quant_types[0])
+            w_q = w_int / w_scale
+        gws[0] = torch.stack([(x_q[:, :, dy:dy + 14, dx:dx + 14] * g).sum(dim=(0, 2, 3)) for dy in range(3) for dx in range(3)], dim=1).reshape(weights[0].shape)
+        gx = F.conv_transpose2d(g, w_q) if need_gx else None
+    return gx, gws
+
+
+class _CNNFrontFn(torch.autograd.Function):
+    """Forward: the one-kernel front in its training form (the planes the backward needs are written once, by the kernel that computes
+    them).  Backward: cnn_front_backward - library calls and elementwise passes, no hand-written kernel."""
+
+    @staticmethod
+    def forward(ctx, x, quant_types, w1, w2, w3, s1, s2, s3):
+        features, y1, y2, y3 = cnn_front_forward(x, [w1, w2, w3], [s1, s2, s3], quant_types, return_planes=True)
+        ctx.save_for_backward(x, y1, y2, y3, w1, w2, w3, s1, s2, s3)
+        ctx.qts = tuple(quant_types)
+        return features
+
+    @staticmethod
+    def backward(ctx, g_features):
+        x, y1, y2, y3, w1, w2, w3, s1, s2, s3 = ctx.saved_tensors
+        gx, gws = cnn_front_backward(x, y1, y2, y3, [w1, w2, w3], [s1, s2, s3], ctx.qts, g_features, need_gx=ctx.needs_input_grad[0])
+        return (gx.reshape(x.shape) if gx is not None else None), None, gws[0], gws[1], gws[2], None, None, None
 
 
 def ste_backward(x, gy, norm_type, x_q, w_q):
@@ -617,8 +680,9 @@ class FCMNIST(nn.Module):
 class CNNMNIST(nn.Module):
     """Stand-in for the reference's CNNMNIST (models.py:93-139; the model trainingparameters.yaml names): same constructor, same
     module / parameter names (`model.0`, `model.2`, `model.5` the convolutions, `model.9`, `model.11`, `model.fc3`, `classifier`).
-    The depthwise-separable front runs as ONE kernel (`cnn_front_forward`) where no gradient is asked for (evaluation) and layer by
-    layer through `BitConv2d`'s op in training steps; the FC stack behind Flatten - 64 channels x 4
+    The depthwise-separable front runs as ONE kernel (`cnn_front_forward`; with a gradient asked for: its training form, which writes
+    the planes `cnn_front_backward` works from), layer by layer through `BitConv2d`'s op where the kernel does not serve the
+    configuration; the FC stack behind Flatten - 64 channels x 4
     = 256 inputs - runs as ONE kernel (`fc_model_forward`: per-layer QuantTypes: 2bitsym first, then `QuantType`) where the fused op
     serves the configuration, else layer by layer."""
 
@@ -647,17 +711,18 @@ class CNNMNIST(nn.Module):
         self.classifier = BitLinear(last_width, num_classes, QuantType=QuantType, NormType=NormType, WScale=WScale)
 
     def front_fused(self, x):
-        """True when front(x) runs as the one-kernel op: a CUDA batch of 16x16 images, nothing that needs a gradient (the backward
-        pass works from the per-layer ops' saved planes: training steps run layer by layer), a configuration the kernel serves."""
+        """True when front(x) runs as the one-kernel op: a CUDA batch of 16x16 images in a configuration the kernel serves (where a
+        gradient is asked for: in its training form, which also writes the planes the backward pass works from)."""
         convs = [m for m in list(self.model)[:9] if isinstance(m, BitConv2d)]
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(c.weight.requires_grad for c in convs))
-        return (x.is_cuda and not needs_grad and tuple(x.shape[1:]) == (1, 16, 16) and all(c.NormType == "None" for c in convs)
+        return (x.is_cuda and tuple(x.shape[1:]) == (1, 16, 16) and all(c.NormType == "None" for c in convs)
                 and cnn_front_supported(self.cnn_width, [c.s for c in convs], [c.QuantType for c in convs]))
 
     def front(self, x):
         """the convolution front up to and including Flatten (models.py:109-119)"""
         if self.front_fused(x):
             convs = [m for m in list(self.model)[:9] if isinstance(m, BitConv2d)]
+            if torch.is_grad_enabled() and (x.requires_grad or any(c.weight.requires_grad for c in convs)):
+                return _CNNFrontFn.apply(x, [c.QuantType for c in convs], *[c.weight for c in convs], *[c.s for c in convs])
             return cnn_front_forward(x, [c.weight for c in convs], [c.s for c in convs], [c.QuantType for c in convs])
         for m in list(self.model)[:9]:
             x = m(x)

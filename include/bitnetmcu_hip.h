@@ -365,6 +365,14 @@ BNM_API uint64_t bnm_qat_cnn_front_workspace_bytes(uint32_t channels);
 BNM_API int bnm_qat_cnn_front_forward_device(const float *d_x, uint64_t n, uint32_t channels, const float *const *d_w,
                                              const float *const *d_s, const uint32_t *s_count, const int *quant_types,
                                              float *d_features, void *d_workspace, uint64_t workspace_bytes, void *stream);
+/* The training form: the same call, which also writes the three convolutions' outputs BEFORE their ReLU, CHANNELS-LAST -
+ * d_y1 [n][14][14][C], d_y2 [n][12][12][C], d_y3 [n][4][4][C] (float32, 16-byte aligned: the NHWC memory order of an [n, C, k, k]
+ * tensor; all three or all NULL = the call above).  With d_x and the weights they are all a straight-through backward pass
+ * needs: every ReLU mask, pooling argument and layer input is a function of them.  356 C floats per image: bound by those writes. */
+BNM_API int bnm_qat_cnn_front_forward_train_device(const float *d_x, uint64_t n, uint32_t channels, const float *const *d_w,
+                                                   const float *const *d_s, const uint32_t *s_count, const int *quant_types,
+                                                   float *d_features, float *d_y1, float *d_y2, float *d_y3, void *d_workspace,
+                                                   uint64_t workspace_bytes, void *stream);
 
 /* ---- synthetic workload + digests ---------------------------------------- */
 #define BNM_DIST_U 0

@@ -67,9 +67,60 @@ def test_front_and_model_against_the_reference_module(gpu_ok):
     ref = GM["cnn/logits"]
     err = distances(y, ref)
     assert (err <= 5e-4).mean() >= 0.9 and err.max() <= 6e-2, ((err <= 5e-4).mean(), err.max())
-    # the per-layer path is the one a training step takes: same answers, same distances
+    # the per-layer path (what configurations outside the kernel take): same answers, same distances
     close(layer_by_layer(m, x), GM["cnn/features"], "layer by layer")
-    assert not m.front_fused(x.clone().requires_grad_(True))
+
+
+@pytest.mark.parametrize("channels", [16, 34, 64, 128])
+def test_training_form_writes_the_planes_the_backward_needs(channels, gpu_ok):
+    """The training form's features are the evaluation form's bit for bit; its planes y1 / y2 / y3 (the convolutions' outputs before
+    their ReLU, channels-last) are the per-layer ops' outputs within the file's tolerances (relative to the plane's largest value per
+    image); ragged batches; the features are the pooled ReLU of y3 exactly."""
+    torch.manual_seed(channels + 1)
+    m = qat.CNNMNIST(64, 64, 0, cnn_width=channels, QuantType="4bitsym").cuda()
+    convs = [c for c in m.model if isinstance(c, qat.BitConv2d)]
+    ws, ss, qts = [c.weight.detach() for c in convs], [c.s for c in convs], [c.QuantType for c in convs]
+    for n in (1, 3, 130, 1001):
+        x = torch.randn(n, 1, 16, 16, device="cuda") * (torch.rand(n, 1, 1, 1, device="cuda") * 2 + 0.05)
+        f, y1, y2, y3 = qat.cnn_front_forward(x, ws, ss, qts, return_planes=True)
+        assert torch.equal(f, qat.cnn_front_forward(x, ws, ss, qts))
+        assert y1.shape == (n, channels, 14, 14) and y2.shape == (n, channels, 12, 12) and y3.shape == (n, channels, 4, 4)
+        assert all(t.is_contiguous(memory_format=torch.channels_last) for t in (y1, y2, y3))
+        w1 = qat.bitconv2d_forward(x, ws[0], ss[0], qts[0], "None")
+        w2 = qat.bitconv2d_forward(torch.relu(w1), ws[1], ss[1], qts[1], "None", groups=channels)
+        w3 = qat.bitconv2d_forward(torch.nn.functional.max_pool2d(torch.relu(w2), 2), ws[2], ss[2], qts[2], "None", groups=channels)
+        for got, want, what in ((y1, w1, "y1"), (y2, w2, "y2"), (y3, w3, "y3")):
+            close(got.flatten(1), want.flatten(1), (channels, n, what))
+        assert torch.equal(f, torch.nn.functional.max_pool2d(torch.relu(y3), 2).flatten(1))
+
+
+def test_module_trains_through_the_fused_front(gpu_ok):
+    """With a gradient asked for, CNNMNIST's front runs in its training form and the backward works from the saved planes: the
+    gradients of the input and of all six weight tensors equal the per-layer path's (the layers called one by one) within the gradient
+    tolerances of tests/test_gpu_qat_model.py; images that want no gradient get none computed.  (The reference's own gradients:
+    test_cnnmnist_module_forward_backward there, through this same path.)"""
+    m = golden_module()
+    x = torch.from_numpy(GM["cnn/x"]).cuda().reshape(-1, 1, 16, 16)
+    gy = torch.from_numpy(GM["cnn/gy"]).cuda()
+    xa = x.clone().requires_grad_(True)
+    assert m.front_fused(xa)
+    (m(xa) * gy).sum().backward()
+    got = [xa.grad.clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+    m.zero_grad()
+    xb = x.clone().requires_grad_(True)
+    y = xb
+    for k in list(m.model):
+        y = k(y)
+    (m.classifier(y) * gy).sum().backward()
+    want = [xb.grad] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+    assert len(got) == len(want) == 7
+    for a, b_ in zip(got, want):
+        e = (a - b_).abs() / b_.abs().max()
+        assert e.median() <= 2e-3 and e.max() <= 0.15, (tuple(a.shape), float(e.median()), float(e.max()))
+    m.zero_grad()
+    (m(x) * gy).sum().backward()      # the usual case: data without a gradient
+    again = [p.grad for p in m.parameters() if p.grad is not None]
+    assert len(again) == 6 and all(torch.equal(a, b_) for a, b_ in zip(again, got[1:]))
 
 
 @pytest.mark.parametrize("channels", [16, 18, 32, 48, 64, 100, 128])

@@ -239,3 +239,27 @@ def test_depthwise_backward_from_forward_passes_equals_autograd(pad, nt, qt):
     gx, gw = qat._BitConv2dFn.backward(ctx, gy)[:2]
     for a, b_ in ((gx, want[0]), (gw, want[1])):
         assert a.shape == b_.shape and (a - b_).abs().max() <= 2e-5 * b_.abs().max()
+
+
+def test_front_backward_from_saved_planes_equals_autograd_through_the_whole_front():
+    """qat.cnn_front_backward (the fused front's backward: from x and the three convolutions' outputs before their ReLU) against
+    autograd through the composed formula - BitConv2d / ReLU / BitConv2d / ReLU / MaxPool / BitConv2d / ReLU / MaxPool / Flatten as
+    differentiable torch ops - on CPU, where the planes it is given are exactly the formula's: equal up to float32 rounding."""
+    torch.manual_seed(3)
+    channels, n = 6, 5
+    ws = [torch.randn(channels, 1, 3, 3) * 0.3 for _ in range(3)]
+    ss = [w.abs().mean() / 0.25 for w in ws]
+    qts = ["8bit", "4bitsym", "8bit"]
+    x = torch.randn(n, 1, 16, 16).requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    y1 = qat.ste_conv_formula(x, wr[0], ss[0], qts[0], "None", groups=1)
+    y2 = qat.ste_conv_formula(torch.relu(y1), wr[1], ss[1], qts[1], "None", groups=channels)
+    y3 = qat.ste_conv_formula(torch.nn.functional.max_pool2d(torch.relu(y2), 2), wr[2], ss[2], qts[2], "None", groups=channels)
+    f = torch.nn.functional.max_pool2d(torch.relu(y3), 2).flatten(1)
+    g = torch.randn_like(f)
+    want = torch.autograd.grad(f, [x] + wr, g)
+    planes = [t.detach().contiguous(memory_format=torch.channels_last) for t in (y1, y2, y3)]
+    gx, gws = qat.cnn_front_backward(x.detach(), *planes, ws, ss, qts, g)
+    for a, b_ in zip([gx] + gws, want):
+        assert a.shape == b_.shape and (a - b_).abs().max() <= 2e-5 * b_.abs().max().clamp(min=1e-30)
+    assert qat.cnn_front_backward(x.detach(), *planes, ws, ss, qts, g, need_gx=False)[0] is None
