@@ -286,3 +286,33 @@ def test_c_host_runs_the_whole_cnnmnist_forward(tmp_path, gpu_ok):
     ref = GM["cnn/logits"]
     err = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
     assert (err <= 5e-4).mean() >= 0.9 and err.max() <= 6e-2, ((err <= 5e-4).mean(), err.max())
+
+
+def test_two_streams_and_two_threads_do_not_share_scratch(gpu_ok):
+    """The taps / weight images of a call live in a workspace per (device, stream): the whole CNNMNIST forward on two side streams from
+    two host threads at once, different models and batches, gives each thread exactly what it gets alone."""
+    import threading
+    m1, m2 = golden_module(), qat.CNNMNIST(64, 48, 0, cnn_width=32, QuantType="8bit", NormType="Lin").cuda()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x1 = torch.randn(20_000, 1, 16, 16, device="cuda", generator=g)
+    x2 = torch.randn(33_333, 1, 16, 16, device="cuda", generator=g) * 3.0
+    with torch.no_grad():
+        alone = [m1(x1).clone(), m2(x2).clone()]
+    torch.cuda.synchronize()
+    got, errors = [None, None], []
+
+    def work(k, m, x):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s), torch.no_grad():
+                for _ in range(5):
+                    y = m(x)
+                s.synchronize()
+            got[k] = y
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(0, m1, x1)), threading.Thread(target=work, args=(1, m2, x2))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    assert torch.equal(got[0], alone[0]) and torch.equal(got[1], alone[1])
